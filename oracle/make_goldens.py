@@ -1,0 +1,301 @@
+"""Golden-vector generator — BUILD-CONTAINER ONLY (needs /root/reference; never runs on the GPU box).
+
+Imports the reference TRACE python package through a shim (the package is named `trace`, which
+shadows the stdlib module, and it imports timm/decord/... that are absent here), instantiates
+`TraceMistralForCausalLM` at the tiny geometry of `trace_amd.config.tiny()`, loads the synthetic
+weights of `trace_amd.synth`, runs the reference's own `forward()` for prefill and decode, and writes
+input/output vectors to tests/golden/.  Only data is written: no reference source or bytecode.
+
+    python oracle/make_goldens.py            # regenerates tests/golden/*
+
+transformers here is 5.15 (reference pins 4.40.1): `forward()` works, `generate()` does not
+(SURVEY.md §8c), so the greedy loop below restates trace_mistral.py:336-344 around forward().
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def install_shim():
+    tmp = tempfile.mkdtemp(prefix="trace_shim_")
+    os.symlink(REF, os.path.join(tmp, "Trace"))
+    sys.path.insert(0, tmp)
+    from transformers import (AutoConfig, AutoModelForCausalLM, MistralConfig, MistralModel,  # noqa: F401
+                              MistralForCausalLM, CLIPVisionModel, CLIPImageProcessor, CLIPVisionConfig,
+                              PreTrainedTokenizer, AutoTokenizer, StoppingCriteria, PretrainedConfig,
+                              BitsAndBytesConfig)
+    sys.modules["transformers"].TRANSFORMERS_CACHE = "/tmp/hf"
+
+    def mod(name, **a):
+        m = types.ModuleType(name)
+        m.__dict__.update(a)
+        sys.modules[name] = m
+
+    class LN(nn.LayerNorm):  # timm.models.layers.LayerNorm: eps defaults to 1e-6
+        def __init__(s, c, eps=1e-6, affine=True):
+            super().__init__(c, eps=eps, elementwise_affine=affine)
+
+    mod("timm"); mod("timm.models"); mod("timm.models.regnet", RegStage=None)
+    mod("timm.models.layers", LayerNorm=LN, LayerNorm2d=LN)
+    mod("decord", VideoReader=None, cpu=None); mod("imageio"); mod("moviepy")
+    mod("moviepy.editor", VideoFileClip=None)
+    mod("scenedetect", open_video=None, SceneManager=None)
+    mod("scenedetect.detectors", ContentDetector=None)
+    mod("scenedetect.stats_manager", StatsManager=None)
+    return tmp
+
+
+def build_reference_model(cfg, tmp):
+    from transformers import CLIPVisionConfig, CLIPVisionModel, CLIPImageProcessor
+    from Trace.trace.model import TraceMistralForCausalLM, TraceMistralConfig
+    clip_dir = os.path.join(tmp, "tiny-clip")
+    vc = CLIPVisionConfig(hidden_size=cfg.vision_hidden_size, intermediate_size=cfg.vision_intermediate_size,
+                          num_hidden_layers=cfg.vision_num_layers, num_attention_heads=cfg.vision_num_heads,
+                          image_size=cfg.vision_image_size, patch_size=cfg.vision_patch_size,
+                          hidden_act="quick_gelu", layer_norm_eps=cfg.vision_layer_norm_eps)
+    CLIPVisionModel(vc).save_pretrained(clip_dir)
+    CLIPImageProcessor(size={"shortest_edge": cfg.vision_image_size},
+                       crop_size={"height": cfg.vision_image_size, "width": cfg.vision_image_size}
+                       ).save_pretrained(clip_dir)
+    mc = TraceMistralConfig(
+        vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+        num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+        num_key_value_heads=cfg.num_key_value_heads, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+        max_position_embeddings=cfg.max_position_embeddings, sliding_window=None,
+        time_vocab_size=cfg.time_vocab_size, score_vocab_size=cfg.score_vocab_size,
+        mm_vision_tower=clip_dir, mm_vision_select_layer=cfg.mm_vision_select_layer,
+        mm_vision_select_feature="patch", mm_projector_type="spatial_slot", mm_hidden_size=cfg.mm_hidden_size,
+        num_frames=cfg.num_frames, downsample_num=1, attn_implementation="eager",
+    )
+    model = TraceMistralForCausalLM(mc).float().eval()
+    return model
+
+
+def load_synth(model, cfg):
+    from trace_amd import synth
+    sd_ref = model.state_dict()
+    mine = synth.state_dict(cfg, dtype=torch.bfloat16)
+    used = set()
+    new = {}
+    for k in sd_ref:
+        cand = [k, k.replace("vision_tower.vision_tower.", "vision_tower.vision_tower.vision_model.")]
+        hit = next((c for c in cand if c in mine), None)
+        if hit is None:
+            if "position_ids" in k or "inv_freq" in k or "cached" in k:
+                new[k] = sd_ref[k]
+                continue
+            raise KeyError(f"no synthetic tensor for reference key {k}")
+        assert tuple(mine[hit].shape) == tuple(sd_ref[k].shape), (k, mine[hit].shape, sd_ref[k].shape)
+        new[k] = mine[hit].float()
+        used.add(hit)
+    unused = [k for k in mine if k not in used]
+    assert not unused, f"synthetic tensors with no reference counterpart: {unused[:5]}"
+    model.load_state_dict(new, strict=True)
+    return sorted(sd_ref.keys())
+
+
+def scripted_ids(cfg):
+    """A DVC-shaped stream visiting all three heads: time digits, <sep>, digits, time-<sync>,
+    score digits, score-<sync>, some text, text-<sync>, then time again."""
+    V, Tv = cfg.vocab_size, cfg.time_vocab_size
+    t0, s0 = V + 1, V + Tv + 1
+    dig = lambda base, s: [base + {"<sync>": 0, "<sep>": 1, ".": 12, **{str(i): i + 2 for i in range(10)}}[c] for c in s]
+    seq = dig(t0, "0012.5") + [t0 + 1] + dig(t0, "0031.0") + [t0]
+    seq += dig(s0, "4.5") + [s0]
+    seq += [17, 45, 203, 99, 7, 311, 28] + [V]
+    seq += dig(t0, "0040.2") + [t0 + 1] + dig(t0, "0055.9") + [t0]
+    seq += dig(s0, "3.0") + [s0] + [5, 150, 62] + [V]
+    return seq
+
+
+@torch.no_grad()
+def run_reference(model, cfg, input_ids, frames, ts, forced=None, n_new=24):
+    """prefill + decode loop over the reference forward(); returns per-step masked logits + argmax ids."""
+    heads = [1]
+    ids = input_ids.view(1, -1)
+    out = model(input_ids=ids, attention_mask=torch.ones_like(ids), images=[[frames], ["video"]], times=[[]],
+                scores=[[]], video_timestamps=[ts], heads=heads, use_cache=True, return_dict=True)
+    pkv = out.past_key_values
+    L = out.logits.shape[1]
+    step_logits, toks = [], []
+    lg = out.logits[0, -1]
+    mask_len = L
+    n = len(forced) + 1 if forced is not None else n_new
+    for step in range(n):
+        step_logits.append(lg.clone())
+        tok = int(torch.argmax(lg))
+        toks.append(tok)
+        if step == n - 1:
+            break
+        feed = tok if forced is None else int(forced[step])
+        heads[0] = model.swap_tokens.get(feed, heads[0])            # trace_mistral.py:336-344
+        mask_len += 1
+        o = model(input_ids=torch.tensor([[feed]]), attention_mask=torch.ones(1, mask_len, dtype=torch.long),
+                  past_key_values=pkv, heads=heads, use_cache=True, return_dict=True)
+        pkv = o.past_key_values
+        lg = o.logits[0, -1]
+    return torch.stack(step_logits), toks, L
+
+
+def fp_goldens(tmp):
+    from trace_amd import config as tcfg, synth
+    cfg = tcfg.tiny(num_frames=4)
+    model = build_reference_model(cfg, tmp)
+    keys = load_synth(model, cfg)
+    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16).float()
+    ts = [[float(i) * 2.5] for i in range(cfg.num_frames)]
+    input_ids = synth.synth_prompt_ids(cfg, n_text=24, video_pos=10)
+
+    # stage captures through the reference's own modules
+    with torch.no_grad():
+        vt = model.get_model().get_vision_tower()
+        feats = vt(frames)                                                           # clip_encoder.py:41-53
+        slots = model.get_model().mm_projector(feats[None])                          # [1,T,8,H]
+        vfeat = model.encode_images_or_videos([frames], ["video"], [ts])             # [1,T*14,H]
+        (_, _, _, embeds, _, _, _) = model.prepare_inputs_labels_for_multimodal(
+            input_ids.view(1, -1), torch.ones(1, input_ids.numel(), dtype=torch.long), None, None,
+            [[frames], ["video"]], [[]], [[]], video_timestamps=[ts])
+        # NB: never pass output_hidden_states=True to the outer model here: on transformers 5.x that
+        # installs capture hooks which also fire inside the nested CLIP tower, duplicating entries of
+        # its hidden_states tuple so that hidden_states[-2] silently becomes the LAST layer's output
+        # (4.40.1 semantics, pinned by the reference's requirements.txt, is N+1 entries -> layer N-1).
+        cap = {}
+        h0 = model.model.layers[0].register_forward_hook(lambda m, i, o: cap.__setitem__("l0", o[0] if isinstance(o, tuple) else o))
+        hs = model.model(inputs_embeds=embeds, use_cache=False, return_dict=True)
+        h0.remove()
+        clip_hs = vt.vision_tower(frames, output_hidden_states=True).hidden_states
+        assert len(clip_hs) == cfg.vision_num_layers + 1, len(clip_hs)
+    free_logits, free_ids, L = run_reference(model, cfg, input_ids, frames, ts, n_new=40)
+    forced = scripted_ids(cfg)
+    tf_logits, tf_argmax, _ = run_reference(model, cfg, input_ids, frames, ts, forced=forced)
+
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(
+        os.path.join(OUT, "tiny_e2e.npz"),
+        input_ids=input_ids.numpy(), timestamps=np.array(ts, dtype=np.float64),
+        vit_feats=feats.numpy().astype(np.float32),
+        slots=slots[0].numpy().astype(np.float32),
+        video_feats_rows=vfeat[0, ::7].numpy().astype(np.float32),
+        embeds_rows=embeds[0, ::5].numpy().astype(np.float32),
+        hidden_last_rows=hs.last_hidden_state[0, -4:].numpy().astype(np.float32),
+        layer0_last_row=cap["l0"][0, -1].numpy().astype(np.float32),
+        prefill_len=np.array(L),
+        free_logits=free_logits.numpy().astype(np.float32), free_ids=np.array(free_ids),
+        forced_ids=np.array(forced), tf_logits=tf_logits.numpy().astype(np.float32),
+        tf_argmax=np.array(tf_argmax),
+    )
+    with open(os.path.join(OUT, "reference_state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0)
+    with torch.no_grad():
+        assert torch.equal(vt(frames), feats), "reference CLIP feature selection changed state mid-run"
+    print("tiny_e2e: L=%d free_ids=%s" % (L, free_ids))
+    print("tf_argmax", tf_argmax)
+
+    # B=2 equal-length batch (reference supports it): second video + same prompt
+    frames2 = synth.synth_frames(cfg, 1).to(torch.bfloat16).float()
+    l2, ids2, _ = run_reference(model, cfg, input_ids, frames2, ts, n_new=16)
+    np.savez_compressed(os.path.join(OUT, "tiny_video1.npz"), free_logits=l2.numpy().astype(np.float32),
+                        free_ids=np.array(ids2))
+
+
+def int_goldens():
+    """Integer / string functions of the path captured from the reference modules."""
+    from Trace.trace.model.multimodal_encoder.time_encoder import TimeTower, TimeTokenizer
+    from Trace.trace.model.multimodal_encoder.score_encoder import ScoreTower, ScoreTokenizer
+    from Trace.trace import conversation as conv_mod
+    from Trace.trace import mm_utils as ref_mm
+    from Trace.trace import constants as ref_const
+    G = {}
+    tt, st = TimeTower(TimeTokenizer(), hidden_dim=8), ScoreTower(ScoreTokenizer(), hidden_dim=8)
+    tcases = [[12.3, 45.6], [0.0], [1234.56], [], [9999.0], [0.04], [0.05], [0.15], [99999.9], [7.0, 8.25, 100.0], [3.14159]]
+    scases = [[4.5], [10.0], [], [0.0], [3.0, 2.5], [9.96], [0.04]]
+    G["time_encode"] = [{"in": c, "out": tt.encode(c).tolist()} for c in tcases]
+    G["score_encode"] = [{"in": c, "out": st.encode(c).tolist()} for c in scases]
+    G["time_decode"] = [{"in": i, "out": TimeTokenizer().decode(i)} for i in range(13)]
+    G["score_decode"] = [{"in": i, "out": ScoreTokenizer().decode(torch.tensor(i))} for i in range(13)]
+    G["time_vocab"] = TimeTokenizer().get_vocab()
+
+    # prompts: llama_2 template with each task prompt file (evaluate.py:327-332)
+    prompts = {}
+    pdir = os.path.join(REF, "trace", "prompts")
+    for fn in sorted(os.listdir(pdir)):
+        q = open(os.path.join(pdir, fn)).read()
+        conv = conv_mod.conv_templates["llama_2"].copy()
+        conv.append_message(conv.roles[0], "<video>\n" + q)
+        conv.append_message(conv.roles[1], None)
+        prompts[fn] = {"question": q, "prompt": conv.get_prompt() + "<sync>"}
+    conv = conv_mod.conv_templates["llama_2"].copy()
+    conv.append_message(conv.roles[0], "<video>\nhello")
+    conv.append_message(conv.roles[1], "an answer")
+    conv.append_message(conv.roles[0], "second turn")
+    conv.append_message(conv.roles[1], None)
+    prompts["_multi_turn"] = {"prompt": conv.get_prompt()}
+    G["llama2_prompts"] = prompts
+    G["llama2_sep"] = [conv_mod.conv_templates["llama_2"].sep, conv_mod.conv_templates["llama_2"].sep2]
+
+    # tokenizer_MMODAL_token_all with a fake whitespace tokenizer (no sentencepiece model offline)
+    class FakeTok:
+        bos_token_id = 1
+
+        def __call__(self, text):
+            return types.SimpleNamespace(input_ids=[1] + [10 + len(w) for w in text.split()])
+
+    cases = ["a bb <video>\nccc dd [/INST]<sync>", "<video>\nxx", "no modal here", "x <time> y <score> z <sync>",
+             "<image> a <video> b <audio> c", "<sync>", "lead <sync><sync> tail"]
+    G["tokenizer_MMODAL_token_all"] = [
+        {"in": c, "out": ref_mm.tokenizer_MMODAL_token_all(c, FakeTok(), return_tensors="pt").tolist()} for c in cases]
+    G["tokenizer_MMODAL_token_video"] = [
+        {"in": c, "out": ref_mm.tokenizer_MMODAL_token(c, FakeTok(), -201, return_tensors="pt").tolist()}
+        for c in ["a <video> b", "<video>\nq", "plain"]]
+    G["get_model_name_from_path"] = [{"in": p, "out": ref_mm.get_model_name_from_path(p)}
+                                     for p in ["/a/b/trace-7b/", "x/checkpoint-100", "trace"]]
+    G["constants"] = {k: getattr(ref_const, k) for k in
+                      ["NUM_FRAMES", "MAX_FRAMES", "IGNORE_INDEX", "IMAGE_TOKEN_INDEX", "MMODAL_TOKEN_INDEX",
+                       "DEFAULT_MMODAL_TOKEN", "NUM_FRAMES_PER_SECOND"]}
+
+    # frame sampling arithmetic of process_video (mm_utils.py:379-437): uniform linspace + timestamps
+    fs = []
+    for duration, fps, n in [(300, 30.0, 8), (3000, 25.0, 128), (100, 29.97, 64), (50, 10.0, 128), (7, 1.0, 8), (1, 24.0, 4)]:
+        idx = np.linspace(0, duration - 1, n, dtype=int)
+        if len(idx) > ref_const.MAX_FRAMES:
+            idx = np.linspace(0, duration - 1, ref_const.MAX_FRAMES, dtype=int)
+        fs.append({"duration": duration, "fps": fps, "num_frames": n, "indices": idx.tolist(),
+                   "timestamps": [[float(i / fps)] for i in idx]})
+    G["frame_sample_uniform"] = fs
+
+    # expand2square on small synthetic images (mm_utils.py:259-270)
+    from PIL import Image
+    e2s = []
+    rng = np.random.RandomState(0)
+    for (w, h) in [(6, 4), (3, 7), (5, 5)]:
+        arr = rng.randint(0, 255, size=(h, w, 3), dtype=np.uint8)
+        bg = tuple(int(x * 255) for x in [0.48145466, 0.4578275, 0.40821073])
+        out = ref_mm.expand2square(Image.fromarray(arr), bg)
+        e2s.append({"in": arr.tolist(), "bg": list(bg), "out": np.array(out).tolist()})
+    G["expand2square"] = e2s
+
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "host_functions.json"), "w") as f:
+        json.dump(G, f, indent=0)
+    print("host_functions.json written:", list(G.keys()))
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    tmp = install_shim()
+    int_goldens()
+    fp_goldens(tmp)

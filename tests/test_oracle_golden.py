@@ -1,0 +1,124 @@
+"""Pins the oracle (oracle/trace_oracle.py) against vectors captured from the reference itself
+(oracle/make_goldens.py, run in the build container).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import trace_oracle as O
+from trace_amd import config as tcfg, synth
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "host_functions.json")))
+
+
+@pytest.fixture(scope="module")
+def E(golden_dir):
+    return np.load(os.path.join(golden_dir, "tiny_e2e.npz"))
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    cfg = tcfg.tiny(num_frames=4)
+    return O.Oracle(cfg, synth.state_dict(cfg), emulate_bf16=False)
+
+
+def test_time_score_encode(G):
+    for c in G["time_encode"]:
+        assert O.time_encode(c["in"]) == c["out"], c
+    for c in G["score_encode"]:
+        assert O.score_encode(c["in"]) == c["out"], c
+    for c in G["time_decode"]:
+        assert O.num_decode([c["in"]]) == c["out"]
+    for c in G["score_decode"]:
+        assert O.num_decode([c["in"]]) == c["out"]
+    assert G["time_vocab"] == O.NUM_VOCAB
+
+
+def test_known_values_from_survey():
+    # SURVEY.md §4 probed values
+    assert O.time_encode([12.3, 45.6]) == [2, 2, 3, 4, 12, 5, 1, 2, 2, 6, 7, 12, 8, 0]
+    assert O.time_encode([]) == [0]
+    assert O.score_encode([10.0]) == [3, 2, 12, 2, 0]
+
+
+def _frames(cfg, idx=0):
+    return synth.synth_frames(cfg, idx).to(torch.bfloat16).float()
+
+
+def test_vit_and_slots(oracle, E):
+    cfg = oracle.cfg
+    feats = oracle.vit_forward(_frames(cfg))
+    np.testing.assert_allclose(feats.numpy(), E["vit_feats"], rtol=1e-4, atol=2e-5)
+    slots = oracle.slot_pool(feats)
+    np.testing.assert_allclose(slots.numpy(), E["slots"], rtol=1e-4, atol=2e-5)
+
+
+def test_splice_and_hidden(oracle, E):
+    cfg = oracle.cfg
+    ts = E["timestamps"].tolist()
+    vf = oracle.encode_video(_frames(cfg), ts)
+    np.testing.assert_allclose(vf[::7].numpy(), E["video_feats_rows"], rtol=1e-4, atol=2e-5)
+    emb = oracle.splice(torch.from_numpy(E["input_ids"]), vf)
+    assert emb.shape[0] == int(E["prefill_len"])
+    np.testing.assert_allclose(emb[::5].numpy(), E["embeds_rows"], rtol=1e-4, atol=2e-5)
+    hidden, kv, layers = oracle.llm_forward(emb, return_layers=True)
+    np.testing.assert_allclose(layers[0][-1].numpy(), E["layer0_last_row"], rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(hidden[-4:].numpy(), E["hidden_last_rows"], rtol=2e-4, atol=5e-5)
+
+
+def _cmp_logits(a, b):
+    fin = np.isfinite(b)
+    assert (np.isfinite(a) == fin).all()
+    np.testing.assert_allclose(a[fin], b[fin], rtol=2e-4, atol=1e-4)
+
+
+def test_greedy_free_run(oracle, E):
+    cfg = oracle.cfg
+    ids, lg = oracle.generate(torch.from_numpy(E["input_ids"]), _frames(cfg), E["timestamps"].tolist(), head=1,
+                              max_new_tokens=len(E["free_ids"]), return_logits=True)
+    assert ids == E["free_ids"].tolist()
+    _cmp_logits(lg.numpy(), E["free_logits"])
+
+
+def test_teacher_forced_all_heads(oracle, E):
+    cfg = oracle.cfg
+    forced = E["forced_ids"].tolist()
+    ids, lg = oracle.generate(torch.from_numpy(E["input_ids"]), _frames(cfg), E["timestamps"].tolist(), head=1,
+                              max_new_tokens=len(forced) + 1, forced_ids=forced, return_logits=True)
+    assert ids == E["tf_argmax"].tolist()
+    _cmp_logits(lg.numpy(), E["tf_logits"])
+    # all three heads visited
+    V, Tv = cfg.vocab_size, cfg.time_vocab_size
+    a = np.array(ids)
+    assert (a <= V).any() and ((a > V) & (a <= V + Tv)).any() and (a > V + Tv).any()
+
+
+def test_second_video(oracle, golden_dir):
+    cfg = oracle.cfg
+    E1 = np.load(os.path.join(golden_dir, "tiny_video1.npz"))
+    E0 = np.load(os.path.join(golden_dir, "tiny_e2e.npz"))
+    ids, lg = oracle.generate(torch.from_numpy(E0["input_ids"]), _frames(cfg, 1), E0["timestamps"].tolist(), head=1,
+                              max_new_tokens=len(E1["free_ids"]), return_logits=True)
+    assert ids == E1["free_ids"].tolist()
+    _cmp_logits(lg.numpy(), E1["free_logits"])
+
+
+def test_parse_output_ids():
+    cfg = tcfg.trace_7b()
+    V = 32000
+    t = lambda s: [32001 + O.NUM_VOCAB[c] for c in s]
+    s = lambda s_: [32014 + O.NUM_VOCAB[c] for c in s_]
+    ids = t("0012.5") + [32002] + t("0031.0") + [32001] + s("4.5") + [32014] + [5, 6, 7] + [V]
+    out = O.parse_output_ids(cfg, ids)
+    assert out["timestamps"] == [[12.5, 31.0]] and out["scores"] == [[4.5]] and out["captions"] == [[5, 6, 7]]
+
+
+def test_swap_head():
+    cfg = tcfg.trace_7b()
+    assert O.swap_head(cfg, 32000, 0) == 1 and O.swap_head(cfg, 32001, 1) == 2 and O.swap_head(cfg, 32014, 2) == 0
+    assert O.swap_head(cfg, 17, 0) == 0 and O.swap_head(cfg, 32005, 1) == 1

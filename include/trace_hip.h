@@ -1,0 +1,112 @@
+/* libtrace_hip.so — C ABI of the MI355X-native TRACE inference hot path.
+ *
+ * The reference (gyxxyg/TRACE) is 100% Python and has no FFI of its own; its arithmetic lives in
+ * transformers/torch.  This header is the boundary a maintainer binds instead (ctypes stub in INTEGRATION.md):
+ * everything from the sampled frame tensor to the greedy token ids.  Each entry point cites the reference
+ * interface it replaces (paths relative to the reference repo root).
+ *
+ * Conventions: extern "C"; every function returns 0 on success or a negative TRACE_ERR_* code, the message is
+ * available from trace_last_error(); no C++ exceptions cross the ABI; pointers are raw device (or, where
+ * stated, host) addresses + explicit sizes; `stream` is a hipStream_t passed as void* (0 = default stream).
+ * A trace_ctx owns its weights, KV cache and workspaces (hipMalloc) and is not thread-safe; one per process/GPU.
+ * All device tensors are bf16 (uint16 bit patterns) unless stated.
+ */
+#ifndef TRACE_HIP_H
+#define TRACE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRACE_ABI_VERSION 1
+
+typedef struct trace_ctx trace_ctx;
+
+/* Geometry: the config.json keys the reference reads (trace/model/language_model/trace_mistral.py:84-96,
+ * trace/model/multimodal_encoder/clip_encoder.py:15-16, trace/model/multimodal_projector/builder.py:413-421). */
+typedef struct trace_config {
+    int32_t vocab_size, hidden_size, intermediate_size, num_layers, num_heads, num_kv_heads;
+    int32_t time_vocab, score_vocab;
+    float rms_eps, rope_theta;
+    int32_t v_hidden, v_inter, v_layers_used, v_heads, v_image, v_patch;
+    float v_eps;
+    int32_t num_slots;
+    float slot_eps, slot_rope_base;
+    int32_t max_frames;      /* largest T per video                                    */
+    int32_t max_ctx;         /* KV-cache length per sequence slot (prefill + new tokens) */
+    int32_t max_batch;       /* sequence slots (videos decoded together), <= 16          */
+    int32_t max_new_tokens;  /* capacity of the on-device output id buffer               */
+} trace_config;
+
+const char* trace_last_error(void);
+int trace_abi_version(void);
+
+/* from_pretrained (trace/model/builder.py:113-114): create, stream tensors in by their reference state-dict
+ * names (bf16; `on_device` says whether `data` is a device or host pointer), then finalize. */
+int trace_ctx_create(const trace_config* cfg, int device_id, trace_ctx** out);
+int trace_ctx_destroy(trace_ctx* ctx);
+int trace_ctx_load_tensor(trace_ctx* ctx, const char* name, const void* data, int on_device, const int64_t* shape,
+                          int ndim);
+int trace_ctx_finalize(trace_ctx* ctx);
+int64_t trace_ctx_device_bytes(trace_ctx* ctx);
+
+/* CLIPVisionTower.forward + feature_select (trace/model/multimodal_encoder/clip_encoder.py:31-53):
+ * frames [T,3,S,S] (dtype 0 = bf16, 1 = fp32, device) -> features [T, patches, v_hidden] bf16 = hidden state
+ * after encoder layer v_layers_used, CLS dropped.  feats_out may be NULL (kept internally for trace_slot_pool). */
+int trace_vit_forward(trace_ctx* ctx, const void* frames, int frames_dtype, int T, void* feats_out, void* stream);
+
+/* SpatialSlotPool.forward (trace/model/multimodal_projector/builder.py:427-467): feats (NULL = the internal
+ * buffer of the last trace_vit_forward) -> slots_out [T, num_slots, hidden]; slots_out may be NULL. */
+int trace_slot_pool(trace_ctx* ctx, const void* feats, int T, void* slots_out, void* stream);
+
+/* encode_images_or_videos (trace/model/trace_arch.py:218-266): ViT + slot pool + per-frame time-token embedding;
+ * time_ids is HOST int32 [T, 6] (TimeTower.encode(t)[:-1]).  Result [T*(slots+6), hidden] stays internal;
+ * video_out (device, may be NULL) receives a copy. */
+int trace_encode_video(trace_ctx* ctx, const void* frames, int frames_dtype, int T, const int32_t* time_ids,
+                       void* video_out, void* stream);
+
+/* prepare_inputs_labels_for_multimodal, prefill branch (trace/model/trace_arch.py:377-456): HOST ids with the
+ * modal placeholders (-201 video, -203 time, -204 score, -205 sync); the single video placeholder expands to
+ * the rows of the last trace_encode_video.  time_rows/score_rows: HOST tower row ids consumed in order by the
+ * -203/-204 placeholders (may be NULL).  Writes the spliced embeddings internally, returns their length in
+ * *L_out; embeds_out (device [L,hidden], may be NULL) receives a copy. */
+int trace_splice_embeds(trace_ctx* ctx, const int32_t* ids, int n_ids, const int32_t* time_rows, int n_time,
+                        const int32_t* score_rows, int n_score, int* L_out, void* embeds_out, void* stream);
+
+/* TraceMistralForCausalLM.forward, prefill (trace/model/language_model/trace_mistral.py:114-264): runs the L
+ * spliced rows (embeds == NULL: internal buffer) through the decoder into KV slot `slot`.  hidden_out (device
+ * [L,hidden] bf16, may be NULL) receives the final-norm hidden states (tests). */
+int trace_llm_prefill(trace_ctx* ctx, int slot, const void* embeds, int L, void* hidden_out, void* stream);
+
+/* generate() = greedy loop with head switching (trace_mistral.py:268-347 + HF greedy search).
+ * begin: sequences = the given KV slots (each prefilled); heads[b] in {0 text,1 time,2 score} (callers pass [1]);
+ *        computes token 0 from the prefill hidden state.  forced: HOST [B, max_new] teacher-forcing ids or NULL.
+ *        eos < 0 disables the stop.  logits_out (device fp32 [B, V+1+Tv+Sv], may be NULL) = masked logits of step 0.
+ * steps: runs n more decode steps entirely on device (use_graph: hipGraph replay; logits_out only with n == 1).
+ * read : synchronises and copies ids [B, max_new] / lengths [B] / current heads [B] to HOST buffers. */
+int trace_decode_begin(trace_ctx* ctx, const int32_t* slots, int B, const int32_t* heads, int max_new, int eos,
+                       const int32_t* forced, float* logits_out, void* stream);
+int trace_decode_steps(trace_ctx* ctx, int n, int use_graph, float* logits_out, void* stream);
+int trace_decode_read(trace_ctx* ctx, int32_t* out_ids, int32_t* out_len, int32_t* heads, void* stream);
+
+/* Timing hook for bench.py: average device time (ms, hipEvents on `stream`) of the last trace_decode_steps call
+ * per step, and of its skinny-GEMM launches if profiling was enabled with trace_set_profile(ctx, 1). */
+int trace_set_profile(trace_ctx* ctx, int on);
+int trace_get_profile(trace_ctx* ctx, float* out, int n);
+
+/* ---- kernel-level entry points (unit tests / microbenchmarks; raw device pointers) ---- */
+int trace_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* R,
+                  int ldr, int M, int N, int K, int epilogue, void* stream);
+int trace_op_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, float eps, void* stream);
+int trace_op_rmsnorm(const void* x, void* y, const void* w, int rows, int D, float eps, void* stream);
+int trace_op_attention(const void* Q, const void* K, const void* V, void* O, void* vt_scratch, int batch, int heads,
+                       int kv_heads, int nq, int nkv, int head_dim, int causal, float scale, void* stream);
+int trace_op_skinny_gemm(const void* X, const void* W, void* out, const void* R, int B, int N, int K, int epilogue,
+                         void* stream);
+int trace_op_attn_decode(const void* q, const void* kcache, const void* vcache, const int32_t* pos, void* O, float* ws,
+                         int B, int nq, int nkv, int max_ctx, int nsplit, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -144,7 +144,7 @@ class Oracle:
         # patch-embed conv, stride = kernel = P, no bias (modeling_clip.py:148-154,208-211) as a GEMM
         pw = W[VIS + "embeddings.patch_embedding.weight"].reshape(vh, 3 * P * P)
         patches = x.reshape(T, 3, g, P, g, P).permute(0, 2, 4, 1, 3, 5).reshape(T, g * g, 3 * P * P)
-        pe = patches @ pw.t()
+        pe = r(patches @ pw.t())
         cls = W[VIS + "embeddings.class_embedding"].reshape(1, 1, vh).expand(T, 1, vh)
         x = torch.cat([cls, pe], dim=1) + W[VIS + "embeddings.position_embedding.weight"][None]
         x = r(x)
@@ -164,11 +164,11 @@ class Oracle:
             s = (q @ k.transpose(-1, -2)) * (hd ** -0.5)          # modeling_clip.py:261-277
             pattn = torch.softmax(s, dim=-1)
             o = r((pattn @ v).transpose(1, 2).reshape(T, N, vh))
-            x = r(x + o @ W[p + "self_attn.out_proj.weight"].t() + W[p + "self_attn.out_proj.bias"])
+            x = r(x + r(o @ W[p + "self_attn.out_proj.weight"].t() + W[p + "self_attn.out_proj.bias"]))
             h = r(self._ln(x, W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], c.vision_layer_norm_eps))
             u = h @ W[p + "mlp.fc1.weight"].t() + W[p + "mlp.fc1.bias"]
             u = r(u * torch.sigmoid(1.702 * u))                    # quick_gelu
-            x = r(x + u @ W[p + "mlp.fc2.weight"].t() + W[p + "mlp.fc2.bias"])
+            x = r(x + r(u @ W[p + "mlp.fc2.weight"].t() + W[p + "mlp.fc2.bias"]))
             hs.append(x)
         feats = x[:, 1:]
         return (feats, hs) if return_all else feats
@@ -287,12 +287,12 @@ class Oracle:
             s = s.masked_fill(mask[None], float("-inf"))
             pa = torch.softmax(s, dim=-1)
             o = r(torch.einsum("hlc,chd->lhd", pa, vv).reshape(L, nq * hd))
-            x = r(x + o @ W[p + "self_attn.o_proj.weight"].t())
+            x = r(x + r(o @ W[p + "self_attn.o_proj.weight"].t()))
             h = r(self._rms(x, W[p + "post_attention_layernorm.weight"]))
             g = h @ W[p + "mlp.gate_proj.weight"].t()
             u = h @ W[p + "mlp.up_proj.weight"].t()
             a = r(torch.nn.functional.silu(g) * u)
-            x = r(x + a @ W[p + "mlp.down_proj.weight"].t())
+            x = r(x + r(a @ W[p + "mlp.down_proj.weight"].t()))
             layers.append(x)
         hidden = r(self._rms(x, W["model.norm.weight"]))
         if return_layers:

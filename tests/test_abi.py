@@ -1,0 +1,52 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports every
+symbol include/trace_hip.h declares.  No compute calls (no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from trace_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "trace_hip.h")).read()
+    declared = set(re.findall(r"\b(trace_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"trace_ctx", "trace_config"}
+    from trace_amd._lib import SIGNATURES
+    assert declared == set(SIGNATURES), declared ^ set(SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_abi_version_and_error_string(lib):
+    assert lib.trace_abi_version() == 1
+    assert isinstance(lib.trace_last_error(), (bytes, type(None)))
+
+
+def test_config_struct_matches_header():
+    from trace_amd._lib import TraceConfigC
+    hdr = open(os.path.join(ROOT, "include", "trace_hip.h")).read()
+    body = hdr[hdr.index("typedef struct trace_config {"):hdr.index("} trace_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in re.findall(r"(?:int32_t|float)\s+([^;]+);", body):
+        names += [n.strip() for n in decl.split(",")]
+    assert names == [f[0] for f in TraceConfigC._fields_]
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from trace_amd import config as tcfg
+    from trace_amd.engine import TraceEngine
+    from trace_amd._lib import TraceHipError
+    with pytest.raises(TraceHipError, match="no CPU fallback"):
+        TraceEngine(tcfg.tiny())

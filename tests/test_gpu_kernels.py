@@ -1,0 +1,160 @@
+"""Kernel-level parity on the GPU: every HIP kernel against a plain PyTorch fp32 reference of the same op
+(bf16 inputs, fp32 math), called through the C ABI (trace_op_* entry points).  Tolerances are stated per test:
+bf16 outputs carry 2^-8 relative rounding, accumulation is fp32."""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a HIP device", allow_module_level=True)
+
+from trace_amd import engine as E  # noqa: E402
+from trace_amd.engine import ops  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(DEV)
+
+
+def check(name, got, ref, atol, rtol):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any() or not torch.isfinite(got).all():
+        idx = torch.nonzero(bad)
+        rows = torch.unique(idx[:, 0])[:16].tolist() if idx.numel() else []
+        cols = torch.unique(idx[:, -1])[:16].tolist() if idx.numel() else []
+        first = idx[0].tolist() if idx.numel() else None
+        msg = (f"{name}: {int(bad.sum())}/{bad.numel()} elements off; max err {err.max().item():.4g} "
+               f"(ref max {ref.abs().max().item():.4g}); first bad {first} got "
+               f"{got[tuple(first)].item() if first else None} ref {ref[tuple(first)].item() if first else None}; "
+               f"bad rows {rows} cols {cols}; finite={torch.isfinite(got).all().item()}")
+        pytest.fail(msg)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 256, 128), (577, 384, 1024), (1, 128, 64), (1000, 1024, 640)])
+def test_gemm_plain_bias(M, N, K):
+    A, W, b = rnd(M, K), rnd(N, K, scale=0.05), rnd(N, scale=0.5)
+    ref = A.float() @ W.float().t() + b.float()
+    check("gemm+bias", ops.gemm(A, W, bias=b), ref, 2e-2, 1e-2)
+    check("gemm", ops.gemm(A, W), A.float() @ W.float().t(), 2e-2, 1e-2)
+
+
+def test_gemm_asymmetric_layout():
+    # transpose-detecting: A rows and W rows carry different, non-symmetric patterns
+    M, N, K = 256, 256, 128
+    A = torch.zeros(M, K)
+    W = torch.zeros(N, K)
+    for i in range(M):
+        A[i, i % K] = 1.0 + (i % 7)
+    for j in range(N):
+        W[j, (3 * j) % K] = 0.5 + (j % 5)
+    A, W = A.to(torch.bfloat16).to(DEV), W.to(torch.bfloat16).to(DEV)
+    check("gemm layout", ops.gemm(A, W), A.float() @ W.float().t(), 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (64, 128, 4096)])
+def test_gemm_epilogues(M, N, K):
+    A, W, b, R = rnd(M, K), rnd(N, K, scale=0.05), rnd(N, scale=0.5), rnd(M, N)
+    lin = A.float() @ W.float().t() + b.float()
+    check("residual", ops.gemm(A, W, bias=b, R=R, epilogue=E.EPI_RESIDUAL), lin.to(torch.bfloat16).float() + R.float(), 3e-2, 1e-2)
+    check("quickgelu", ops.gemm(A, W, bias=b, epilogue=E.EPI_QUICKGELU), lin * torch.sigmoid(1.702 * lin), 2e-2, 1e-2)
+    # SwiGLU on 16-row interleaved [gate|up] weights
+    Wg, Wu = rnd(N // 2, K, scale=0.05, seed=1), rnd(N // 2, K, scale=0.05, seed=2)
+    Wp = torch.stack([Wg.view(-1, 16, K), Wu.view(-1, 16, K)], dim=1).reshape(N, K).contiguous()
+    g, u = A.float() @ Wg.float().t(), A.float() @ Wu.float().t()
+    check("swiglu", ops.gemm(A, Wp, epilogue=E.EPI_SWIGLU), torch.nn.functional.silu(g) * u, 2e-2, 1e-2)
+
+
+def test_gemm_residual_in_place():
+    M, N, K = 130, 128, 64
+    A, W, R = rnd(M, K), rnd(N, K, scale=0.1), rnd(M, N)
+    ref = (A.float() @ W.float().t()).to(torch.bfloat16).float() + R.float()
+    lib = E._lib.load()
+    Rc = R.clone()
+    E._lib.check(lib.trace_op_gemm(E._ptr(A), K, E._ptr(W), K, E._ptr(Rc), N, None, E._ptr(Rc), N, M, N, K, E.EPI_RESIDUAL, E._stream()))
+    check("residual in place", Rc, ref, 3e-2, 1e-2)
+
+
+@pytest.mark.parametrize("rows,D", [(5, 128), (577, 1024), (33, 4096)])
+def test_norms(rows, D):
+    x, w, b = rnd(rows, D, scale=2.0), 1 + rnd(D, scale=0.1), rnd(D, scale=0.1)
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5)
+    check("layernorm", ops.layernorm(x, w, b, 1e-5), ref, 2e-2, 1e-2)
+    xf = x.float()
+    ref = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * w.float()
+    check("rmsnorm", ops.rmsnorm(x, w, 1e-5), ref, 2e-2, 1e-2)
+
+
+def _attn_ref(q, k, v, causal, scale):
+    Bn, nq, heads, hd = q.shape
+    nkv, kvh = k.shape[1], k.shape[2]
+    qf = q.float().permute(0, 2, 1, 3)
+    kf = k.float().permute(0, 2, 1, 3).repeat_interleave(heads // kvh, dim=1)
+    vf = v.float().permute(0, 2, 1, 3).repeat_interleave(heads // kvh, dim=1)
+    s = qf @ kf.transpose(-1, -2) * scale
+    if causal:
+        off = nkv - nq
+        mask = torch.arange(nkv, device=q.device)[None, :] > (torch.arange(nq, device=q.device)[:, None] + off)
+        s = s.masked_fill(mask, float("-inf"))
+    return (torch.softmax(s, dim=-1) @ vf).permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("Bn,n,heads", [(2, 17, 2), (3, 577, 16), (1, 64, 1), (1, 130, 4)])
+def test_attention_vit(Bn, n, heads):
+    q, k, v = rnd(Bn, n, heads, 64, seed=1), rnd(Bn, n, heads, 64, seed=2), rnd(Bn, n, heads, 64, seed=3)
+    check("attn vit", ops.attention(q, k, v, False, 0.125), _attn_ref(q, k, v, False, 0.125), 2e-2, 2e-2)
+
+
+def test_attention_vit_spiked_scores():
+    # forces large running-max jumps between kv tiles (online-softmax rescale path)
+    Bn, n, heads = 1, 200, 2
+    q, k, v = rnd(Bn, n, heads, 64, seed=1), rnd(Bn, n, heads, 64, seed=2), rnd(Bn, n, heads, 64, seed=3)
+    k[:, 150] = q[:, 10] * 4
+    k[:, 70] = q[:, 11] * 6
+    check("attn spike", ops.attention(q, k, v, False, 0.125), _attn_ref(q, k, v, False, 0.125), 3e-2, 2e-2)
+
+
+@pytest.mark.parametrize("L,kvh", [(79, 8), (200, 2), (1, 1), (64, 1), (333, 8)])
+def test_attention_prefill_causal_gqa(L, kvh):
+    q = rnd(1, L, 4 * kvh, 128, seed=1)
+    k, v = rnd(1, L, kvh, 128, seed=2), rnd(1, L, kvh, 128, seed=3)
+    sc = 1 / math.sqrt(128)
+    check("attn prefill", ops.attention(q, k, v, True, sc), _attn_ref(q, k, v, True, sc), 2e-2, 2e-2)
+
+
+@pytest.mark.parametrize("Bn,N,K", [(1, 128, 256), (1, 4096, 4096), (3, 6144, 4096), (16, 256, 14336), (2, 512, 128)])
+def test_skinny_gemm(Bn, N, K):
+    X, W, R = rnd(Bn, K), rnd(N, K, scale=0.05), rnd(Bn, N)
+    lin = X.float() @ W.float().t()
+    check("skinny", ops.skinny_gemm(X, W), lin, 3e-2, 1e-2)
+    check("skinny+res", ops.skinny_gemm(X, W, R=R, epilogue=E.EPI_RESIDUAL), lin.to(torch.bfloat16).float() + R.float(), 4e-2, 1e-2)
+    if N % 32 == 0:
+        Wg, Wu = W[: N // 2], W[N // 2:]
+        Wp = torch.stack([Wg.reshape(-1, 16, K), Wu.reshape(-1, 16, K)], dim=1).reshape(N, K).contiguous()
+        g, u = X.float() @ Wg.float().t(), X.float() @ Wu.float().t()
+        check("skinny swiglu", ops.skinny_gemm(X, Wp, epilogue=E.EPI_SWIGLU), torch.nn.functional.silu(g) * u, 3e-2, 1e-2)
+
+
+@pytest.mark.parametrize("Bn,ctxs", [(1, [80]), (3, [1, 200, 2047]), (2, [16, 17])])
+def test_attn_decode(Bn, ctxs):
+    nq, nkv, max_ctx = 32, 8, 2048
+    q = rnd(Bn, nq * 128, seed=4)
+    kc, vc = rnd(Bn, nkv, max_ctx, 128, seed=5), rnd(Bn, nkv, max_ctx, 128, seed=6)
+    pos = torch.tensor([c - 1 for c in ctxs], dtype=torch.int32, device=DEV)
+    sc = 1 / math.sqrt(128)
+    out = ops.attn_decode(q, kc, vc, pos, 16, sc)
+    for b, ctx in enumerate(ctxs):
+        qq = q[b].view(1, 1, nq, 128)
+        kk = kc[b, :, :ctx].permute(1, 0, 2).unsqueeze(0)
+        vv = vc[b, :, :ctx].permute(1, 0, 2).unsqueeze(0)
+        ref = _attn_ref(qq, kk, vv, False, sc).reshape(-1)
+        check(f"attn decode b{b}", out[b], ref, 2e-2, 2e-2)

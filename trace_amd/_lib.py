@@ -1,0 +1,85 @@
+"""ctypes binding of libtrace_hip.so (C ABI: include/trace_hip.h).  No CPU fallback: importing the
+symbols fails loudly if the library has not been built (`python -m trace_amd.build`)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtrace_hip.so")
+
+
+class TraceConfigC(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("intermediate_size", C.c_int32),
+        ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32),
+        ("time_vocab", C.c_int32), ("score_vocab", C.c_int32),
+        ("rms_eps", C.c_float), ("rope_theta", C.c_float),
+        ("v_hidden", C.c_int32), ("v_inter", C.c_int32), ("v_layers_used", C.c_int32), ("v_heads", C.c_int32),
+        ("v_image", C.c_int32), ("v_patch", C.c_int32),
+        ("v_eps", C.c_float),
+        ("num_slots", C.c_int32),
+        ("slot_eps", C.c_float), ("slot_rope_base", C.c_float),
+        ("max_frames", C.c_int32), ("max_ctx", C.c_int32), ("max_batch", C.c_int32), ("max_new_tokens", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/trace_hip.h declares
+P, I, F = C.c_void_p, C.c_int, C.c_float
+SIGNATURES = {
+    "trace_last_error": (C.c_char_p, []),
+    "trace_abi_version": (I, []),
+    "trace_ctx_create": (I, [C.POINTER(TraceConfigC), I, C.POINTER(P)]),
+    "trace_ctx_destroy": (I, [P]),
+    "trace_ctx_load_tensor": (I, [P, C.c_char_p, P, I, C.POINTER(C.c_int64), I]),
+    "trace_ctx_finalize": (I, [P]),
+    "trace_ctx_device_bytes": (C.c_int64, [P]),
+    "trace_vit_forward": (I, [P, P, I, I, P, P]),
+    "trace_slot_pool": (I, [P, P, I, P, P]),
+    "trace_encode_video": (I, [P, P, I, I, P, P, P]),
+    "trace_splice_embeds": (I, [P, P, I, P, I, P, I, C.POINTER(I), P, P]),
+    "trace_llm_prefill": (I, [P, I, P, I, P, P]),
+    "trace_decode_begin": (I, [P, P, I, P, I, I, P, P, P]),
+    "trace_decode_steps": (I, [P, I, I, P, P]),
+    "trace_decode_read": (I, [P, P, P, P, P]),
+    "trace_set_profile": (I, [P, I]),
+    "trace_get_profile": (I, [P, P, I]),
+    "trace_op_gemm": (I, [P, I, P, I, P, I, P, P, I, I, I, I, I, P]),
+    "trace_op_layernorm": (I, [P, P, P, P, I, I, F, P]),
+    "trace_op_rmsnorm": (I, [P, P, P, I, I, F, P]),
+    "trace_op_attention": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
+    "trace_op_skinny_gemm": (I, [P, P, P, P, I, I, I, I, P]),
+    "trace_op_attn_decode": (I, [P, P, P, P, P, P, I, I, I, I, I, F, P]),
+}
+
+_lib = None
+
+
+class TraceHipError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TraceHipError(
+            f"{LIB_PATH} is missing: build it with `python -m trace_amd.build` (hipcc, gfx950). "
+            "trace_amd has no CPU or PyTorch fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.trace_abi_version() != 1:
+        raise TraceHipError("libtrace_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        msg = load().trace_last_error()
+        raise TraceHipError(f"libtrace_hip error {rc}: {msg.decode() if msg else '?'}")
+    return rc

@@ -1,0 +1,47 @@
+// Shared device helpers for the TRACE gfx950 kernels.  CDNA4 only: wave = 64 lanes, MFMA 16x16x32 /
+// 32x32x16 bf16 with fp32 accumulators, LDS 160 KiB/CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;                                                   // raw bf16 bits in HBM
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;                // MFMA A/B fragment (8 bf16 = 4 VGPR)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;                 // 16x16 MFMA C/D fragment
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;               // 32x32 MFMA C/D fragment
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float bflo(uint32_t v) { return __uint_as_float(v << 16); }          // low half of a packed pair
+__device__ __forceinline__ float bfhi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }  // high half
+// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware bijective remap of a 1-D block id: the dispatcher places block b on XCD b%8, so give each
+// XCD a contiguous chunk of logical tile ids (neighbouring tiles share operand panels in that XCD's L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+#define TRACE_OK 0
+#define TRACE_ERR_ARG (-1)
+#define TRACE_ERR_HIP (-2)
+#define TRACE_ERR_STATE (-3)

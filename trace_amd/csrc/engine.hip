@@ -1,0 +1,679 @@
+// Engine behind include/trace_hip.h: owns weights (repacked for the kernels), KV cache and workspaces, and
+// sequences the HIP kernels for the three phases of the path
+//   video encode (CLIP ViT -> SpatialSlotPool -> [slots | time tokens])  -> splice -> Mistral prefill
+//   -> on-device greedy decode with head switching (hipGraph-replayed step, no host round trip per token).
+// One context per process / GPU; videos are independent, so multi-GPU is one context per rank (trace_amd/dist.py).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/trace_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& m) { g_err = m; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(TRACE_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+#define TRY(x) do { int r_ = (x); if (r_ != TRACE_OK) { if (g_err.empty()) g_err = std::string("failed: ") + #x; return r_; } } while (0)
+
+struct VitLayer { bf16_t *ln1w, *ln1b, *wqkv, *bqkv, *wo, *bo, *ln2w, *ln2b, *w1, *b1, *w2, *b2; };
+struct LlmLayer { bf16_t *rms1, *wqkv, *wo, *rms2, *wgu, *wd; };
+
+struct trace_ctx {
+    trace_config c{};
+    int dev = 0;
+    // derived
+    int H, I, NL, NQ, NKV, HD, V, Tv, Sv, NV, NVpad, QKV;
+    int vh, vi, vL, vheads, G, GG, NT, P, Kpatch, Kpad, tokpad;
+    int S, TPF;                      // slots per frame, tokens per frame (slots + 6)
+    int max_ctx, max_B, ctx_pad;
+    std::vector<void*> allocs;
+    size_t total_bytes = 0;
+    std::unordered_map<std::string, int> loaded;
+    bool finalized = false;
+    // weights
+    bf16_t *patch_w, *cls, *pos_emb, *pre_w, *pre_b;
+    std::vector<VitLayer> vit;
+    bf16_t *sl_lnw, *sl_lnb, *sl_slots, *sl_readout;
+    bf16_t *embed, *final_norm, *wheads, *time_tab, *score_tab, *sync_row;
+    std::vector<LlmLayer> llm;
+    float *slot_cos, *slot_sin, *rope_cos, *rope_sin;
+    // KV cache: [layer][slot][kvh][max_ctx][hd]
+    bf16_t *kcache, *vcache;
+    size_t kv_head_stride, slot_stride, layer_stride;
+    // ViT workspaces
+    bf16_t *vX, *vH, *vQKV, *vVT, *vMLP;
+    bf16_t *sl_res, *sl_out, *video;     // [T*S, vh], [T*S, H], [T*TPF, H]
+    int video_rows = 0;
+    // LLM prefill workspaces
+    bf16_t *pX, *pH, *pQKV, *pVT, *pO, *pACT;
+    int32_t *d_kind, *d_row;             // splice index arrays (max_ctx)
+    int32_t *h_kind, *h_row;             // pinned host staging
+    int spliced_len = 0;
+    // decode state
+    bf16_t *dX, *dH, *dQKV, *dO, *dACT, *xlast;   // [16, *]
+    float* attn_ws;
+    float* part_val; int32_t* part_idx;
+    int32_t *d_slots, *d_pos, *d_heads, *d_done, *d_out_ids, *d_out_len, *d_step, *d_forced;
+    int B = 0, max_new = 0, eos = -1, has_forced = 0, ntiles = 0, nsplit = 16;
+    int slot_len[16] = {0};
+    hipGraphExec_t graphs[17] = {nullptr};
+    hipStream_t cap_stream = nullptr;
+    // profiling
+    int profile = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float prof[8] = {0};
+};
+
+template <typename T>
+static int dalloc(trace_ctx* c, T** p, size_t n_elems) {
+    void* q = nullptr;
+    const size_t bytes = (n_elems * sizeof(T) + 255) & ~(size_t)255;
+    HIPCHK(hipMalloc(&q, bytes));
+    HIPCHK(hipMemset(q, 0, bytes));
+    c->allocs.push_back(q);
+    c->total_bytes += bytes;
+    *p = (T*)q;
+    return TRACE_OK;
+}
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+extern "C" const char* trace_last_error(void) { return g_err.c_str(); }
+extern "C" int trace_abi_version(void) { return TRACE_ABI_VERSION; }
+
+extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ctx** out) {
+    if (!cfg || !out) return fail(TRACE_ERR_ARG, "null argument");
+    g_err.clear();
+    HIPCHK(hipSetDevice(device_id));
+    trace_ctx* c = new trace_ctx();
+    c->c = *cfg;
+    c->dev = device_id;
+    c->H = cfg->hidden_size; c->I = cfg->intermediate_size; c->NL = cfg->num_layers;
+    c->NQ = cfg->num_heads; c->NKV = cfg->num_kv_heads; c->HD = c->H / c->NQ;
+    c->V = cfg->vocab_size; c->Tv = cfg->time_vocab; c->Sv = cfg->score_vocab;
+    c->NV = c->V + 1 + c->Tv + c->Sv; c->NVpad = round_up(c->NV, 16);
+    c->QKV = (c->NQ + 2 * c->NKV) * c->HD;
+    c->vh = cfg->v_hidden; c->vi = cfg->v_inter; c->vL = cfg->v_layers_used; c->vheads = cfg->v_heads;
+    c->P = cfg->v_patch; c->G = cfg->v_image / cfg->v_patch; c->GG = c->G * c->G; c->NT = c->GG + 1;
+    c->Kpatch = 3 * c->P * c->P; c->Kpad = round_up(c->Kpatch, 64); c->tokpad = round_up(c->NT, 64);
+    c->S = cfg->num_slots; c->TPF = c->S + 6;
+    c->max_ctx = cfg->max_ctx; c->max_B = cfg->max_batch; c->ctx_pad = round_up(c->max_ctx, 64);
+    auto bad = [&](const char* m) { delete c; return fail(TRACE_ERR_ARG, m); };
+    if (c->HD != 128 || c->NQ != 4 * c->NKV) return bad("LLM kernels need head_dim 128 and 4:1 GQA");
+    if (c->vh / c->vheads != 64) return bad("ViT kernels need head_dim 64");
+    if (c->H % 128 || c->I % 128 || c->vh % 128 || c->vi % 128 || c->QKV % 128) return bad("dims must be multiples of 128");
+    if (c->S != 8 || c->vh > 1024) return bad("slot pool kernel needs 8 slots and mm_hidden <= 1024");
+    if (c->max_B < 1 || c->max_B > 16) return bad("max_batch must be in [1,16]");
+    if (c->max_ctx > 16 * 1024) return bad("max_ctx too large for the decode attention split");
+    if (cfg->max_frames < 1 || cfg->max_frames * c->TPF > c->max_ctx) return bad("max_frames*14 exceeds max_ctx");
+    if (c->Tv != 13 || c->Sv != 13) { /* any size works; kept for clarity */ }
+
+    const size_t H = c->H, I = c->I, vh = c->vh, vi = c->vi;
+    int rc = TRACE_OK;
+#define A(p, n) if (rc == TRACE_OK) rc = dalloc(c, &(p), (size_t)(n))
+    // --- weights ---
+    A(c->patch_w, vh * c->Kpad); A(c->cls, vh); A(c->pos_emb, (size_t)c->NT * vh); A(c->pre_w, vh); A(c->pre_b, vh);
+    c->vit.resize(c->vL);
+    for (auto& l : c->vit) {
+        A(l.ln1w, vh); A(l.ln1b, vh); A(l.wqkv, 3 * vh * vh); A(l.bqkv, 3 * vh); A(l.wo, vh * vh); A(l.bo, vh);
+        A(l.ln2w, vh); A(l.ln2b, vh); A(l.w1, vi * vh); A(l.b1, vi); A(l.w2, vh * vi); A(l.b2, vh);
+    }
+    A(c->sl_lnw, vh); A(c->sl_lnb, vh); A(c->sl_slots, vh * c->S); A(c->sl_readout, H * vh);
+    A(c->embed, (size_t)c->V * H); A(c->final_norm, H); A(c->wheads, (size_t)c->NVpad * H);
+    A(c->time_tab, (size_t)c->Tv * H); A(c->score_tab, (size_t)c->Sv * H); A(c->sync_row, H);
+    c->llm.resize(c->NL);
+    for (auto& l : c->llm) {
+        A(l.rms1, H); A(l.wqkv, (size_t)c->QKV * H); A(l.wo, H * H); A(l.rms2, H); A(l.wgu, 2 * I * H); A(l.wd, H * I);
+    }
+    A(c->slot_cos, (size_t)c->GG * vh / 2); A(c->slot_sin, (size_t)c->GG * vh / 2);
+    A(c->rope_cos, (size_t)c->max_ctx * c->HD / 2); A(c->rope_sin, (size_t)c->max_ctx * c->HD / 2);
+    // --- KV cache ---
+    c->kv_head_stride = (size_t)c->max_ctx * c->HD;
+    c->slot_stride = c->kv_head_stride * c->NKV;
+    c->layer_stride = c->slot_stride * c->max_B;
+    A(c->kcache, c->layer_stride * c->NL); A(c->vcache, c->layer_stride * c->NL);
+    // --- ViT workspaces ---
+    const size_t Tm = cfg->max_frames, Mv = Tm * c->NT;
+    A(c->vX, Mv * vh); A(c->vH, Mv * vh); A(c->vQKV, Mv * 3 * vh); A(c->vVT, Tm * vh * c->tokpad);
+    {
+        const size_t mlp = Mv * vi, im2 = Tm * c->GG * c->Kpad;
+        A(c->vMLP, mlp > im2 ? mlp : im2);
+    }
+    A(c->sl_res, Tm * c->S * vh); A(c->sl_out, Tm * c->S * H); A(c->video, Tm * c->TPF * H);
+    // --- prefill workspaces ---
+    const size_t Lm = c->max_ctx;
+    A(c->pX, Lm * H); A(c->pH, Lm * H); A(c->pQKV, Lm * c->QKV); A(c->pVT, (size_t)c->NKV * c->HD * c->ctx_pad);
+    A(c->pO, Lm * H); A(c->pACT, Lm * I);
+    A(c->d_kind, Lm); A(c->d_row, Lm);
+    // --- decode ---
+    A(c->dX, 16 * H); A(c->dH, 16 * H); A(c->dQKV, 16 * (size_t)c->QKV); A(c->dO, 16 * H); A(c->dACT, 16 * I);
+    A(c->xlast, 16 * H);
+    A(c->attn_ws, (size_t)16 * c->NQ * c->nsplit * (c->HD + 2));
+    c->ntiles = c->NVpad / 16;
+    A(c->part_val, (size_t)16 * c->ntiles); A(c->part_idx, (size_t)16 * c->ntiles);
+    A(c->d_slots, 16); A(c->d_pos, 16); A(c->d_heads, 16); A(c->d_done, 16); A(c->d_out_len, 16); A(c->d_step, 4);
+    A(c->d_out_ids, (size_t)16 * cfg->max_new_tokens); A(c->d_forced, (size_t)16 * cfg->max_new_tokens);
+#undef A
+    if (rc == TRACE_OK && hipHostMalloc((void**)&c->h_kind, Lm * 8) != hipSuccess) rc = fail(TRACE_ERR_HIP, "hipHostMalloc");
+    if (rc != TRACE_OK) { trace_ctx_destroy(c); return rc; }
+    c->h_row = c->h_kind + Lm;
+    hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking);
+    hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
+    *out = c;
+    return TRACE_OK;
+}
+
+extern "C" int trace_ctx_destroy(trace_ctx* c) {
+    if (!c) return TRACE_OK;
+    hipDeviceSynchronize();
+    for (auto& g : c->graphs) if (g) hipGraphExecDestroy(g);
+    for (void* p : c->allocs) hipFree(p);
+    if (c->h_kind) hipHostFree(c->h_kind);
+    if (c->cap_stream) hipStreamDestroy(c->cap_stream);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    delete c;
+    return TRACE_OK;
+}
+
+extern "C" int64_t trace_ctx_device_bytes(trace_ctx* c) { return c ? (int64_t)c->total_bytes : 0; }
+
+// ------------------------------------------------------------------------------------------------ weights
+static int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int on_device) {
+    HIPCHK(hipMemcpy2D(dst, dpitch, src, spitch, width, height, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    return TRACE_OK;
+}
+static int copy1d(void* dst, const void* src, size_t bytes, int on_device) {
+    HIPCHK(hipMemcpy(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    return TRACE_OK;
+}
+static bool starts(const std::string& s, const char* p) { return s.compare(0, strlen(p), p) == 0; }
+
+extern "C" int trace_ctx_load_tensor(trace_ctx* c, const char* name_, const void* data, int on_device, const int64_t* shape,
+                                     int ndim) {
+    if (!c || !name_ || !data) return fail(TRACE_ERR_ARG, "null argument");
+    std::string name(name_);
+    int64_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= shape[i];
+    const size_t H = c->H, I = c->I, vh = c->vh, vi = c->vi, E = sizeof(bf16_t);
+    auto expect = [&](int64_t n) -> int {
+        if (numel != n) return fail(TRACE_ERR_ARG, "tensor " + name + ": expected " + std::to_string(n) + " elements, got " + std::to_string(numel));
+        return TRACE_OK;
+    };
+    auto done = [&]() { c->loaded[name] = 1; return TRACE_OK; };
+    auto flat = [&](bf16_t* dst, int64_t n) -> int { TRY(expect(n)); TRY(copy1d(dst, data, n * E, on_device)); return done(); };
+
+    if (name == "model.embed_tokens.weight") return flat(c->embed, (int64_t)c->V * H);
+    if (name == "model.norm.weight") return flat(c->final_norm, H);
+    if (name == "lm_head.weight") return flat(c->wheads, (int64_t)c->V * H);
+    if (name == "sync_head.weight") return flat(c->wheads + (size_t)c->V * H, H);
+    if (name == "time_head.weight") return flat(c->wheads + (size_t)(c->V + 1) * H, (int64_t)c->Tv * H);
+    if (name == "score_head.weight") return flat(c->wheads + (size_t)(c->V + 1 + c->Tv) * H, (int64_t)c->Sv * H);
+    if (name == "model.time_tower.embed_tokens.weight") return flat(c->time_tab, (int64_t)c->Tv * H);
+    if (name == "model.score_tower.embed_tokens.weight") return flat(c->score_tab, (int64_t)c->Sv * H);
+    if (name == "model.sync_tower.embed_tokens.weight") return flat(c->sync_row, H);
+    if (name == "model.mm_projector.slots") return flat(c->sl_slots, (int64_t)vh * c->S);
+    if (name == "model.mm_projector.ln_vision.weight") return flat(c->sl_lnw, vh);
+    if (name == "model.mm_projector.ln_vision.bias") return flat(c->sl_lnb, vh);
+    if (name == "model.mm_projector.readout.weight") return flat(c->sl_readout, (int64_t)H * vh);
+
+    if (starts(name, "model.layers.")) {
+        const char* p = name.c_str() + strlen("model.layers.");
+        char* end = nullptr;
+        const long l = strtol(p, &end, 10);
+        if (l < 0 || l >= c->NL || *end != '.') return fail(TRACE_ERR_ARG, "bad layer index in " + name);
+        const std::string k(end + 1);
+        LlmLayer& L = c->llm[l];
+        const size_t qrows = (size_t)c->NQ * c->HD, kvrows = (size_t)c->NKV * c->HD;
+        if (k == "input_layernorm.weight") return flat(L.rms1, H);
+        if (k == "post_attention_layernorm.weight") return flat(L.rms2, H);
+        if (k == "self_attn.q_proj.weight") return flat(L.wqkv, qrows * H);
+        if (k == "self_attn.k_proj.weight") return flat(L.wqkv + qrows * H, kvrows * H);
+        if (k == "self_attn.v_proj.weight") return flat(L.wqkv + (qrows + kvrows) * H, kvrows * H);
+        if (k == "self_attn.o_proj.weight") return flat(L.wo, H * H);
+        if (k == "mlp.down_proj.weight") return flat(L.wd, H * I);
+        if (k == "mlp.gate_proj.weight" || k == "mlp.up_proj.weight") {
+            // interleave 16-row groups: packed rows [32t, 32t+16) = gate[16t..], [32t+16, 32t+32) = up[16t..]
+            TRY(expect(I * H));
+            bf16_t* dst = L.wgu + (k == "mlp.up_proj.weight" ? 16 * H : 0);
+            TRY(copy2d(dst, 32 * H * E, data, 16 * H * E, 16 * H * E, I / 16, on_device));
+            return done();
+        }
+        return fail(TRACE_ERR_ARG, "unknown tensor " + name);
+    }
+
+    // vision tower: accept both transformers key layouts (with / without ".vision_model")
+    const char* vp1 = "model.vision_tower.vision_tower.vision_model.";
+    const char* vp2 = "model.vision_tower.vision_tower.";
+    std::string k;
+    if (starts(name, vp1)) k = name.substr(strlen(vp1));
+    else if (starts(name, vp2)) k = name.substr(strlen(vp2));
+    else return fail(TRACE_ERR_ARG, "unknown tensor " + name);
+    auto vdone = [&](const std::string& canon) { c->loaded[std::string(vp1) + canon] = 1; return TRACE_OK; };
+    auto vflat = [&](bf16_t* dst, int64_t n) -> int { TRY(expect(n)); TRY(copy1d(dst, data, n * E, on_device)); return vdone(k); };
+    if (k == "embeddings.class_embedding") return vflat(c->cls, vh);
+    if (k == "embeddings.position_embedding.weight") return vflat(c->pos_emb, (int64_t)c->NT * vh);
+    if (k == "embeddings.patch_embedding.weight") {
+        TRY(expect((int64_t)vh * c->Kpatch));
+        TRY(copy2d(c->patch_w, c->Kpad * E, data, c->Kpatch * E, c->Kpatch * E, vh, on_device));
+        return vdone(k);
+    }
+    if (k == "pre_layrnorm.weight") return vflat(c->pre_w, vh);
+    if (k == "pre_layrnorm.bias") return vflat(c->pre_b, vh);
+    if (starts(k, "post_layernorm.") || k == "embeddings.position_ids") return 1;       // unused on this path
+    if (starts(k, "encoder.layers.")) {
+        const char* p = k.c_str() + strlen("encoder.layers.");
+        char* end = nullptr;
+        const long l = strtol(p, &end, 10);
+        if (l < 0 || *end != '.') return fail(TRACE_ERR_ARG, "bad layer index in " + name);
+        if (l >= c->vL) return 1;     // layers after the selected hidden state never run (select_layer = -2)
+        const std::string kk(end + 1);
+        VitLayer& L = c->vit[l];
+        if (kk == "layer_norm1.weight") return vflat(L.ln1w, vh);
+        if (kk == "layer_norm1.bias") return vflat(L.ln1b, vh);
+        if (kk == "layer_norm2.weight") return vflat(L.ln2w, vh);
+        if (kk == "layer_norm2.bias") return vflat(L.ln2b, vh);
+        if (kk == "self_attn.q_proj.weight") return vflat(L.wqkv, vh * vh);
+        if (kk == "self_attn.k_proj.weight") return vflat(L.wqkv + vh * vh, vh * vh);
+        if (kk == "self_attn.v_proj.weight") return vflat(L.wqkv + 2 * vh * vh, vh * vh);
+        if (kk == "self_attn.q_proj.bias") return vflat(L.bqkv, vh);
+        if (kk == "self_attn.k_proj.bias") return vflat(L.bqkv + vh, vh);
+        if (kk == "self_attn.v_proj.bias") return vflat(L.bqkv + 2 * vh, vh);
+        if (kk == "self_attn.out_proj.weight") return vflat(L.wo, vh * vh);
+        if (kk == "self_attn.out_proj.bias") return vflat(L.bo, vh);
+        if (kk == "mlp.fc1.weight") return vflat(L.w1, vi * vh);
+        if (kk == "mlp.fc1.bias") return vflat(L.b1, vi);
+        if (kk == "mlp.fc2.weight") return vflat(L.w2, vh * vi);
+        if (kk == "mlp.fc2.bias") return vflat(L.b2, vh);
+    }
+    return fail(TRACE_ERR_ARG, "unknown tensor " + name);
+}
+
+extern "C" int trace_ctx_finalize(trace_ctx* c) {
+    if (!c) return fail(TRACE_ERR_ARG, "null ctx");
+    const int expected = 13 + 9 * c->NL + 5 + 16 * c->vL;
+    if ((int)c->loaded.size() != expected)
+        return fail(TRACE_ERR_STATE, "weights incomplete: " + std::to_string(c->loaded.size()) + " of " + std::to_string(expected) + " tensors loaded");
+    // RoPE tables, computed the way the reference does (fp32 inv_freq, fp32 angle, cos/sin of that angle)
+    {
+        const int d = c->vh, h2 = d / 2, n = c->GG;
+        std::vector<float> cs((size_t)n * h2), sn((size_t)n * h2);
+        for (int j = 0; j < h2; ++j) {
+            const float inv = 1.0f / (float)pow((double)c->c.slot_rope_base, (double)((float)(2 * j) / (float)d));
+            for (int t = 0; t < n; ++t) {
+                const float ang = (float)t * inv;
+                cs[(size_t)t * h2 + j] = (float)cos((double)ang);
+                sn[(size_t)t * h2 + j] = (float)sin((double)ang);
+            }
+        }
+        HIPCHK(hipMemcpy(c->slot_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->slot_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    }
+    {
+        const int d = c->HD, h2 = d / 2, n = c->max_ctx;
+        std::vector<float> cs((size_t)n * h2), sn((size_t)n * h2);
+        for (int j = 0; j < h2; ++j) {
+            const float inv = 1.0f / (float)pow((double)c->c.rope_theta, (double)((float)(2 * j) / (float)d));
+            for (int t = 0; t < n; ++t) {
+                const float ang = (float)t * inv;
+                cs[(size_t)t * h2 + j] = (float)cos((double)ang);
+                sn[(size_t)t * h2 + j] = (float)sin((double)ang);
+            }
+        }
+        HIPCHK(hipMemcpy(c->rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    }
+    c->finalized = true;
+    return TRACE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ ViT
+static int gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* C, int ldc, const bf16_t* bias, const bf16_t* R,
+                int ldr, int M, int N, int K, int epi, hipStream_t s) {
+    GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K};
+    const int rc = launch_gemm_bf16(g, epi, s);
+    if (rc != TRACE_OK) return fail(rc, "gemm launch failed (M=" + std::to_string(M) + " N=" + std::to_string(N) + " K=" + std::to_string(K) + ")");
+    return TRACE_OK;
+}
+#define LCHK(x) do { int r_ = (x); if (r_ != TRACE_OK) return fail(r_, std::string("launch failed: ") + #x); } while (0)
+
+extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dtype, int T, void* feats_out, void* stream) {
+    if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
+    if (!frames || T < 1 || T > c->c.max_frames) return fail(TRACE_ERR_ARG, "bad frames / T");
+    hipStream_t s = (hipStream_t)stream;
+    const int vh = c->vh, vi = c->vi, NT = c->NT, GG = c->GG, Mv = T * NT;
+    bf16_t* im2 = c->vMLP;                       // [T*GG, Kpad]
+    bf16_t* pe = c->vH;                          // [T*GG, vh]
+    LCHK(launch_im2col(frames, frames_dtype == 1, im2, T, c->c.v_image, c->P, c->Kpad, s));
+    TRY(gemm(im2, c->Kpad, c->patch_w, c->Kpad, pe, vh, nullptr, nullptr, 0, T * GG, vh, c->Kpad, EPI_NONE, s));
+    LCHK(launch_vit_assemble(pe, c->cls, c->pos_emb, c->pre_w, c->pre_b, c->vX, T, GG, vh, c->c.v_eps, s));
+    AttnArgs a{};
+    a.Q = c->vQKV; a.K = c->vQKV + vh; a.V = c->vVT; a.O = c->vH;
+    a.q_bs = (long)NT * 3 * vh; a.q_hs = 64; a.q_rs = 3 * vh;
+    a.k_bs = a.q_bs; a.k_hs = 64; a.k_rs = 3 * vh;
+    a.v_bs = (long)vh * c->tokpad; a.v_hs = 64L * c->tokpad; a.v_rs = c->tokpad;
+    a.o_bs = (long)NT * vh; a.o_hs = 64; a.o_rs = vh;
+    a.nq_rows = NT; a.nkv_rows = NT; a.batch = T; a.heads = c->vheads; a.kv_heads = c->vheads;
+    a.scale = 0.125f; a.causal = 0;
+    for (int l = 0; l < c->vL; ++l) {
+        const VitLayer& L = c->vit[l];
+        LCHK(launch_layernorm(c->vX, vh, c->vH, vh, L.ln1w, L.ln1b, Mv, vh, c->c.v_eps, s));
+        TRY(gemm(c->vH, vh, L.wqkv, vh, c->vQKV, 3 * vh, L.bqkv, nullptr, 0, Mv, 3 * vh, vh, EPI_NONE, s));
+        LCHK(launch_transpose_v(c->vQKV + 2 * vh, (long)NT * 3 * vh, 64, 3 * vh, c->vVT, a.v_bs, a.v_hs, c->tokpad, NT, 64,
+                                c->vheads, T, s));
+        LCHK(launch_attn_vit(a, s));
+        TRY(gemm(c->vH, vh, L.wo, vh, c->vX, vh, L.bo, c->vX, vh, Mv, vh, vh, EPI_RESIDUAL, s));
+        LCHK(launch_layernorm(c->vX, vh, c->vH, vh, L.ln2w, L.ln2b, Mv, vh, c->c.v_eps, s));
+        TRY(gemm(c->vH, vh, L.w1, vh, c->vMLP, vi, L.b1, nullptr, 0, Mv, vi, vh, EPI_QUICKGELU, s));
+        TRY(gemm(c->vMLP, vi, L.w2, vi, c->vX, vh, L.b2, c->vX, vh, Mv, vh, vi, EPI_RESIDUAL, s));
+    }
+    if (feats_out)   // drop CLS: [T, GG, vh]
+        HIPCHK(hipMemcpy2DAsync(feats_out, (size_t)GG * vh * 2, c->vX + vh, (size_t)NT * vh * 2, (size_t)GG * vh * 2, T,
+                                hipMemcpyDeviceToDevice, s));
+    return TRACE_OK;
+}
+
+extern "C" int trace_slot_pool(trace_ctx* c, const void* feats, int T, void* slots_out, void* stream) {
+    if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
+    if (T < 1 || T > c->c.max_frames) return fail(TRACE_ERR_ARG, "bad T");
+    hipStream_t s = (hipStream_t)stream;
+    const int vh = c->vh;
+    const bf16_t* f = feats ? (const bf16_t*)feats : c->vX + vh;
+    const long fs = feats ? (long)c->GG * vh : (long)c->NT * vh;
+    LCHK(launch_slot_pool(f, fs, vh, c->sl_lnw, c->sl_lnb, c->sl_slots, c->slot_cos, c->slot_sin, c->sl_res, T, c->GG, vh,
+                          c->S, c->c.slot_eps, s));
+    TRY(gemm(c->sl_res, vh, c->sl_readout, vh, c->sl_out, c->H, nullptr, nullptr, 0, T * c->S, c->H, vh, EPI_NONE, s));
+    if (slots_out) HIPCHK(hipMemcpyAsync(slots_out, c->sl_out, (size_t)T * c->S * c->H * 2, hipMemcpyDeviceToDevice, s));
+    return TRACE_OK;
+}
+
+extern "C" int trace_encode_video(trace_ctx* c, const void* frames, int frames_dtype, int T, const int32_t* time_ids,
+                                  void* video_out, void* stream) {
+    if (!time_ids) return fail(TRACE_ERR_ARG, "null time_ids");
+    hipStream_t s = (hipStream_t)stream;
+    TRY(trace_vit_forward(c, frames, frames_dtype, T, nullptr, stream));
+    TRY(trace_slot_pool(c, nullptr, T, nullptr, stream));
+    const int rows = T * c->TPF;
+    HIPCHK(hipStreamSynchronize(s));        // pinned staging buffer reuse
+    for (int t = 0; t < T; ++t)
+        for (int j = 0; j < c->TPF; ++j) {
+            const int r = t * c->TPF + j;
+            if (j < c->S) { c->h_kind[r] = 0; c->h_row[r] = t * c->S + j; }
+            else {
+                const int id = time_ids[t * 6 + (j - c->S)];
+                if (id < 0 || id >= c->Tv) return fail(TRACE_ERR_ARG, "time id out of range");
+                c->h_kind[r] = 1; c->h_row[r] = id;
+            }
+        }
+    HIPCHK(hipMemcpyAsync(c->d_kind, c->h_kind, rows * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_row, c->h_row, rows * 4, hipMemcpyHostToDevice, s));
+    GatherTabs tabs{};
+    tabs.t[0] = c->sl_out; tabs.t[1] = c->time_tab;
+    LCHK(launch_gather_rows(tabs, c->d_kind, c->d_row, c->video, rows, c->H, s));
+    c->video_rows = rows;
+    if (video_out) HIPCHK(hipMemcpyAsync(video_out, c->video, (size_t)rows * c->H * 2, hipMemcpyDeviceToDevice, s));
+    return TRACE_OK;
+}
+
+extern "C" int trace_splice_embeds(trace_ctx* c, const int32_t* ids, int n_ids, const int32_t* time_rows, int n_time,
+                                   const int32_t* score_rows, int n_score, int* L_out, void* embeds_out, void* stream) {
+    if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
+    if (!ids || n_ids < 1) return fail(TRACE_ERR_ARG, "bad ids");
+    hipStream_t s = (hipStream_t)stream;
+    int nvid = 0;
+    for (int i = 0; i < n_ids; ++i) nvid += (ids[i] == -201 || ids[i] == -200);
+    if (nvid != 1) return fail(TRACE_ERR_ARG, "only have one video inputs!");          // trace_arch.py:411
+    if (c->video_rows <= 0) return fail(TRACE_ERR_STATE, "no encoded video");
+    const int L = n_ids - 1 + c->video_rows;
+    if (L > c->max_ctx) return fail(TRACE_ERR_ARG, "spliced prompt longer than max_ctx");
+    HIPCHK(hipStreamSynchronize(s));
+    int r = 0, ti = 0, si = 0;
+    for (int i = 0; i < n_ids; ++i) {
+        const int id = ids[i];
+        if (id == -201 || id == -200) {
+            for (int j = 0; j < c->video_rows; ++j, ++r) { c->h_kind[r] = 1; c->h_row[r] = j; }
+        } else if (id == -205) { c->h_kind[r] = 4; c->h_row[r] = 0; ++r; }
+        else if (id == -203) {
+            if (ti >= n_time || !time_rows) return fail(TRACE_ERR_ARG, "more <time> placeholders than time tokens");
+            c->h_kind[r] = 2; c->h_row[r] = time_rows[ti++]; ++r;
+        } else if (id == -204) {
+            if (si >= n_score || !score_rows) return fail(TRACE_ERR_ARG, "more <score> placeholders than score tokens");
+            c->h_kind[r] = 3; c->h_row[r] = score_rows[si++]; ++r;
+        } else {
+            const int t = id < 0 ? 0 : id;      // torch.clamp(ids, min=0) (trace_arch.py:417)
+            if (t >= c->V) return fail(TRACE_ERR_ARG, "token id out of range");
+            c->h_kind[r] = 0; c->h_row[r] = t; ++r;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(c->d_kind, c->h_kind, L * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_row, c->h_row, L * 4, hipMemcpyHostToDevice, s));
+    GatherTabs tabs{};
+    tabs.t[0] = c->embed; tabs.t[1] = c->video; tabs.t[2] = c->time_tab; tabs.t[3] = c->score_tab; tabs.t[4] = c->sync_row;
+    LCHK(launch_gather_rows(tabs, c->d_kind, c->d_row, c->pX, L, c->H, s));
+    c->spliced_len = L;
+    if (L_out) *L_out = L;
+    if (embeds_out) HIPCHK(hipMemcpyAsync(embeds_out, c->pX, (size_t)L * c->H * 2, hipMemcpyDeviceToDevice, s));
+    return TRACE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ LLM prefill
+extern "C" int trace_llm_prefill(trace_ctx* c, int slot, const void* embeds, int L, void* hidden_out, void* stream) {
+    if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
+    if (slot < 0 || slot >= c->max_B || L < 1 || L > c->max_ctx) return fail(TRACE_ERR_ARG, "bad slot / L");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = c->H, I = c->I, HD = c->HD, QKV = c->QKV;
+    if (embeds) HIPCHK(hipMemcpyAsync(c->pX, embeds, (size_t)L * H * 2, hipMemcpyDeviceToDevice, s));
+    const int Lpad = round_up(L, 64);
+    AttnArgs a{};
+    a.Q = c->pQKV; a.V = c->pVT; a.O = c->pO;
+    a.q_bs = 0; a.q_hs = HD; a.q_rs = QKV;
+    a.k_bs = 0; a.k_hs = (long)c->kv_head_stride; a.k_rs = HD;
+    a.v_bs = 0; a.v_hs = (long)HD * Lpad; a.v_rs = Lpad;
+    a.o_bs = 0; a.o_hs = HD; a.o_rs = H;
+    a.nq_rows = L; a.nkv_rows = L; a.batch = 1; a.heads = c->NQ; a.kv_heads = c->NKV;
+    a.scale = 1.0f / sqrtf((float)HD); a.causal = 1;
+    for (int l = 0; l < c->NL; ++l) {
+        const LlmLayer& W = c->llm[l];
+        bf16_t* kc = c->kcache + (size_t)l * c->layer_stride;
+        bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
+        LCHK(launch_rmsnorm(c->pX, H, c->pH, H, W.rms1, L, H, c->c.rms_eps, s));
+        TRY(gemm(c->pH, H, W.wqkv, H, c->pQKV, QKV, nullptr, nullptr, 0, L, QKV, H, EPI_NONE, s));
+        LCHK(launch_rope_kv(c->pQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, nullptr, nullptr, slot, 0, L,
+                            c->NQ, c->NKV, HD, c->rope_cos, c->rope_sin, s));
+        LCHK(launch_transpose_v(c->pQKV + (size_t)(c->NQ + c->NKV) * HD, 0, HD, QKV, c->pVT, 0, (long)HD * Lpad, Lpad, L, HD,
+                                c->NKV, 1, s));
+        a.K = kc + (size_t)slot * c->slot_stride;
+        LCHK(launch_attn_prefill(a, s));
+        TRY(gemm(c->pO, H, W.wo, H, c->pX, H, nullptr, c->pX, H, L, H, H, EPI_RESIDUAL, s));
+        LCHK(launch_rmsnorm(c->pX, H, c->pH, H, W.rms2, L, H, c->c.rms_eps, s));
+        TRY(gemm(c->pH, H, W.wgu, H, c->pACT, I, nullptr, nullptr, 0, L, 2 * I, H, EPI_SWIGLU, s));
+        TRY(gemm(c->pACT, I, W.wd, I, c->pX, H, nullptr, c->pX, H, L, H, I, EPI_RESIDUAL, s));
+    }
+    if (hidden_out) LCHK(launch_rmsnorm(c->pX, H, (bf16_t*)hidden_out, H, c->final_norm, L, H, c->c.rms_eps, s));
+    LCHK(launch_rmsnorm(c->pX + (size_t)(L - 1) * H, H, c->xlast + (size_t)slot * H, H, c->final_norm, 1, H, c->c.rms_eps, s));
+    c->slot_len[slot] = L;
+    return TRACE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ decode
+static StepState step_state(trace_ctx* c) {
+    StepState st{};
+    st.heads = c->d_heads; st.pos = c->d_pos; st.done = c->d_done; st.out_ids = c->d_out_ids; st.out_len = c->d_out_len;
+    st.step = c->d_step; st.forced = c->has_forced ? c->d_forced : nullptr;
+    return st;
+}
+
+static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* logits_out, hipStream_t s) {
+    LCHK(launch_head_logits(xn, c->H, c->wheads, c->H, c->d_heads, c->V, c->Tv, c->Sv, c->part_val, c->part_idx, logits_out,
+                            c->B, s));
+    LCHK(launch_select_next(c->part_val, c->part_idx, step_state(c), c->embed, c->time_tab, c->score_tab, c->sync_row, c->dX,
+                            c->H, c->B, c->H, c->V, c->Tv, c->Sv, c->max_new, c->eos, advance, s));
+    return TRACE_OK;
+}
+
+// one decode step for the current batch: consumes dX (embedding of the last token), leaves the next one in dX
+static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
+    const int H = c->H, I = c->I, HD = c->HD, QKV = c->QKV, B = c->B;
+    for (int l = 0; l < c->NL; ++l) {
+        const LlmLayer& W = c->llm[l];
+        bf16_t* kc = c->kcache + (size_t)l * c->layer_stride;
+        bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
+        LCHK(launch_rmsnorm(c->dX, H, c->dH, H, W.rms1, B, H, c->c.rms_eps, s));
+        LCHK(launch_skinny_gemm(c->dH, H, W.wqkv, H, c->dQKV, QKV, nullptr, 0, B, QKV, H, EPI_NONE, s));
+        LCHK(launch_rope_kv(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->d_slots, c->d_pos, 0, 0, B,
+                            c->NQ, c->NKV, HD, c->rope_cos, c->rope_sin, s));
+        LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->d_slots, c->d_pos, c->dO,
+                                H, c->attn_ws, B, c->NQ, c->NKV, HD, c->nsplit, 1.0f / sqrtf((float)HD), s));
+        LCHK(launch_skinny_gemm(c->dO, H, W.wo, H, c->dX, H, c->dX, H, B, H, H, EPI_RESIDUAL, s));
+        LCHK(launch_rmsnorm(c->dX, H, c->dH, H, W.rms2, B, H, c->c.rms_eps, s));
+        LCHK(launch_skinny_gemm(c->dH, H, W.wgu, H, c->dACT, I, nullptr, 0, B, 2 * I, H, EPI_SWIGLU, s));
+        LCHK(launch_skinny_gemm(c->dACT, I, W.wd, I, c->dX, H, c->dX, H, B, H, I, EPI_RESIDUAL, s));
+    }
+    LCHK(launch_rmsnorm(c->dX, H, c->dH, H, c->final_norm, B, H, c->c.rms_eps, s));
+    return head_and_select(c, c->dH, 1, logits_out, s);
+}
+
+extern "C" int trace_decode_begin(trace_ctx* c, const int32_t* slots, int B, const int32_t* heads, int max_new, int eos,
+                                  const int32_t* forced, float* logits_out, void* stream) {
+    if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
+    if (!slots || !heads || B < 1 || B > c->max_B) return fail(TRACE_ERR_ARG, "bad batch");
+    if (max_new < 1 || max_new > c->c.max_new_tokens) return fail(TRACE_ERR_ARG, "max_new exceeds capacity");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t pos[16], zero[16] = {0};
+    for (int b = 0; b < B; ++b) {
+        if (slots[b] < 0 || slots[b] >= c->max_B || c->slot_len[slots[b]] <= 0) return fail(TRACE_ERR_STATE, "slot not prefilled");
+        if (heads[b] < 0 || heads[b] > 2) return fail(TRACE_ERR_ARG, "head must be 0, 1 or 2");
+        pos[b] = c->slot_len[slots[b]];
+        if (pos[b] + max_new > c->max_ctx) return fail(TRACE_ERR_ARG, "prefill + max_new_tokens exceeds max_ctx");
+        for (int b2 = 0; b2 < b; ++b2) if (slots[b2] == slots[b]) return fail(TRACE_ERR_ARG, "duplicate slot");
+    }
+    c->B = B; c->max_new = max_new; c->eos = eos; c->has_forced = forced != nullptr;
+    HIPCHK(hipMemcpyAsync(c->d_slots, slots, B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_pos, pos, B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_heads, heads, B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_done, zero, B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_out_len, zero, B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_step, zero, 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(c->d_out_ids, 0, (size_t)B * max_new * 4, s));
+    if (forced) HIPCHK(hipMemcpyAsync(c->d_forced, forced, (size_t)B * max_new * 4, hipMemcpyHostToDevice, s));
+    // gather the prefill hidden rows of the chosen slots into dH, then head + select (no position advance)
+    for (int b = 0; b < B; ++b)
+        HIPCHK(hipMemcpyAsync(c->dH + (size_t)b * c->H, c->xlast + (size_t)slots[b] * c->H, (size_t)c->H * 2, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));     // host stack arrays above must outlive the async copies
+    return head_and_select(c, c->dH, 0, logits_out, s);
+}
+
+extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* logits_out, void* stream) {
+    if (!c || c->B < 1) return fail(TRACE_ERR_STATE, "trace_decode_begin not called");
+    if (n < 0) return fail(TRACE_ERR_ARG, "bad n");
+    if (logits_out && (n != 1 || use_graph)) return fail(TRACE_ERR_ARG, "logits_out needs n == 1 and eager mode");
+    hipStream_t s = (hipStream_t)stream;
+    if (c->profile) hipEventRecord(c->ev0, s);
+    if (!use_graph) {
+        for (int i = 0; i < n; ++i) TRY(decode_step(c, logits_out, s));
+    } else {
+        const int key = c->B;
+        if (!c->graphs[key]) {
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeGlobal));
+            const int rc = decode_step(c, nullptr, c->cap_stream);
+            hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
+            if (rc != TRACE_OK) { if (g) hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess) return fail(TRACE_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            e = hipGraphInstantiate(&c->graphs[key], g, nullptr, nullptr, 0);
+            hipGraphDestroy(g);
+            if (e != hipSuccess) { c->graphs[key] = nullptr; return fail(TRACE_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+        }
+        for (int i = 0; i < n; ++i) HIPCHK(hipGraphLaunch(c->graphs[key], s));
+    }
+    if (c->profile) {
+        hipEventRecord(c->ev1, s);
+        hipEventSynchronize(c->ev1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        c->prof[0] = n > 0 ? ms / n : 0.f;
+        c->prof[1] = (float)n;
+    }
+    return TRACE_OK;
+}
+
+extern "C" int trace_decode_read(trace_ctx* c, int32_t* out_ids, int32_t* out_len, int32_t* heads, void* stream) {
+    if (!c || c->B < 1) return fail(TRACE_ERR_STATE, "trace_decode_begin not called");
+    hipStream_t s = (hipStream_t)stream;
+    if (out_ids) HIPCHK(hipMemcpyAsync(out_ids, c->d_out_ids, (size_t)c->B * c->max_new * 4, hipMemcpyDeviceToHost, s));
+    if (out_len) HIPCHK(hipMemcpyAsync(out_len, c->d_out_len, c->B * 4, hipMemcpyDeviceToHost, s));
+    if (heads) HIPCHK(hipMemcpyAsync(heads, c->d_heads, c->B * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return TRACE_OK;
+}
+
+extern "C" int trace_set_profile(trace_ctx* c, int on) { if (!c) return fail(TRACE_ERR_ARG, "null ctx"); c->profile = on; return TRACE_OK; }
+extern "C" int trace_get_profile(trace_ctx* c, float* out, int n) {
+    if (!c || !out) return fail(TRACE_ERR_ARG, "null argument");
+    for (int i = 0; i < n && i < 8; ++i) out[i] = c->prof[i];
+    return TRACE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ op-level hooks
+extern "C" int trace_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* R,
+                             int ldr, int M, int N, int K, int epilogue, void* stream) {
+    return gemm((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (bf16_t*)C, ldc, (const bf16_t*)bias, (const bf16_t*)R, ldr, M, N, K,
+                epilogue, (hipStream_t)stream);
+}
+extern "C" int trace_op_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, float eps, void* stream) {
+    LCHK(launch_layernorm((const bf16_t*)x, D, (bf16_t*)y, D, (const bf16_t*)w, (const bf16_t*)b, rows, D, eps, (hipStream_t)stream));
+    return TRACE_OK;
+}
+extern "C" int trace_op_rmsnorm(const void* x, void* y, const void* w, int rows, int D, float eps, void* stream) {
+    LCHK(launch_rmsnorm((const bf16_t*)x, D, (bf16_t*)y, D, (const bf16_t*)w, rows, D, eps, (hipStream_t)stream));
+    return TRACE_OK;
+}
+// Q [batch, nq, heads, hd], K/V [batch, nkv, kv_heads, hd] (token-major, heads interleaved), O like Q.
+// vt_scratch: batch*kv_heads*hd*round_up(nkv,64) bf16.
+extern "C" int trace_op_attention(const void* Q, const void* K, const void* V, void* O, void* vt_scratch, int batch, int heads,
+                                  int kv_heads, int nq, int nkv, int head_dim, int causal, float scale, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int pad = round_up(nkv, 64);
+    AttnArgs a{};
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)vt_scratch; a.O = (bf16_t*)O;
+    a.q_bs = (long)nq * heads * head_dim; a.q_hs = head_dim; a.q_rs = heads * head_dim;
+    a.k_bs = (long)nkv * kv_heads * head_dim; a.k_hs = head_dim; a.k_rs = kv_heads * head_dim;
+    a.v_bs = (long)kv_heads * head_dim * pad; a.v_hs = (long)head_dim * pad; a.v_rs = pad;
+    a.o_bs = a.q_bs; a.o_hs = head_dim; a.o_rs = heads * head_dim;
+    a.nq_rows = nq; a.nkv_rows = nkv; a.batch = batch; a.heads = heads; a.kv_heads = kv_heads; a.scale = scale; a.causal = causal;
+    LCHK(launch_transpose_v((const bf16_t*)V, a.k_bs, head_dim, kv_heads * head_dim, (bf16_t*)vt_scratch, a.v_bs, a.v_hs, pad, nkv,
+                            head_dim, kv_heads, batch, s));
+    if (head_dim == 64) { LCHK(launch_attn_vit(a, s)); }
+    else if (head_dim == 128) { LCHK(launch_attn_prefill(a, s)); }
+    else return fail(TRACE_ERR_ARG, "head_dim must be 64 or 128");
+    return TRACE_OK;
+}
+extern "C" int trace_op_skinny_gemm(const void* X, const void* W, void* out, const void* R, int B, int N, int K, int epilogue,
+                                    void* stream) {
+    const int No = epilogue == EPI_SWIGLU ? N / 2 : N;
+    LCHK(launch_skinny_gemm((const bf16_t*)X, K, (const bf16_t*)W, K, (bf16_t*)out, No, (const bf16_t*)R, No, B, N, K, epilogue,
+                            (hipStream_t)stream));
+    return TRACE_OK;
+}
+// kcache/vcache [B, nkv, max_ctx, 128]; pos[b] = index of the newest token (ctx = pos+1)
+extern "C" int trace_op_attn_decode(const void* q, const void* kcache, const void* vcache, const int32_t* pos, void* O, float* ws,
+                                    int B, int nq, int nkv, int max_ctx, int nsplit, float scale, void* stream) {
+    static int32_t* d_slots = nullptr;
+    if (!d_slots) {
+        int32_t h[16];
+        for (int i = 0; i < 16; ++i) h[i] = i;
+        HIPCHK(hipMalloc((void**)&d_slots, 64));
+        HIPCHK(hipMemcpy(d_slots, h, 64, hipMemcpyHostToDevice));
+    }
+    LCHK(launch_attn_decode((const bf16_t*)q, nq * 128, (const bf16_t*)kcache, (const bf16_t*)vcache, (long)nkv * max_ctx * 128,
+                            (long)max_ctx * 128, d_slots, pos, (bf16_t*)O, nq * 128, ws, B, nq, nkv, 128, nsplit, scale,
+                            (hipStream_t)stream));
+    return TRACE_OK;
+}

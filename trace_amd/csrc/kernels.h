@@ -1,0 +1,96 @@
+// Internal launcher interface between the kernel translation units and the engine (engine.hip).
+// Everything here takes raw device pointers + an explicit stream; the public C ABI is include/trace_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_QUICKGELU = 2, EPI_SWIGLU = 3 };
+
+struct GemmArgs {
+    const bf16_t* A; int lda;       // [M,K] activations, row stride lda (elements)
+    const bf16_t* W; int ldw;       // [N,K] weights (nn.Linear layout)
+    bf16_t* C; int ldc;             // [M,N] (or [M,N/2] for EPI_SWIGLU)
+    const bf16_t* bias;             // [N] or null
+    const bf16_t* R; int ldr;       // residual [M,N] for EPI_RESIDUAL (may alias C)
+    int M, N, K;
+};
+int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s);
+
+// ---- norms (norm.hip) ----
+// y = LN(x) * w + b over the last dim D (D % 8 == 0, D <= 8192); rows independent; x,y bf16, stats fp32.
+int launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w, const bf16_t* b,
+                     int rows, int D, float eps, hipStream_t s);
+int launch_rmsnorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w, int rows, int D, float eps,
+                   hipStream_t s);
+
+// ---- ViT front end (vit.hip) ----
+// frames [T,3,S,S] (bf16 or fp32) -> im2col patches A [T*G*G, Kpad] bf16 (k = c*P*P + py*P + px, zero padded)
+int launch_im2col(const void* frames, int frames_fp32, bf16_t* A, int T, int S, int P, int Kpad, hipStream_t s);
+// X[t, 0] = cls + pos[0];  X[t, 1+p] = PE[t*GG + p] + pos[1+p]      (PE = patch-embed GEMM output)
+//   then X = LayerNorm(X) (pre_layrnorm), fused
+int launch_vit_assemble(const bf16_t* PE, const bf16_t* cls, const bf16_t* pos, const bf16_t* lw, const bf16_t* lb,
+                        bf16_t* X, int T, int GG, int D, float eps, hipStream_t s);
+
+// ---- attention (attn.hip) ----
+struct AttnArgs {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O;
+    long q_bs, q_hs; int q_rs;      // batch / head / row strides (elements)
+    long k_bs, k_hs; int k_rs;
+    long v_bs, v_hs; int v_rs;
+    long o_bs, o_hs; int o_rs;
+    int nq_rows;                    // query rows per (batch, head)
+    int nkv_rows;                   // kv rows per (batch, kv head)
+    int batch, heads, kv_heads;
+    float scale;
+    int causal;                     // 1: query row i attends kv rows <= i + (nkv_rows - nq_rows)
+};
+// NB: V is passed PRE-TRANSPOSED: V^T[d, kv] with row stride v_rs (multiple of 64, >= nkv_rows, zero padded)
+int launch_attn_vit(const AttnArgs& a, hipStream_t s);       // head_dim 64, non-causal, heads == kv_heads
+int launch_attn_prefill(const AttnArgs& a, hipStream_t s);   // head_dim 128, causal, GQA 4:1
+// V [n, hd] (row stride src_rs) -> V^T [hd, dst_rs] per (batch, head); zero fill beyond n
+int launch_transpose_v(const bf16_t* src, long src_bs, long src_hs, int src_rs, bf16_t* dst, long dst_bs, long dst_hs,
+                       int dst_rs, int n, int hd, int heads, int batch, hipStream_t s);
+
+// ---- SpatialSlotPool (slot_pool.hip) ----
+// feats rows: frame t patch p at feats + (t*frame_stride + p*row_stride); out RES [T*S, D] bf16 (pre-readout)
+int launch_slot_pool(const bf16_t* feats, long frame_stride, int row_stride, const bf16_t* ln_w, const bf16_t* ln_b,
+                     const bf16_t* slots /*[D,S]*/, const float* cos_t, const float* sin_t /*[n,D/2]*/,
+                     bf16_t* res, int T, int n, int D, int S, float eps, hipStream_t s);
+
+// ---- LLM glue (llm.hip) ----
+struct GatherTabs { const bf16_t* t[6]; };
+// out[r, :] = tabs.t[kind[r]][row[r], :]   (embedding splice / per-frame [slots | time tokens] interleave)
+int launch_gather_rows(const GatherTabs& tabs, const int32_t* kind, const int32_t* row, bf16_t* out, int L, int H,
+                       hipStream_t s);
+// RoPE on q (in place) and k (-> cache at pos) + v copy (-> cache).  qkv rows are [q heads | k heads | v heads].
+// Row r: pos = pos_arr ? pos_arr[r] : pos0 + r ; slot = slot_arr ? slot_arr[r] : slot0.
+int launch_rope_kv(bf16_t* qkv, int ld, bf16_t* kcache, bf16_t* vcache, long slot_stride, long kv_head_stride,
+                   const int32_t* slot_arr, const int32_t* pos_arr, int slot0, int pos0, int R, int nq, int nkv, int hd,
+                   const float* cos_t, const float* sin_t, hipStream_t s);
+
+// ---- decode (decode.hip) ----
+// out[b, n] = sum_k X[b,k] W[n,k]  (B <= 16) (+ residual / SwiGLU on interleaved W)
+int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R,
+                       int ldr, int B, int N, int K, int epi, hipStream_t s);
+// single-query GQA attention over the cache; q [B, nq*hd]; O [B, nq*hd]
+int launch_attn_decode(const bf16_t* q, int ldq, const bf16_t* kcache, const bf16_t* vcache, long slot_stride,
+                       long kv_head_stride, const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws,
+                       int B, int nq, int nkv, int hd, int nsplit, float scale, hipStream_t s);
+// heads: logits over [text V+1 | time Tv | score Sv] rows of Wh [NV_pad, H]; only tiles intersecting an active
+// head's range are computed.  part: [B, ntiles] (max,idx).  logits_out optional [B, NV] fp32 (masked -inf).
+int launch_head_logits(const bf16_t* X, int ldx, const bf16_t* Wh, int H, const int32_t* heads, int V, int Tv, int Sv,
+                       float* part_val, int32_t* part_idx, float* logits_out, int B, hipStream_t s);
+// argmax over partials + state machine + next-token embedding
+struct StepState {
+    int32_t* heads;       // [B] in/out
+    int32_t* pos;         // [B] in/out (position of the NEXT token to be written)
+    int32_t* done;        // [B] in/out
+    int32_t* out_ids;     // [B, max_new]
+    int32_t* out_len;     // [B]
+    int32_t* step;        // [1] device step counter
+    const int32_t* forced;// [B, max_new] teacher-forcing ids or null
+};
+int launch_select_next(const float* part_val, const int32_t* part_idx, const StepState& st, const bf16_t* embed,
+                       const bf16_t* time_tab, const bf16_t* score_tab, const bf16_t* sync_row, bf16_t* xnext, int ldx,
+                       int B, int H, int V, int Tv, int Sv, int max_new, int eos, int advance, hipStream_t s);

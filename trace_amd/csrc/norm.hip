@@ -1,0 +1,87 @@
+// LayerNorm (CLIP, eps 1e-5) and RMSNorm (Mistral, eps from config): HBM-bound row kernels.
+// One 64-lane wave per row, the row is held in registers (16-byte loads, D <= 4096), statistics in fp32
+// (two-pass mean/variance on the register copy), 16-byte stores.  4 rows per 256-thread block.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+constexpr int MAXCH = 8;   // 8 chunks x 64 lanes x 8 elements = 4096
+
+template <bool RMS>
+__global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
+                                                   const bf16_t* __restrict__ w, const bf16_t* __restrict__ b, int rows,
+                                                   int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = D >> 3;
+    const bf16_t* xr = x + (size_t)row * ldx;
+    float v[MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            const uint4 u = *reinterpret_cast<const uint4*>(xr + c * 8);
+            v[i][0] = bflo(u.x); v[i][1] = bfhi(u.x); v[i][2] = bflo(u.y); v[i][3] = bfhi(u.y);
+            v[i][4] = bflo(u.z); v[i][5] = bfhi(u.z); v[i][6] = bflo(u.w); v[i][7] = bfhi(u.w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += RMS ? v[i][e] * v[i][e] : v[i][e];
+        }
+    }
+    s = wave_sum(s);
+    float mean = 0.f, rstd;
+    if (RMS) {
+        rstd = rsqrtf(s / (float)D + eps);
+    } else {
+        mean = s / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int c = lane + i * 64;
+            if (c < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            }
+        }
+        q = wave_sum(q);
+        rstd = rsqrtf(q / (float)D + eps);
+    }
+    bf16_t* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            const uint4 uw = *reinterpret_cast<const uint4*>(w + c * 8);
+            float o[8];
+            const float ww[8] = {bflo(uw.x), bfhi(uw.x), bflo(uw.y), bfhi(uw.y), bflo(uw.z), bfhi(uw.z), bflo(uw.w), bfhi(uw.w)};
+            if (RMS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = v[i][e] * rstd * ww[e];
+            } else {
+                const uint4 ub = *reinterpret_cast<const uint4*>(b + c * 8);
+                const float bb[8] = {bflo(ub.x), bfhi(ub.x), bflo(ub.y), bfhi(ub.y), bflo(ub.z), bfhi(ub.z), bflo(ub.w), bfhi(ub.w)};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * ww[e] + bb[e];
+            }
+            uint4 out;
+            out.x = pack2bf(o[0], o[1]); out.y = pack2bf(o[2], o[3]); out.z = pack2bf(o[4], o[5]); out.w = pack2bf(o[6], o[7]);
+            *reinterpret_cast<uint4*>(yr + c * 8) = out;
+        }
+    }
+}
+}  // namespace
+
+int launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w, const bf16_t* b, int rows, int D,
+                     float eps, hipStream_t s) {
+    if (D % 8 || D > MAXCH * 512 || (ldx % 8) || (ldy % 8) || rows <= 0) return TRACE_ERR_ARG;
+    hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, w, b, rows, D, eps);
+    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+}
+
+int launch_rmsnorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w, int rows, int D, float eps,
+                   hipStream_t s) {
+    if (D % 8 || D > MAXCH * 512 || (ldx % 8) || (ldy % 8) || rows <= 0) return TRACE_ERR_ARG;
+    hipLaunchKernelGGL(norm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, w, nullptr, rows, D, eps);
+    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+}

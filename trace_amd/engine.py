@@ -1,0 +1,270 @@
+"""Python face of the HIP engine (libtrace_hip.so).  PyTorch is plumbing here: device allocations for the
+tensors the caller hands in/out, and the current HIP stream.  All arithmetic happens in the C-ABI library."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .config import TraceConfig
+from .model.encoders import TimeTower, ScoreTower
+
+EPI_NONE, EPI_RESIDUAL, EPI_QUICKGELU, EPI_SWIGLU = 0, 1, 2, 3
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _i32(seq) -> "C.Array":
+    seq = [int(x) for x in seq]
+    return (C.c_int32 * len(seq))(*seq)
+
+
+class TraceEngine:
+    def __init__(self, cfg: TraceConfig, device: int = 0, max_batch: int = 1, max_ctx: Optional[int] = None,
+                 max_frames: Optional[int] = None, max_new_tokens: int = 1024):
+        if not torch.cuda.is_available():
+            raise _lib.TraceHipError("no HIP device visible: the TRACE hot path only runs on an MI355X (no CPU fallback)")
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        max_frames = max_frames or cfg.num_frames
+        max_ctx = max_ctx or min(cfg.max_position_embeddings, max_frames * cfg.tokens_per_frame + 512 + max_new_tokens)
+        self.max_batch, self.max_ctx, self.max_frames, self.max_new_tokens = max_batch, max_ctx, max_frames, max_new_tokens
+        c = _lib.TraceConfigC(
+            cfg.vocab_size, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.num_attention_heads,
+            cfg.num_key_value_heads, cfg.time_vocab_size, cfg.score_vocab_size, cfg.rms_norm_eps, cfg.rope_theta,
+            cfg.vision_hidden_size, cfg.vision_intermediate_size, cfg.vision_layers_used, cfg.vision_num_heads,
+            cfg.vision_image_size, cfg.vision_patch_size, cfg.vision_layer_norm_eps, cfg.num_slots, cfg.slot_ln_eps,
+            cfg.slot_rope_base, max_frames, max_ctx, max_batch, max_new_tokens)
+        h = C.c_void_p()
+        _lib.check(self.lib.trace_ctx_create(C.byref(c), device, C.byref(h)))
+        self.h = h
+        self.time_tower, self.score_tower = TimeTower(), ScoreTower()
+        self._B = 0
+        self._max_new = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.trace_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights -------------------------------------------------------------------------------
+    def load_weights(self, items: Iterable[Tuple[str, torch.Tensor]]) -> int:
+        """items: (reference state-dict name, tensor).  Tensors are converted to contiguous bf16; host or device."""
+        n = 0
+        for name, t in items:
+            t = t.detach().to(torch.bfloat16).contiguous()
+            shape = (C.c_int64 * max(t.dim(), 1))(*(list(t.shape) or [1]))
+            rc = _lib.check(self.lib.trace_ctx_load_tensor(self.h, name.encode(), C.c_void_p(t.data_ptr()),
+                                                          1 if t.is_cuda else 0, shape, t.dim()))
+            n += rc == 0
+        _lib.check(self.lib.trace_ctx_finalize(self.h))
+        return n
+
+    def device_bytes(self) -> int:
+        return int(self.lib.trace_ctx_device_bytes(self.h))
+
+    # ---- stages --------------------------------------------------------------------------------
+    def _frames(self, frames: torch.Tensor):
+        if frames.dim() != 4:
+            raise ValueError("frames must be [T,3,H,W]")
+        if frames.dtype not in (torch.bfloat16, torch.float32):
+            frames = frames.to(torch.bfloat16)
+        frames = frames.to(self.device).contiguous()
+        return frames, (1 if frames.dtype == torch.float32 else 0)
+
+    def vit_forward(self, frames: torch.Tensor) -> torch.Tensor:
+        frames, dt = self._frames(frames)
+        T = frames.shape[0]
+        out = torch.empty((T, self.cfg.vision_patches, self.cfg.vision_hidden_size), dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.trace_vit_forward(self.h, _ptr(frames), dt, T, _ptr(out), _stream()))
+        return out
+
+    def slot_pool(self, feats: Optional[torch.Tensor], T: int) -> torch.Tensor:
+        out = torch.empty((T, self.cfg.num_slots, self.cfg.hidden_size), dtype=torch.bfloat16, device=self.device)
+        if feats is not None:
+            feats = feats.to(self.device, torch.bfloat16).contiguous()
+        _lib.check(self.lib.trace_slot_pool(self.h, _ptr(feats), T, _ptr(out), _stream()))
+        return out
+
+    def time_ids(self, timestamps: Sequence[Sequence[float]]) -> List[int]:
+        """encode_time + [:-1] (trace_arch.py:243,271-288): 6 ids per frame; all frames must agree in length."""
+        toks = [self.time_tower.encode(t) for t in timestamps]
+        assert all(x.shape == toks[0].shape for x in toks), f"{timestamps} {[x.shape for x in toks]}"
+        if toks[0].numel() - 1 != self.cfg.time_tokens_per_frame:
+            raise ValueError("each frame must carry exactly one timestamp (6 time tokens)")
+        return [int(i) for x in toks for i in x[:-1]]
+
+    def encode_video(self, frames: torch.Tensor, timestamps, want_output: bool = False):
+        frames, dt = self._frames(frames)
+        T = frames.shape[0]
+        ids = _i32(self.time_ids(timestamps))
+        out = None
+        if want_output:
+            out = torch.empty((T * self.cfg.tokens_per_frame, self.cfg.hidden_size), dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.trace_encode_video(self.h, _ptr(frames), dt, T, ids, _ptr(out), _stream()))
+        return out
+
+    def splice(self, input_ids: Sequence[int], time_rows: Sequence[int] = (), score_rows: Sequence[int] = (),
+               want_output: bool = False):
+        ids = _i32(input_ids)
+        tr, sr = _i32(time_rows), _i32(score_rows)
+        L = C.c_int(0)
+        # length is known up-front: n_ids - 1 + video rows; allocate generously when a copy is requested
+        out = None
+        if want_output:
+            out = torch.empty((self.max_ctx, self.cfg.hidden_size), dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.trace_splice_embeds(self.h, ids, len(ids), tr, len(tr), sr, len(sr), C.byref(L), _ptr(out), _stream()))
+        return (L.value, out[: L.value]) if want_output else L.value
+
+    def prefill(self, slot: int, L: int, embeds: Optional[torch.Tensor] = None, want_hidden: bool = False):
+        hid = torch.empty((L, self.cfg.hidden_size), dtype=torch.bfloat16, device=self.device) if want_hidden else None
+        if embeds is not None:
+            embeds = embeds.to(self.device, torch.bfloat16).contiguous()
+        _lib.check(self.lib.trace_llm_prefill(self.h, slot, _ptr(embeds), L, _ptr(hid), _stream()))
+        return hid
+
+    # ---- decode --------------------------------------------------------------------------------
+    def decode_begin(self, slots: Sequence[int], heads: Sequence[int], max_new: int, eos: int = -1,
+                     forced: Optional[Sequence[Sequence[int]]] = None, want_logits: bool = False):
+        B = len(slots)
+        self._B, self._max_new = B, max_new
+        f = None
+        if forced is not None:
+            flat = []
+            for row in forced:
+                row = list(row)[:max_new]
+                flat += row + [0] * (max_new - len(row))
+            f = _i32(flat)
+        lg = torch.empty((B, self.cfg.total_vocab), dtype=torch.float32, device=self.device) if want_logits else None
+        _lib.check(self.lib.trace_decode_begin(self.h, _i32(slots), B, _i32(heads), max_new, eos, f, _ptr(lg), _stream()))
+        return lg
+
+    def decode_steps(self, n: int, use_graph: bool = True, want_logits: bool = False):
+        lg = None
+        if want_logits:
+            lg = torch.empty((self._B, self.cfg.total_vocab), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.trace_decode_steps(self.h, n, 1 if use_graph else 0, _ptr(lg), _stream()))
+        return lg
+
+    def decode_read(self):
+        B, mn = self._B, self._max_new
+        ids = (C.c_int32 * (B * mn))()
+        ln = (C.c_int32 * B)()
+        hd = (C.c_int32 * B)()
+        _lib.check(self.lib.trace_decode_read(self.h, ids, ln, hd, _stream()))
+        out = [[ids[b * mn + i] for i in range(ln[b])] for b in range(B)]
+        return out, list(hd)
+
+    def set_profile(self, on: bool):
+        _lib.check(self.lib.trace_set_profile(self.h, 1 if on else 0))
+
+    def get_profile(self) -> List[float]:
+        buf = (C.c_float * 8)()
+        _lib.check(self.lib.trace_get_profile(self.h, buf, 8))
+        return list(buf)
+
+    # ---- one-call convenience: what generate() does for one batch of videos ----------------------
+    def generate(self, videos: Sequence[torch.Tensor], timestamps: Sequence, input_ids: Sequence[Sequence[int]],
+                 heads: Sequence[int], max_new_tokens: int, eos: int = -1, use_graph: bool = True,
+                 forced: Optional[Sequence[Sequence[int]]] = None):
+        B = len(videos)
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} exceeds engine max_batch {self.max_batch}")
+        for b in range(B):
+            self.encode_video(videos[b], timestamps[b])
+            L = self.splice(input_ids[b])
+            self.prefill(b, L)
+        self.decode_begin(list(range(B)), heads, max_new_tokens, eos, forced)
+        if max_new_tokens > 1:
+            if eos < 0:
+                self.decode_steps(max_new_tokens - 1, use_graph)
+            else:
+                done, chunk = 0, 32
+                while done < max_new_tokens - 1:
+                    n = min(chunk, max_new_tokens - 1 - done)
+                    self.decode_steps(n, use_graph)
+                    done += n
+                    ids, _ = self.decode_read()
+                    if all(len(x) and x[-1] == eos for x in ids):
+                        break
+        return self.decode_read()
+
+
+# ---- kernel-level wrappers for unit tests / microbenchmarks -------------------------------------
+class ops:
+    @staticmethod
+    def gemm(A, W, bias=None, R=None, epilogue=EPI_NONE):
+        lib = _lib.load()
+        M, K = A.shape
+        N = W.shape[0]
+        No = N // 2 if epilogue == EPI_SWIGLU else N
+        Cc = torch.empty((M, No), dtype=torch.bfloat16, device=A.device)
+        _lib.check(lib.trace_op_gemm(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(Cc), No, _ptr(bias), _ptr(R),
+                                     0 if R is None else R.stride(0), M, N, K, epilogue, _stream()))
+        return Cc
+
+    @staticmethod
+    def layernorm(x, w, b, eps):
+        lib = _lib.load()
+        y = torch.empty_like(x)
+        _lib.check(lib.trace_op_layernorm(_ptr(x), _ptr(y), _ptr(w), _ptr(b), x.shape[0], x.shape[1], eps, _stream()))
+        return y
+
+    @staticmethod
+    def rmsnorm(x, w, eps):
+        lib = _lib.load()
+        y = torch.empty_like(x)
+        _lib.check(lib.trace_op_rmsnorm(_ptr(x), _ptr(y), _ptr(w), x.shape[0], x.shape[1], eps, _stream()))
+        return y
+
+    @staticmethod
+    def attention(q, k, v, causal, scale):
+        """q [B, nq, heads, hd]; k, v [B, nkv, kv_heads, hd] -> [B, nq, heads, hd]"""
+        lib = _lib.load()
+        Bn, nq, heads, hd = q.shape
+        nkv, kvh = k.shape[1], k.shape[2]
+        pad = (nkv + 63) // 64 * 64
+        vt = torch.empty((Bn * kvh * hd * pad,), dtype=torch.bfloat16, device=q.device)
+        o = torch.empty_like(q)
+        _lib.check(lib.trace_op_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(vt), Bn, heads, kvh, nq, nkv, hd,
+                                          1 if causal else 0, scale, _stream()))
+        return o
+
+    @staticmethod
+    def skinny_gemm(X, W, R=None, epilogue=EPI_NONE):
+        lib = _lib.load()
+        Bn, K = X.shape
+        N = W.shape[0]
+        No = N // 2 if epilogue == EPI_SWIGLU else N
+        out = torch.empty((Bn, No), dtype=torch.bfloat16, device=X.device)
+        _lib.check(lib.trace_op_skinny_gemm(_ptr(X), _ptr(W), _ptr(out), _ptr(R), Bn, N, K, epilogue, _stream()))
+        return out
+
+    @staticmethod
+    def attn_decode(q, kcache, vcache, pos, nsplit, scale):
+        """q [B, nq*128]; caches [B, nkv, max_ctx, 128]; pos int32 [B] (device)"""
+        lib = _lib.load()
+        Bn = q.shape[0]
+        nkv, max_ctx = kcache.shape[1], kcache.shape[2]
+        nq = q.shape[1] // 128
+        ws = torch.empty((Bn * nq * nsplit * 130,), dtype=torch.float32, device=q.device)
+        o = torch.empty_like(q)
+        _lib.check(lib.trace_op_attn_decode(_ptr(q), _ptr(kcache), _ptr(vcache), _ptr(pos), _ptr(o), _ptr(ws), Bn, nq, nkv,
+                                            max_ctx, nsplit, scale, _stream()))
+        return o

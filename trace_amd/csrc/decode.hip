@@ -328,13 +328,13 @@ __global__ __launch_bounds__(256) void select_next_kernel(const float* __restric
                                                           StepState st, const bf16_t* __restrict__ embed,
                                                           const bf16_t* __restrict__ time_tab, const bf16_t* __restrict__ score_tab,
                                                           const bf16_t* __restrict__ sync_row, bf16_t* __restrict__ xnext, int ldx,
-                                                          int B, int H, int V, int Tv, int Sv, int max_new, int eos, int ntiles,
-                                                          int advance) {
+                                                          int B, int H, int V, int Tv, int Sv, int ntiles, int advance) {
     __shared__ float sv[4];
     __shared__ int si[4];
     __shared__ int s_feed;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int step = *st.step;
+    const int max_new = st.params[0], eos = st.params[1];
     for (int b = 0; b < B; ++b) {
         float v = -INFINITY;
         int idx = 0x7fffffff;
@@ -363,7 +363,10 @@ __global__ __launch_bounds__(256) void select_next_kernel(const float* __restric
                 if (eos >= 0 && tok == eos) st.done[b] = 1;
             }
             int feed = tok;
-            if (st.forced && step < max_new) feed = st.forced[(size_t)b * max_new + step];
+            if (step < max_new) {
+                const int f = st.forced[(size_t)b * max_new + step];
+                if (f >= 0) feed = f;
+            }
             // head switch (trace_mistral.py:86-88): V -> time(1), V+1 -> score(2), V+Tv+1 -> text(0)
             int hd = st.heads[b];
             if (feed == V) hd = 1; else if (feed == V + 1) hd = 2; else if (feed == V + Tv + 1) hd = 0;
@@ -427,10 +430,10 @@ int launch_head_logits(const bf16_t* X, int ldx, const bf16_t* Wh, int H, const 
 
 int launch_select_next(const float* part_val, const int32_t* part_idx, const StepState& st, const bf16_t* embed,
                        const bf16_t* time_tab, const bf16_t* score_tab, const bf16_t* sync_row, bf16_t* xnext, int ldx, int B,
-                       int H, int V, int Tv, int Sv, int max_new, int eos, int advance, hipStream_t s) {
+                       int H, int V, int Tv, int Sv, int advance, hipStream_t s) {
     if (B < 1 || B > 16 || H % 8) return TRACE_ERR_ARG;
     const int ntiles = (V + 1 + Tv + Sv + 15) / 16;
     hipLaunchKernelGGL(select_next_kernel, dim3(1), dim3(256), 0, s, part_val, part_idx, st, embed, time_tab, score_tab,
-                       sync_row, xnext, ldx, B, H, V, Tv, Sv, max_new, eos, ntiles, advance);
+                       sync_row, xnext, ldx, B, H, V, Tv, Sv, ntiles, advance);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }

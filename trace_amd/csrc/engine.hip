@@ -59,14 +59,19 @@ struct trace_ctx {
     bf16_t *dX, *dH, *dQKV, *dO, *dACT, *xlast;   // [16, *]
     float* attn_ws;
     float* part_val; int32_t* part_idx;
-    int32_t *d_slots, *d_pos, *d_heads, *d_done, *d_out_ids, *d_out_len, *d_step, *d_forced;
+    int32_t *d_slots, *d_pos, *d_heads, *d_done, *d_out_ids, *d_out_len, *d_step, *d_forced, *d_params;
     int B = 0, max_new = 0, eos = -1, has_forced = 0, ntiles = 0, nsplit = 16;
     int slot_len[16] = {0};
     hipGraphExec_t graphs[17] = {nullptr};
     hipStream_t cap_stream = nullptr;
     // profiling
-    int profile = 0;
+    int profile = 0;                  // 1: time decode_steps calls; 2: also bracket the layer-0 gate|up GEMV launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> kev;      // event pool for per-launch brackets (eager mode)
+    int kev_used = 0;
+    hipEvent_t gev0 = nullptr, gev1 = nullptr;   // pair recorded from inside the captured graph
+    hipGraphExec_t graphs_prof[17] = {nullptr};
+    double ksum_ms = 0.0; int ksamples = 0;
     float prof[8] = {0};
 };
 
@@ -157,7 +162,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     A(c->attn_ws, (size_t)16 * c->NQ * c->nsplit * (c->HD + 2));
     c->ntiles = c->NVpad / 16;
     A(c->part_val, (size_t)16 * c->ntiles); A(c->part_idx, (size_t)16 * c->ntiles);
-    A(c->d_slots, 16); A(c->d_pos, 16); A(c->d_heads, 16); A(c->d_done, 16); A(c->d_out_len, 16); A(c->d_step, 4);
+    A(c->d_slots, 16); A(c->d_pos, 16); A(c->d_heads, 16); A(c->d_done, 16); A(c->d_out_len, 16); A(c->d_step, 4); A(c->d_params, 4);
     A(c->d_out_ids, (size_t)16 * cfg->max_new_tokens); A(c->d_forced, (size_t)16 * cfg->max_new_tokens);
 #undef A
     if (rc == TRACE_OK && hipHostMalloc((void**)&c->h_kind, Lm * 8) != hipSuccess) rc = fail(TRACE_ERR_HIP, "hipHostMalloc");
@@ -165,6 +170,9 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     c->h_row = c->h_kind + Lm;
     hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking);
     hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
+    hipEventCreate(&c->gev0); hipEventCreate(&c->gev1);
+    c->kev.resize(1024);
+    for (auto& e : c->kev) hipEventCreate(&e);
     *out = c;
     return TRACE_OK;
 }
@@ -173,6 +181,10 @@ extern "C" int trace_ctx_destroy(trace_ctx* c) {
     if (!c) return TRACE_OK;
     hipDeviceSynchronize();
     for (auto& g : c->graphs) if (g) hipGraphExecDestroy(g);
+    for (auto& g : c->graphs_prof) if (g) hipGraphExecDestroy(g);
+    for (auto& e : c->kev) if (e) hipEventDestroy(e);
+    if (c->gev0) hipEventDestroy(c->gev0);
+    if (c->gev1) hipEventDestroy(c->gev1);
     for (void* p : c->allocs) hipFree(p);
     if (c->h_kind) hipHostFree(c->h_kind);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
@@ -505,7 +517,7 @@ extern "C" int trace_llm_prefill(trace_ctx* c, int slot, const void* embeds, int
 static StepState step_state(trace_ctx* c) {
     StepState st{};
     st.heads = c->d_heads; st.pos = c->d_pos; st.done = c->d_done; st.out_ids = c->d_out_ids; st.out_len = c->d_out_len;
-    st.step = c->d_step; st.forced = c->has_forced ? c->d_forced : nullptr;
+    st.step = c->d_step; st.forced = c->d_forced; st.params = c->d_params;
     return st;
 }
 
@@ -513,7 +525,7 @@ static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* l
     LCHK(launch_head_logits(xn, c->H, c->wheads, c->H, c->d_heads, c->V, c->Tv, c->Sv, c->part_val, c->part_idx, logits_out,
                             c->B, s));
     LCHK(launch_select_next(c->part_val, c->part_idx, step_state(c), c->embed, c->time_tab, c->score_tab, c->sync_row, c->dX,
-                            c->H, c->B, c->H, c->V, c->Tv, c->Sv, c->max_new, c->eos, advance, s));
+                            c->H, c->B, c->H, c->V, c->Tv, c->Sv, advance, s));
     return TRACE_OK;
 }
 
@@ -532,7 +544,15 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
                                 H, c->attn_ws, B, c->NQ, c->NKV, HD, c->nsplit, 1.0f / sqrtf((float)HD), s));
         LCHK(launch_skinny_gemm(c->dO, H, W.wo, H, c->dX, H, c->dX, H, B, H, H, EPI_RESIDUAL, s));
         LCHK(launch_rmsnorm(c->dX, H, c->dH, H, W.rms2, B, H, c->c.rms_eps, s));
+        // roofline probe: HIP events around ONE launch of the dominant kernel (layer 0 gate|up GEMV) per step
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (l == 0 && c->profile == 2) {
+            if (s == c->cap_stream) { e0 = c->gev0; e1 = c->gev1; }
+            else if (c->kev_used + 2 <= (int)c->kev.size()) { e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2; }
+        }
+        if (e0) hipEventRecord(e0, s);
         LCHK(launch_skinny_gemm(c->dH, H, W.wgu, H, c->dACT, I, nullptr, 0, B, 2 * I, H, EPI_SWIGLU, s));
+        if (e1) hipEventRecord(e1, s);
         LCHK(launch_skinny_gemm(c->dACT, I, W.wd, I, c->dX, H, c->dX, H, B, H, I, EPI_RESIDUAL, s));
     }
     LCHK(launch_rmsnorm(c->dX, H, c->dH, H, c->final_norm, B, H, c->c.rms_eps, s));
@@ -561,7 +581,10 @@ extern "C" int trace_decode_begin(trace_ctx* c, const int32_t* slots, int B, con
     HIPCHK(hipMemcpyAsync(c->d_out_len, zero, B * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_step, zero, 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(c->d_out_ids, 0, (size_t)B * max_new * 4, s));
+    const int32_t prm[2] = {max_new, eos};
+    HIPCHK(hipMemcpyAsync(c->d_params, prm, 8, hipMemcpyHostToDevice, s));
     if (forced) HIPCHK(hipMemcpyAsync(c->d_forced, forced, (size_t)B * max_new * 4, hipMemcpyHostToDevice, s));
+    else HIPCHK(hipMemsetAsync(c->d_forced, 0xff, (size_t)B * max_new * 4, s));      // -1 = not forced
     // gather the prefill hidden rows of the chosen slots into dH, then head + select (no position advance)
     for (int b = 0; b < B; ++b)
         HIPCHK(hipMemcpyAsync(c->dH + (size_t)b * c->H, c->xlast + (size_t)slots[b] * c->H, (size_t)c->H * 2, hipMemcpyDeviceToDevice, s));
@@ -579,7 +602,8 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
         for (int i = 0; i < n; ++i) TRY(decode_step(c, logits_out, s));
     } else {
         const int key = c->B;
-        if (!c->graphs[key]) {
+        hipGraphExec_t* slot_g = c->profile == 2 ? &c->graphs_prof[key] : &c->graphs[key];
+        if (!*slot_g) {
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamSynchronize(s));
             HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeGlobal));
@@ -587,11 +611,24 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
             hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
             if (rc != TRACE_OK) { if (g) hipGraphDestroy(g); return rc; }
             if (e != hipSuccess) return fail(TRACE_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-            e = hipGraphInstantiate(&c->graphs[key], g, nullptr, nullptr, 0);
+            e = hipGraphInstantiate(slot_g, g, nullptr, nullptr, 0);
             hipGraphDestroy(g);
-            if (e != hipSuccess) { c->graphs[key] = nullptr; return fail(TRACE_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+            if (e != hipSuccess) { *slot_g = nullptr; return fail(TRACE_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
         }
-        for (int i = 0; i < n; ++i) HIPCHK(hipGraphLaunch(c->graphs[key], s));
+        for (int i = 0; i < n; ++i) HIPCHK(hipGraphLaunch(*slot_g, s));
+        if (c->profile == 2 && n > 0) {      // the pair recorded by the last replay
+            hipStreamSynchronize(s);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->gev0, c->gev1) == hipSuccess && ms > 0.f) { c->ksum_ms += ms; c->ksamples += 1; }
+        }
+    }
+    if (c->profile == 2 && c->kev_used > 0) {   // drain the eager-mode brackets
+        hipStreamSynchronize(s);
+        for (int i = 0; i + 1 < c->kev_used; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->kev[i], c->kev[i + 1]) == hipSuccess) { c->ksum_ms += ms; c->ksamples += 1; }
+        }
+        c->kev_used = 0;
     }
     if (c->profile) {
         hipEventRecord(c->ev1, s);
@@ -600,6 +637,9 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
         hipEventElapsedTime(&ms, c->ev0, c->ev1);
         c->prof[0] = n > 0 ? ms / n : 0.f;
         c->prof[1] = (float)n;
+        c->prof[2] = c->ksamples ? (float)(c->ksum_ms / c->ksamples) : 0.f;
+        c->prof[3] = (float)c->ksamples;
+        c->prof[4] = (float)(2.0 * c->I * c->H * 2.0);      // algorithmic bytes of the bracketed launch (gate|up weights)
     }
     return TRACE_OK;
 }
@@ -614,7 +654,11 @@ extern "C" int trace_decode_read(trace_ctx* c, int32_t* out_ids, int32_t* out_le
     return TRACE_OK;
 }
 
-extern "C" int trace_set_profile(trace_ctx* c, int on) { if (!c) return fail(TRACE_ERR_ARG, "null ctx"); c->profile = on; return TRACE_OK; }
+extern "C" int trace_set_profile(trace_ctx* c, int on) {
+    if (!c) return fail(TRACE_ERR_ARG, "null ctx");
+    c->profile = on; c->ksum_ms = 0.0; c->ksamples = 0; c->kev_used = 0;
+    return TRACE_OK;
+}
 extern "C" int trace_get_profile(trace_ctx* c, float* out, int n) {
     if (!c || !out) return fail(TRACE_ERR_ARG, "null argument");
     for (int i = 0; i < n && i < 8; ++i) out[i] = c->prof[i];

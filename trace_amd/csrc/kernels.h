@@ -89,8 +89,9 @@ struct StepState {
     int32_t* out_ids;     // [B, max_new]
     int32_t* out_len;     // [B]
     int32_t* step;        // [1] device step counter
-    const int32_t* forced;// [B, max_new] teacher-forcing ids or null
+    const int32_t* forced;// [B, max_new] teacher-forcing ids; negative entry = feed the arg-max
+    const int32_t* params;// device [2]: max_new, eos  (device-resident so a captured graph stays valid)
 };
 int launch_select_next(const float* part_val, const int32_t* part_idx, const StepState& st, const bf16_t* embed,
                        const bf16_t* time_tab, const bf16_t* score_tab, const bf16_t* sync_row, bf16_t* xnext, int ldx,
-                       int B, int H, int V, int Tv, int Sv, int max_new, int eos, int advance, hipStream_t s);
+                       int B, int H, int V, int Tv, int Sv, int advance, hipStream_t s);

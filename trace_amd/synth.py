@@ -86,10 +86,13 @@ def weight_specs(cfg: TraceConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
 
 
 def synth_tensor(name: str, shape: Tuple[int, ...], kind: str, dtype=torch.bfloat16,
-                 base_seed: int = BASE_SEED) -> torch.Tensor:
-    g = torch.Generator(device="cpu")
+                 base_seed: int = BASE_SEED, device: str = "cpu") -> torch.Tensor:
+    """device="cpu" is the canonical stream (what the oracle, the goldens and the parity tests use);
+    device="cuda" draws from the device generator instead (different values, same distribution) so a
+    7B-parameter throughput run does not wait on a host RNG."""
+    g = torch.Generator(device=device)
     g.manual_seed((zlib.crc32(name.encode()) + base_seed) & 0x7FFFFFFF)
-    x = torch.randn(shape, generator=g, dtype=torch.float32)
+    x = torch.randn(shape, generator=g, dtype=torch.float32, device=device)
     if kind == "w":
         x = x * 0.02
     elif kind == "norm":
@@ -106,11 +109,11 @@ def synth_tensor(name: str, shape: Tuple[int, ...], kind: str, dtype=torch.bfloa
     return x.to(dtype)
 
 
-def iter_weights(cfg: TraceConfig, dtype=torch.bfloat16, base_seed: int = BASE_SEED
+def iter_weights(cfg: TraceConfig, dtype=torch.bfloat16, base_seed: int = BASE_SEED, device: str = "cpu"
                  ) -> Iterator[Tuple[str, torch.Tensor]]:
     """Streams (name, tensor) one at a time so a 7B model never has to sit in host RAM twice."""
     for name, shape, kind in weight_specs(cfg):
-        yield name, synth_tensor(name, shape, kind, dtype, base_seed)
+        yield name, synth_tensor(name, shape, kind, dtype, base_seed, device)
 
 
 def state_dict(cfg: TraceConfig, dtype=torch.bfloat16, base_seed: int = BASE_SEED) -> Dict[str, torch.Tensor]:

@@ -161,7 +161,12 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": k_bytes, "avg_launch_ms": k_ms, "samples": k_n},
         }
         if not args.no_cpu_baseline and not args.tiny:
-            line["cpu_baseline"] = cpu_baseline(cfg, n_new, os.cpu_count() or 1)
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 1
+            # cap the thread count: the oracle's small per-head matmuls degrade badly when oversubscribed
+            line["cpu_baseline"] = cpu_baseline(cfg, n_new, max(1, min(32, cores)))
         elif args.tiny:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -63,6 +63,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64; load it first so this library binds to the same HIP runtime
+    # instance (two runtimes in one process cannot both own the device: "no ROCm-capable device is detected").
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise TraceHipError(
             f"{LIB_PATH} is missing: build it with `python -m trace_amd.build` (hipcc, gfx950). "

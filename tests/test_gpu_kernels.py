@@ -40,15 +40,23 @@ def check(name, got, ref, atol, rtol):
         pytest.fail(msg)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 256, 128), (577, 384, 1024), (1, 128, 64), (1000, 1024, 640)])
-def test_gemm_plain_bias(M, N, K):
+@pytest.fixture(params=[0, 1, 2, 3], ids=["auto", "v1", "glds128", "glds256"])
+def gemm_variant(request):
+    ops.set_gemm_variant(request.param)
+    yield request.param
+    ops.set_gemm_variant(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 256, 128), (577, 384, 1024), (1, 128, 64), (1000, 1024, 640),
+                                   (2100, 512, 192)])
+def test_gemm_plain_bias(M, N, K, gemm_variant):
     A, W, b = rnd(M, K), rnd(N, K, scale=0.05), rnd(N, scale=0.5)
     ref = A.float() @ W.float().t() + b.float()
     check("gemm+bias", ops.gemm(A, W, bias=b), ref, 2e-2, 1e-2)
     check("gemm", ops.gemm(A, W), A.float() @ W.float().t(), 2e-2, 1e-2)
 
 
-def test_gemm_asymmetric_layout():
+def test_gemm_asymmetric_layout(gemm_variant):
     # transpose-detecting: A rows and W rows carry different, non-symmetric patterns
     M, N, K = 256, 256, 128
     A = torch.zeros(M, K)
@@ -61,8 +69,8 @@ def test_gemm_asymmetric_layout():
     check("gemm layout", ops.gemm(A, W), A.float() @ W.float().t(), 1e-3, 1e-3)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (64, 128, 4096)])
-def test_gemm_epilogues(M, N, K):
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (64, 128, 4096), (1300, 512, 256)])
+def test_gemm_epilogues(M, N, K, gemm_variant):
     A, W, b, R = rnd(M, K), rnd(N, K, scale=0.05), rnd(N, scale=0.5), rnd(M, N)
     lin = A.float() @ W.float().t() + b.float()
     check("residual", ops.gemm(A, W, bias=b, R=R, epilogue=E.EPI_RESIDUAL), lin.to(torch.bfloat16).float() + R.float(), 3e-2, 1e-2)

@@ -34,6 +34,8 @@ def rnd(*shape, scale=1.0):
 
 res = []
 quick = "--quick" in sys.argv
+variants = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--variant=")] or [0]
+only_gemm = "--gemm-only" in sys.argv
 # --- prefill-shaped GEMMs (ViT M = 128*577, LLM M = 1968)
 for name, M, N, K, epi in [
     ("vit_qkv", 73856, 3072, 1024, E.EPI_NONE), ("vit_out", 73856, 1024, 1024, E.EPI_RESIDUAL),
@@ -47,11 +49,16 @@ for name, M, N, K, epi in [
     b = rnd(N) if "vit" in name else None
     No = N // 2 if epi == E.EPI_SWIGLU else N
     R = rnd(M, No) if epi == E.EPI_RESIDUAL else None
-    ms = timeit(lambda: ops.gemm(A, W, bias=b, R=R, epilogue=epi), iters=5)
-    tf = 2.0 * M * N * K / ms / 1e9
-    res.append({"kernel": "gemm_" + name, "M": M, "N": N, "K": K, "ms": ms, "TFLOPs": tf, "mfma_frac": tf / 2500})
-    print(res[-1], flush=True)
+    for v in variants:
+        ops.set_gemm_variant(v)
+        ms = timeit(lambda: ops.gemm(A, W, bias=b, R=R, epilogue=epi), iters=5)
+        tf = 2.0 * M * N * K / ms / 1e9
+        res.append({"kernel": "gemm_" + name, "variant": v, "M": M, "N": N, "K": K, "ms": round(ms, 4), "TFLOPs": round(tf, 1), "mfma_frac": round(tf / 2500, 3)})
+        print(res[-1], flush=True)
+    ops.set_gemm_variant(0)
     del A, W, R
+if only_gemm:
+    sys.exit(0)
 # --- attention
 for name, Bn, n, heads, kvh, hd, causal in [("attn_vit", 32 if quick else 128, 577, 16, 16, 64, False), ("attn_prefill", 1, 1968, 32, 8, 128, True)]:
     q, k, v = rnd(Bn, n, heads, hd), rnd(Bn, n, kvh, hd), rnd(Bn, n, kvh, hd)

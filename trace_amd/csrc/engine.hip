@@ -671,6 +671,12 @@ extern "C" int trace_op_gemm(const void* A, int lda, const void* W, int ldw, voi
     return gemm((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (bf16_t*)C, ldc, (const bf16_t*)bias, (const bf16_t*)R, ldr, M, N, K,
                 epilogue, (hipStream_t)stream);
 }
+extern int g_gemm_variant;
+extern "C" int trace_op_set_gemm_variant(int variant) {
+    if (variant < 0 || variant > 3) return fail(TRACE_ERR_ARG, "variant must be 0..3");
+    g_gemm_variant = variant;
+    return TRACE_OK;
+}
 extern "C" int trace_op_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, float eps, void* stream) {
     LCHK(launch_layernorm((const bf16_t*)x, D, (bf16_t*)y, D, (const bf16_t*)w, (const bf16_t*)b, rows, D, eps, (hipStream_t)stream));
     return TRACE_OK;

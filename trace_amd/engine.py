@@ -209,6 +209,10 @@ class TraceEngine:
 # ---- kernel-level wrappers for unit tests / microbenchmarks -------------------------------------
 class ops:
     @staticmethod
+    def set_gemm_variant(v: int):
+        _lib.check(_lib.load().trace_op_set_gemm_variant(v))
+
+    @staticmethod
     def gemm(A, W, bias=None, R=None, epilogue=EPI_NONE):
         lib = _lib.load()
         M, K = A.shape

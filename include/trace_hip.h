@@ -105,7 +105,7 @@ int trace_op_rmsnorm(const void* x, void* y, const void* w, int rows, int D, flo
 int trace_op_attention(const void* Q, const void* K, const void* V, void* O, void* vt_scratch, int batch, int heads,
                        int kv_heads, int nq, int nkv, int head_dim, int causal, float scale, void* stream);
 int trace_op_skinny_gemm(const void* X, const void* W, void* out, const void* R, int B, int N, int K, int epilogue,
-                         void* stream);
+                         const void* rms_gamma, float rms_eps, void* stream);
 int trace_op_attn_decode(const void* q, const void* kcache, const void* vcache, const int32_t* pos, void* O, float* ws,
                          int B, int nq, int nkv, int max_ctx, int nsplit, float scale, void* stream);
 

@@ -150,6 +150,11 @@ def test_skinny_gemm(Bn, N, K):
         Wp = torch.stack([Wg.reshape(-1, 16, K), Wu.reshape(-1, 16, K)], dim=1).reshape(N, K).contiguous()
         g, u = X.float() @ Wg.float().t(), X.float() @ Wu.float().t()
         check("skinny swiglu", ops.skinny_gemm(X, Wp, epilogue=E.EPI_SWIGLU), torch.nn.functional.silu(g) * u, 3e-2, 1e-2)
+    # fused RMSNorm prologue
+    gam = 1 + rnd(K, scale=0.1, seed=9)
+    xf = X.float()
+    xn = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * gam.float()).to(torch.bfloat16).float()
+    check("skinny rmsnorm", ops.skinny_gemm(X, W, gamma=gam, eps=1e-5), xn @ W.float().t(), 3e-2, 1e-2)
 
 
 @pytest.mark.parametrize("Bn,ctxs", [(1, [80]), (3, [1, 200, 2047]), (2, [16, 17])])
@@ -160,6 +165,8 @@ def test_attn_decode(Bn, ctxs):
     pos = torch.tensor([c - 1 for c in ctxs], dtype=torch.int32, device=DEV)
     sc = 1 / math.sqrt(128)
     out = ops.attn_decode(q, kc, vc, pos, 16, sc)
+    out2 = ops.attn_decode(q, kc, vc, pos, 32, sc)      # second launch re-uses the ticket counters
+    assert torch.equal(out, out2) or (out.float() - out2.float()).abs().max() < 2e-2
     for b, ctx in enumerate(ctxs):
         qq = q[b].view(1, 1, nq, 128)
         kk = kc[b, :, :ctx].permute(1, 0, 2).unsqueeze(0)

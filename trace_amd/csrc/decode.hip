@@ -25,13 +25,19 @@ __device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
 union Frag { uint4 u; bf16x8_t v; };
 
 // ---------------------------------------------------------------------------------------------------------
-template <int EPI>
+// NORM: X is the raw residual stream; the RMSNorm (gamma, eps) of the reference's input_layernorm /
+// post_attention_layernorm is applied on the fly: every workgroup recomputes the B row scales (8 KB per row from
+// L2) while its first weight loads are in flight, and each lane scales + rounds its activation fragment to bf16
+// (the same rounding point as a separate norm kernel) right before the MFMA.
+template <int EPI, bool NORM>
 __global__ __launch_bounds__(512) void skinny_gemm_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W,
                                                           int ldw, bf16_t* __restrict__ out, int ldo,
-                                                          const bf16_t* __restrict__ R, int ldr, int B, int N, int K) {
+                                                          const bf16_t* __restrict__ R, int ldr, int B, int N, int K,
+                                                          const bf16_t* __restrict__ gamma, float eps) {
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;      // 16-row weight tiles per workgroup
     constexpr int UN = 2;                                // 64-wide k units per batch (4 x 16 B per lane per tile)
     __shared__ float red[8][NT][256];
+    __shared__ float s_ss[8][16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16 * NT;
@@ -48,6 +54,8 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const bf16_t* __restri
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    const bf16_t* gp = NORM ? gamma + g * 16 : nullptr;
+    float rs = 1.f;
     Frag wa[UN][NT][2], wb[UN][NT][2], xa[UN][2], xb[UN][2];
     auto load = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][2], int u) {
 #pragma unroll
@@ -63,23 +71,62 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const bf16_t* __restri
             xf[j][1].u = (ok && xon) ? *reinterpret_cast<const uint4*>(xp + ko + 8) : make_uint4(0, 0, 0, 0);
         }
     };
-    auto mma = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][2]) {
+    auto scale = [&](Frag& x, int ko) {          // x <- bf16(x * rs * gamma[k])
+        const uint4 gq = *reinterpret_cast<const uint4*>(gp + ko);
+        x.u.x = pack2bf(bflo(x.u.x) * rs * bflo(gq.x), bfhi(x.u.x) * rs * bfhi(gq.x));
+        x.u.y = pack2bf(bflo(x.u.y) * rs * bflo(gq.y), bfhi(x.u.y) * rs * bfhi(gq.y));
+        x.u.z = pack2bf(bflo(x.u.z) * rs * bflo(gq.z), bfhi(x.u.z) * rs * bfhi(gq.z));
+        x.u.w = pack2bf(bflo(x.u.w) * rs * bflo(gq.w), bfhi(x.u.w) * rs * bfhi(gq.w));
+    };
+    auto mma = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][2], int u) {
 #pragma unroll
-        for (int j = 0; j < UN; ++j)
+        for (int j = 0; j < UN; ++j) {
+            if (NORM && xon && u + j < u1) { scale(xf[j][0], (u + j) * 64); scale(xf[j][1], (u + j) * 64 + 8); }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][t][0].v, xf[j][0].v, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][t][1].v, xf[j][1].v, acc[t], 0, 0, 0);
             }
+        }
     };
+    if (u0 < u1) load(wa, xa, u0);                 // weights start streaming before the norm statistics
+    if (NORM) {
+        float ss[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) ss[m] = 0.f;
+        for (int k = tid * 8; k < K; k += 512 * 8) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (m < B) {
+                    const uint4 u = *reinterpret_cast<const uint4*>(X + (size_t)m * ldx + k);
+                    const float a0 = bflo(u.x), a1 = bfhi(u.x), a2 = bflo(u.y), a3 = bfhi(u.y);
+                    const float a4 = bflo(u.z), a5 = bfhi(u.z), a6 = bflo(u.w), a7 = bfhi(u.w);
+                    ss[m] += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5 + a6 * a6 + a7 * a7;
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (m < B) {
+                const float t = wave_sum(ss[m]);
+                if (lane == 0) s_ss[wid][m] = t;
+            }
+        }
+        __syncthreads();
+        if (xon) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += s_ss[w][r];
+            rs = rsqrtf(t / (float)K + eps);
+        }
+    }
     if (u0 < u1) {
-        load(wa, xa, u0);
         for (int u = u0; u < u1; u += 2 * UN) {
             if (u + UN < u1) load(wb, xb, u + UN);
-            mma(wa, xa);
+            mma(wa, xa, u);
             if (u + UN < u1) {
                 if (u + 2 * UN < u1) load(wa, xa, u + 2 * UN);
-                mma(wb, xb);
+                mma(wb, xb, u + UN);
             }
         }
     }
@@ -114,95 +161,153 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const bf16_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// grid (nsplit, nkv, B); 256 threads.  ws layout per (b, q-head, split): [hd] o (unnormalised) then m, l.
-constexpr int AD_MAXCHUNK = 1024;
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ kcache,
-                                                          const bf16_t* __restrict__ vcache, long slot_stride,
-                                                          long kv_head_stride, const int32_t* __restrict__ slots,
-                                                          const int32_t* __restrict__ pos, float* __restrict__ ws, int nq,
-                                                          int nkv, int nsplit, float scale) {
-    constexpr int HD = 128, GQ = 4;
-    __shared__ float s_p[GQ][AD_MAXCHUNK];
+// Single-query GQA attention over the KV cache, one launch per layer: RoPE of q / the new k, the KV-cache
+// append, the split-context partial attention and the cross-split combine are all in this kernel.
+// grid (nsplit, nkv, B), 256 threads; 16 lanes per cache row (16 B each = one 256-byte row per 16-lane group),
+// every lane pre-loads its K and V rows up front so the two HBM round trips overlap.  Partials go to `ws`
+// ([b][q-head][split][hd + 2] fp32); the last-arriving workgroup of a (b, kv-head) pair — agent-scope release
+// before the ticket, agent-scope acquire after it, counter re-zeroed by that workgroup — merges them.
+constexpr int AD_MAXIT = 8;            // rows per 16-lane group: chunk <= 16 * AD_MAXIT = 128 rows per split
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ qkv, int ldq, bf16_t* __restrict__ kcache,
+                                                          bf16_t* __restrict__ vcache, long slot_stride, long kv_head_stride,
+                                                          const int32_t* __restrict__ slots, const int32_t* __restrict__ pos,
+                                                          float* __restrict__ ws, unsigned int* __restrict__ tickets,
+                                                          bf16_t* __restrict__ O, int ldo, int nq, int nkv, int nsplit,
+                                                          float scale, int fuse_rope, const float* __restrict__ cos_t,
+                                                          const float* __restrict__ sin_t) {
+    constexpr int HD = 128, GQ = 4, CH = 16 * AD_MAXIT;
+    __shared__ float s_p[GQ][CH];
     __shared__ float s_o[GQ][HD];
+    __shared__ float s_red[4][GQ][2];
     __shared__ float s_ml[GQ][2];
+    __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane >> 4, c = lane & 15;
     const int sp = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
-    const int ctx = pos[b] + 1;
+    const int p_new = pos[b];
+    const int ctx = p_new + 1;
     int chunk = (ctx + nsplit - 1) / nsplit;
-    chunk = min((chunk + 15) & ~15, AD_MAXCHUNK);
+    chunk = (chunk + 15) & ~15;
     const int beg = sp * chunk, end = min(ctx, beg + chunk);
     const int len = max(end - beg, 0);
-    const bf16_t* kb = kcache + (size_t)slots[b] * slot_stride + (size_t)kvh * kv_head_stride;
-    const bf16_t* vb = vcache + (size_t)slots[b] * slot_stride + (size_t)kvh * kv_head_stride;
+    bf16_t* kb = kcache + (size_t)slots[b] * slot_stride + (size_t)kvh * kv_head_stride;
+    bf16_t* vb = vcache + (size_t)slots[b] * slot_stride + (size_t)kvh * kv_head_stride;
+
+    // ---- issue the cache loads first (rows beg + it*16 + wid*4 + j) ----
+    uint4 kr[AD_MAXIT], vr[AD_MAXIT];
+#pragma unroll
+    for (int it = 0; it < AD_MAXIT; ++it) {
+        const int i = it * 16 + wid * 4 + j;
+        const bool ok = i < len && !(fuse_rope && beg + i == p_new);
+        kr[it] = ok ? *reinterpret_cast<const uint4*>(kb + (size_t)(beg + i) * HD + c * 8) : make_uint4(0, 0, 0, 0);
+        vr[it] = ok ? *reinterpret_cast<const uint4*>(vb + (size_t)(beg + i) * HD + c * 8) : make_uint4(0, 0, 0, 0);
+    }
     for (int i = tid; i < GQ * HD; i += 256) (&s_o[0][0])[i] = 0.f;
 
+    // ---- q (4 heads of this kv group) and, when fused, RoPE + the new k/v row ----
     float qv[GQ][8];
+    uint4 knew = make_uint4(0, 0, 0, 0), vnew = make_uint4(0, 0, 0, 0);
+    {
+        const bf16_t* row = qkv + (size_t)b * ldq;
+        float cs[8], sn[8];
+        if (fuse_rope) {
+            const float4* cp = reinterpret_cast<const float4*>(cos_t + (size_t)p_new * (HD / 2) + (c & 7) * 8);
+            const float4* sq = reinterpret_cast<const float4*>(sin_t + (size_t)p_new * (HD / 2) + (c & 7) * 8);
+            const float4 c0 = cp[0], c1 = cp[1], s0 = sq[0], s1 = sq[1];
+            cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
+            sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+        }
+        const float sgn = c < 8 ? -1.f : 1.f;      // first half: x*cos - partner*sin ; second half: x*cos + partner*sin
+        auto rot = [&](const bf16_t* head, float* out) {
+            const uint4 u = *reinterpret_cast<const uint4*>(head + c * 8);
+            const float x[8] = {bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y), bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
+            if (!fuse_rope) {
 #pragma unroll
-    for (int hq = 0; hq < GQ; ++hq) {
-        const uint4 u = *reinterpret_cast<const uint4*>(q + (size_t)b * ldq + (size_t)(kvh * GQ + hq) * HD + c * 8);
-        qv[hq][0] = bflo(u.x); qv[hq][1] = bfhi(u.x); qv[hq][2] = bflo(u.y); qv[hq][3] = bfhi(u.y);
-        qv[hq][4] = bflo(u.z); qv[hq][5] = bfhi(u.z); qv[hq][6] = bflo(u.w); qv[hq][7] = bfhi(u.w);
+                for (int e = 0; e < 8; ++e) out[e] = x[e];
+                return;
+            }
+            const uint4 w = *reinterpret_cast<const uint4*>(head + (c ^ 8) * 8);
+            const float y[8] = {bflo(w.x), bfhi(w.x), bflo(w.y), bfhi(w.y), bflo(w.z), bfhi(w.z), bflo(w.w), bfhi(w.w)};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[e] = bf2f(f2bf(x[e] * cs[e] + sgn * y[e] * sn[e]));   // bf16 like the stored q/k
+        };
+#pragma unroll
+        for (int hq = 0; hq < GQ; ++hq) rot(row + (size_t)(kvh * GQ + hq) * HD, qv[hq]);
+        if (fuse_rope) {
+            float kn[8];
+            rot(row + (size_t)(nq + kvh) * HD, kn);
+            knew = make_uint4(pack2bf(kn[0], kn[1]), pack2bf(kn[2], kn[3]), pack2bf(kn[4], kn[5]), pack2bf(kn[6], kn[7]));
+            vnew = *reinterpret_cast<const uint4*>(row + (size_t)(nq + nkv + kvh) * HD + c * 8);
+            if (len > 0 && end == ctx && wid == 0 && j == 0) {      // the split that owns the newest row appends it to the cache
+                *reinterpret_cast<uint4*>(kb + (size_t)p_new * HD + c * 8) = knew;
+                *reinterpret_cast<uint4*>(vb + (size_t)p_new * HD + c * 8) = vnew;
+            }
+        }
     }
     // ---- scores ----
-    for (int i0 = wid * 4; i0 < len; i0 += 16) {
-        const int i = i0 + j;
-        float part[GQ] = {0.f, 0.f, 0.f, 0.f};
-        if (i < len) {
-            const uint4 u = *reinterpret_cast<const uint4*>(kb + (size_t)(beg + i) * HD + c * 8);
-            const float kv[8] = {bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y), bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
+    float mloc[GQ] = {-1e30f, -1e30f, -1e30f, -1e30f};
 #pragma unroll
-            for (int hq = 0; hq < GQ; ++hq)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) part[hq] += qv[hq][e] * kv[e];
-        }
+    for (int it = 0; it < AD_MAXIT; ++it) {
+        if (it * 16 >= len) break;
+        const int i = it * 16 + wid * 4 + j;
+        const uint4 u = (fuse_rope && beg + i == p_new) ? knew : kr[it];
+        const float kv[8] = {bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y), bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
+        float part[GQ];
 #pragma unroll
         for (int hq = 0; hq < GQ; ++hq) {
+            float a = 0.f;
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) part[hq] += __shfl_xor(part[hq], o, 64);
+            for (int e = 0; e < 8; ++e) a += qv[hq][e] * kv[e];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+            part[hq] = i < len ? a * scale : -1e30f;
+            mloc[hq] = fmaxf(mloc[hq], part[hq]);
         }
         if (c == 0 && i < len) {
 #pragma unroll
-            for (int hq = 0; hq < GQ; ++hq) s_p[hq][i] = part[hq] * scale;
+            for (int hq = 0; hq < GQ; ++hq) s_p[hq][i] = part[hq];
         }
     }
-    __syncthreads();
-    // ---- softmax over the chunk: wave w owns q-head w ----
-    {
-        float mx = -1e30f;
-        for (int i = lane; i < len; i += 64) mx = fmaxf(mx, s_p[wid][i]);
-        mx = wave_max(mx);
-        float sm = 0.f;
-        for (int i = lane; i < len; i += 64) {
-            const float p = __expf(s_p[wid][i] - mx);
-            s_p[wid][i] = p;
-            sm += p;
-        }
-        sm = wave_sum(sm);
-        if (lane == 0) { s_ml[wid][0] = mx; s_ml[wid][1] = sm; }
+    // block max per head
+#pragma unroll
+    for (int hq = 0; hq < GQ; ++hq) {
+        float m = fmaxf(mloc[hq], __shfl_xor(mloc[hq], 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (lane == 0) s_red[wid][hq][0] = m;
     }
     __syncthreads();
-    // ---- o[hq, d] = sum_i p[hq, i] * V[i, d] ----
+    float mx[GQ];
+#pragma unroll
+    for (int hq = 0; hq < GQ; ++hq) mx[hq] = fmaxf(fmaxf(s_red[0][hq][0], s_red[1][hq][0]), fmaxf(s_red[2][hq][0], s_red[3][hq][0]));
+    // ---- p = exp(s - max), o += p * V, l += p ----
     float acc[GQ][8];
+    float lsum[GQ] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int hq = 0; hq < GQ; ++hq)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[hq][e] = 0.f;
-    for (int i0 = wid * 4; i0 < len; i0 += 16) {
-        const int i = i0 + j;
+#pragma unroll
+    for (int it = 0; it < AD_MAXIT; ++it) {
+        if (it * 16 >= len) break;
+        const int i = it * 16 + wid * 4 + j;
         if (i < len) {
-            const uint4 u = *reinterpret_cast<const uint4*>(vb + (size_t)(beg + i) * HD + c * 8);
+            const uint4 u = (fuse_rope && beg + i == p_new) ? vnew : vr[it];
             const float vv[8] = {bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y), bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
 #pragma unroll
             for (int hq = 0; hq < GQ; ++hq) {
-                const float p = s_p[hq][i];
+                const float p = __expf(s_p[hq][i] - mx[hq]);
+                lsum[hq] += p;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[hq][e] += p * vv[e];
             }
         }
     }
 #pragma unroll
-    for (int hq = 0; hq < GQ; ++hq)
+    for (int hq = 0; hq < GQ; ++hq) {
+        float l = lsum[hq];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (lane == 0) s_red[wid][hq][1] = l;          // every 16-lane group holds the same p's: take group c==0 of each j
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float v = acc[hq][e];
@@ -210,30 +315,46 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
             v += __shfl_xor(v, 32, 64);
             if (j == 0) atomicAdd(&s_o[hq][c * 8 + e], v);
         }
+    }
     __syncthreads();
+    {
+        const size_t base = (((size_t)b * nq + kvh * GQ) * nsplit + sp) * (HD + 2);
+        for (int i = tid; i < GQ * HD; i += 256) {
+            const int hq = i >> 7, d = i & 127;
+            ws[base + (size_t)hq * nsplit * (HD + 2) + d] = s_o[hq][d];
+        }
+        if (tid < GQ) {
+            ws[base + (size_t)tid * nsplit * (HD + 2) + HD] = mx[tid];
+            ws[base + (size_t)tid * nsplit * (HD + 2) + HD + 1] = s_red[0][tid][1] + s_red[1][tid][1] + s_red[2][tid][1] + s_red[3][tid][1];
+        }
+    }
+    // ---- publish + ticket; the last arriver of this (b, kv-head) merges the splits ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(&tickets[b * nkv + kvh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == (unsigned)(nsplit - 1));
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
     for (int i = tid; i < GQ * HD; i += 256) {
         const int hq = i >> 7, d = i & 127;
-        float* w = ws + (((size_t)b * nq + kvh * GQ + hq) * nsplit + sp) * (HD + 2);
-        w[d] = s_o[hq][d];
-        if (d == 0) { w[HD] = s_ml[hq][0]; w[HD + 1] = s_ml[hq][1]; }
+        const float* w = ws + (((size_t)b * nq + kvh * GQ + hq) * nsplit) * (HD + 2);
+        float M = -1e30f;
+        for (int s2 = 0; s2 < nsplit; ++s2) M = fmaxf(M, w[s2 * (HD + 2) + HD]);
+        float num = 0.f, den = 0.f;
+        for (int s2 = 0; s2 < nsplit; ++s2) {
+            const float f = __expf(w[s2 * (HD + 2) + HD] - M);
+            num += f * w[s2 * (HD + 2) + d];
+            den += f * w[s2 * (HD + 2) + HD + 1];
+        }
+        O[(size_t)b * ldo + (kvh * GQ + hq) * HD + d] = f2bf(num / den);
     }
-}
-
-// grid (nq, B), 128 threads
-__global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ ws, bf16_t* __restrict__ O, int ldo, int nq,
-                                                           int nsplit) {
-    constexpr int HD = 128;
-    const int hq = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
-    const float* w = ws + ((size_t)b * nq + hq) * nsplit * (HD + 2);
-    float M = -1e30f;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, w[s * (HD + 2) + HD]);
-    float num = 0.f, den = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float f = __expf(w[s * (HD + 2) + HD] - M);
-        num += f * w[s * (HD + 2) + d];
-        den += f * w[s * (HD + 2) + HD + 1];
-    }
-    O[(size_t)b * ldo + hq * HD + d] = f2bf(num / den);
+    if (tid == 0) __hip_atomic_store(&tickets[b * nkv + kvh], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -389,33 +510,35 @@ __global__ __launch_bounds__(256) void select_next_kernel(const float* __restric
 }  // namespace
 
 int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R, int ldr,
-                       int B, int N, int K, int epi, hipStream_t s) {
+                       int B, int N, int K, int epi, const bf16_t* gamma, float eps, hipStream_t s) {
     if (B < 1 || B > 16 || K % 64 || (ldx % 8) || (ldw % 8)) return TRACE_ERR_ARG;
+#define SK(EPI_, NORM_, GRID_) hipLaunchKernelGGL((skinny_gemm_kernel<EPI_, NORM_>), dim3(GRID_), dim3(512), 0, s, X, ldx, W, ldw, out, ldo, R, ldr, B, N, K, gamma, eps)
     switch (epi) {
         case EPI_NONE:
             if (N % 16) return TRACE_ERR_ARG;
-            hipLaunchKernelGGL(skinny_gemm_kernel<EPI_NONE>, dim3(N / 16), dim3(512), 0, s, X, ldx, W, ldw, out, ldo, R, ldr, B, N, K);
+            if (gamma) SK(EPI_NONE, true, N / 16); else SK(EPI_NONE, false, N / 16);
             break;
         case EPI_RESIDUAL:
-            if (N % 16 || !R) return TRACE_ERR_ARG;
-            hipLaunchKernelGGL(skinny_gemm_kernel<EPI_RESIDUAL>, dim3(N / 16), dim3(512), 0, s, X, ldx, W, ldw, out, ldo, R, ldr, B, N, K);
+            if (N % 16 || !R || gamma) return TRACE_ERR_ARG;
+            SK(EPI_RESIDUAL, false, N / 16);
             break;
         case EPI_SWIGLU:
             if (N % 32) return TRACE_ERR_ARG;
-            hipLaunchKernelGGL(skinny_gemm_kernel<EPI_SWIGLU>, dim3(N / 32), dim3(512), 0, s, X, ldx, W, ldw, out, ldo, R, ldr, B, N, K);
+            if (gamma) SK(EPI_SWIGLU, true, N / 32); else SK(EPI_SWIGLU, false, N / 32);
             break;
         default: return TRACE_ERR_ARG;
     }
+#undef SK
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 
-int launch_attn_decode(const bf16_t* q, int ldq, const bf16_t* kcache, const bf16_t* vcache, long slot_stride,
-                       long kv_head_stride, const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, int B,
-                       int nq, int nkv, int hd, int nsplit, float scale, hipStream_t s) {
-    if (hd != 128 || nq != 4 * nkv || nsplit < 1 || B < 1) return TRACE_ERR_ARG;
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv, B), dim3(256), 0, s, q, ldq, kcache, vcache, slot_stride,
-                       kv_head_stride, slots, pos, ws, nq, nkv, nsplit, scale);
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(nq, B), dim3(128), 0, s, ws, O, ldo, nq, nsplit);
+int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vcache, long slot_stride, long kv_head_stride,
+                       const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,
+                       int nq, int nkv, int hd, int nsplit, float scale, int fuse_rope, const float* cos_t, const float* sin_t,
+                       hipStream_t s) {
+    if (hd != 128 || nq != 4 * nkv || nsplit < 1 || B < 1 || !tickets) return TRACE_ERR_ARG;
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv, B), dim3(256), 0, s, qkv, ldq, kcache, vcache, slot_stride,
+                       kv_head_stride, slots, pos, ws, tickets, O, ldo, nq, nkv, nsplit, scale, fuse_rope, cos_t, sin_t);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 

@@ -57,10 +57,10 @@ struct trace_ctx {
     int spliced_len = 0;
     // decode state
     bf16_t *dX, *dH, *dQKV, *dO, *dACT, *xlast;   // [16, *]
-    float* attn_ws;
+    float* attn_ws; unsigned int* tickets;
     float* part_val; int32_t* part_idx;
     int32_t *d_slots, *d_pos, *d_heads, *d_done, *d_out_ids, *d_out_len, *d_step, *d_forced, *d_params;
-    int B = 0, max_new = 0, eos = -1, has_forced = 0, ntiles = 0, nsplit = 16;
+    int B = 0, max_new = 0, eos = -1, has_forced = 0, ntiles = 0, nsplit = 32;
     int slot_len[16] = {0};
     hipGraphExec_t graphs[17] = {nullptr};
     hipStream_t cap_stream = nullptr;
@@ -115,7 +115,8 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     if (c->H % 128 || c->I % 128 || c->vh % 128 || c->vi % 128 || c->QKV % 128) return bad("dims must be multiples of 128");
     if (c->S != 8 || c->vh > 1024) return bad("slot pool kernel needs 8 slots and mm_hidden <= 1024");
     if (c->max_B < 1 || c->max_B > 16) return bad("max_batch must be in [1,16]");
-    if (c->max_ctx > 16 * 1024) return bad("max_ctx too large for the decode attention split");
+    c->nsplit = 32;
+    while (c->nsplit * 128 < c->max_ctx) c->nsplit *= 2;      // decode attention: <= 128 cache rows per split
     if (cfg->max_frames < 1 || cfg->max_frames * c->TPF > c->max_ctx) return bad("max_frames*14 exceeds max_ctx");
     if (c->Tv != 13 || c->Sv != 13) { /* any size works; kept for clarity */ }
 
@@ -159,7 +160,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     // --- decode ---
     A(c->dX, 16 * H); A(c->dH, 16 * H); A(c->dQKV, 16 * (size_t)c->QKV); A(c->dO, 16 * H); A(c->dACT, 16 * I);
     A(c->xlast, 16 * H);
-    A(c->attn_ws, (size_t)16 * c->NQ * c->nsplit * (c->HD + 2));
+    A(c->attn_ws, (size_t)16 * c->NQ * c->nsplit * (c->HD + 2)); A(c->tickets, 16 * c->NKV);
     c->ntiles = c->NVpad / 16;
     A(c->part_val, (size_t)16 * c->ntiles); A(c->part_idx, (size_t)16 * c->ntiles);
     A(c->d_slots, 16); A(c->d_pos, 16); A(c->d_heads, 16); A(c->d_done, 16); A(c->d_out_len, 16); A(c->d_step, 4); A(c->d_params, 4);
@@ -536,14 +537,11 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
         const LlmLayer& W = c->llm[l];
         bf16_t* kc = c->kcache + (size_t)l * c->layer_stride;
         bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
-        LCHK(launch_rmsnorm(c->dX, H, c->dH, H, W.rms1, B, H, c->c.rms_eps, s));
-        LCHK(launch_skinny_gemm(c->dH, H, W.wqkv, H, c->dQKV, QKV, nullptr, 0, B, QKV, H, EPI_NONE, s));
-        LCHK(launch_rope_kv(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->d_slots, c->d_pos, 0, 0, B,
-                            c->NQ, c->NKV, HD, c->rope_cos, c->rope_sin, s));
+        LCHK(launch_skinny_gemm(c->dX, H, W.wqkv, H, c->dQKV, QKV, nullptr, 0, B, QKV, H, EPI_NONE, W.rms1, c->c.rms_eps, s));
         LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->d_slots, c->d_pos, c->dO,
-                                H, c->attn_ws, B, c->NQ, c->NKV, HD, c->nsplit, 1.0f / sqrtf((float)HD), s));
-        LCHK(launch_skinny_gemm(c->dO, H, W.wo, H, c->dX, H, c->dX, H, B, H, H, EPI_RESIDUAL, s));
-        LCHK(launch_rmsnorm(c->dX, H, c->dH, H, W.rms2, B, H, c->c.rms_eps, s));
+                                H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, c->nsplit, 1.0f / sqrtf((float)HD), 1,
+                                c->rope_cos, c->rope_sin, s));
+        LCHK(launch_skinny_gemm(c->dO, H, W.wo, H, c->dX, H, c->dX, H, B, H, H, EPI_RESIDUAL, nullptr, 0.f, s));
         // roofline probe: HIP events around ONE launch of the dominant kernel (layer 0 gate|up GEMV) per step
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (l == 0 && c->profile == 2) {
@@ -551,9 +549,9 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
             else if (c->kev_used + 2 <= (int)c->kev.size()) { e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2; }
         }
         if (e0) hipEventRecord(e0, s);
-        LCHK(launch_skinny_gemm(c->dH, H, W.wgu, H, c->dACT, I, nullptr, 0, B, 2 * I, H, EPI_SWIGLU, s));
+        LCHK(launch_skinny_gemm(c->dX, H, W.wgu, H, c->dACT, I, nullptr, 0, B, 2 * I, H, EPI_SWIGLU, W.rms2, c->c.rms_eps, s));
         if (e1) hipEventRecord(e1, s);
-        LCHK(launch_skinny_gemm(c->dACT, I, W.wd, I, c->dX, H, c->dX, H, B, H, I, EPI_RESIDUAL, s));
+        LCHK(launch_skinny_gemm(c->dACT, I, W.wd, I, c->dX, H, c->dX, H, B, H, I, EPI_RESIDUAL, nullptr, 0.f, s));
     }
     LCHK(launch_rmsnorm(c->dX, H, c->dH, H, c->final_norm, B, H, c->c.rms_eps, s));
     return head_and_select(c, c->dH, 1, logits_out, s);
@@ -706,24 +704,29 @@ extern "C" int trace_op_attention(const void* Q, const void* K, const void* V, v
     return TRACE_OK;
 }
 extern "C" int trace_op_skinny_gemm(const void* X, const void* W, void* out, const void* R, int B, int N, int K, int epilogue,
-                                    void* stream) {
+                                    const void* gamma, float eps, void* stream) {
     const int No = epilogue == EPI_SWIGLU ? N / 2 : N;
     LCHK(launch_skinny_gemm((const bf16_t*)X, K, (const bf16_t*)W, K, (bf16_t*)out, No, (const bf16_t*)R, No, B, N, K, epilogue,
-                            (hipStream_t)stream));
+                            (const bf16_t*)gamma, eps, (hipStream_t)stream));
     return TRACE_OK;
 }
-// kcache/vcache [B, nkv, max_ctx, 128]; pos[b] = index of the newest token (ctx = pos+1)
+// kcache/vcache [B, nkv, max_ctx, 128]; pos[b] = index of the newest token (ctx = pos+1), already in the cache;
+// q [B, nq*128] ready (rotated).  ws: B*nq*nsplit*130 floats.
 extern "C" int trace_op_attn_decode(const void* q, const void* kcache, const void* vcache, const int32_t* pos, void* O, float* ws,
                                     int B, int nq, int nkv, int max_ctx, int nsplit, float scale, void* stream) {
     static int32_t* d_slots = nullptr;
+    static unsigned int* d_tickets = nullptr;
     if (!d_slots) {
         int32_t h[16];
         for (int i = 0; i < 16; ++i) h[i] = i;
         HIPCHK(hipMalloc((void**)&d_slots, 64));
         HIPCHK(hipMemcpy(d_slots, h, 64, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&d_tickets, 16 * 64 * 4));
+        HIPCHK(hipMemset(d_tickets, 0, 16 * 64 * 4));
     }
-    LCHK(launch_attn_decode((const bf16_t*)q, nq * 128, (const bf16_t*)kcache, (const bf16_t*)vcache, (long)nkv * max_ctx * 128,
-                            (long)max_ctx * 128, d_slots, pos, (bf16_t*)O, nq * 128, ws, B, nq, nkv, 128, nsplit, scale,
-                            (hipStream_t)stream));
+    if (nsplit * 128 < max_ctx) return fail(TRACE_ERR_ARG, "nsplit too small: at most 128 cache rows per split");
+    LCHK(launch_attn_decode((const bf16_t*)q, nq * 128, (bf16_t*)kcache, (bf16_t*)vcache, (long)nkv * max_ctx * 128,
+                            (long)max_ctx * 128, d_slots, pos, (bf16_t*)O, nq * 128, ws, d_tickets, B, nq, nkv, 128, nsplit, scale, 0,
+                            nullptr, nullptr, (hipStream_t)stream));
     return TRACE_OK;
 }

@@ -70,13 +70,18 @@ int launch_rope_kv(bf16_t* qkv, int ld, bf16_t* kcache, bf16_t* vcache, long slo
                    const float* cos_t, const float* sin_t, hipStream_t s);
 
 // ---- decode (decode.hip) ----
-// out[b, n] = sum_k X[b,k] W[n,k]  (B <= 16) (+ residual / SwiGLU on interleaved W)
+// out[b, n] = sum_k X'[b,k] W[n,k]  (B <= 16) (+ residual / SwiGLU on interleaved W); gamma != null fuses
+// X' = bf16(RMSNorm(X) * gamma) (eps), else X' = X
 int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R,
-                       int ldr, int B, int N, int K, int epi, hipStream_t s);
-// single-query GQA attention over the cache; q [B, nq*hd]; O [B, nq*hd]
-int launch_attn_decode(const bf16_t* q, int ldq, const bf16_t* kcache, const bf16_t* vcache, long slot_stride,
-                       long kv_head_stride, const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws,
-                       int B, int nq, int nkv, int hd, int nsplit, float scale, hipStream_t s);
+                       int ldr, int B, int N, int K, int epi, const bf16_t* gamma, float eps, hipStream_t s);
+// single-query GQA attention over the cache (context = pos[b] + 1 rows, split nsplit ways, <= 128 rows per split).
+// fuse_rope = 1: `qkv` rows are the raw [q | k | v] projections of the new token: q and the new k are rotated here
+// (RoPE at pos[b]) and k/v appended to the cache at row pos[b].  fuse_rope = 0: `qkv` holds ready q rows (ld ldq)
+// and the cache already contains row pos[b].  tickets: zeroed uint32 [B*nkv].  O [B, nq*hd].
+int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vcache, long slot_stride, long kv_head_stride,
+                       const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,
+                       int nq, int nkv, int hd, int nsplit, float scale, int fuse_rope, const float* cos_t, const float* sin_t,
+                       hipStream_t s);
 // heads: logits over [text V+1 | time Tv | score Sv] rows of Wh [NV_pad, H]; only tiles intersecting an active
 // head's range are computed.  part: [B, ntiles] (max,idx).  logits_out optional [B, NV] fp32 (masked -inf).
 int launch_head_logits(const bf16_t* X, int ldx, const bf16_t* Wh, int H, const int32_t* heads, int V, int Tv, int Sv,

@@ -251,13 +251,13 @@ class ops:
         return o
 
     @staticmethod
-    def skinny_gemm(X, W, R=None, epilogue=EPI_NONE):
+    def skinny_gemm(X, W, R=None, epilogue=EPI_NONE, gamma=None, eps=0.0):
         lib = _lib.load()
         Bn, K = X.shape
         N = W.shape[0]
         No = N // 2 if epilogue == EPI_SWIGLU else N
         out = torch.empty((Bn, No), dtype=torch.bfloat16, device=X.device)
-        _lib.check(lib.trace_op_skinny_gemm(_ptr(X), _ptr(W), _ptr(out), _ptr(R), Bn, N, K, epilogue, _stream()))
+        _lib.check(lib.trace_op_skinny_gemm(_ptr(X), _ptr(W), _ptr(out), _ptr(R), Bn, N, K, epilogue, _ptr(gamma), eps, _stream()))
         return out
 
     @staticmethod
@@ -267,7 +267,7 @@ class ops:
         Bn = q.shape[0]
         nkv, max_ctx = kcache.shape[1], kcache.shape[2]
         nq = q.shape[1] // 128
-        ws = torch.empty((Bn * nq * nsplit * 130,), dtype=torch.float32, device=q.device)
+        ws = torch.zeros((Bn * nq * nsplit * 130,), dtype=torch.float32, device=q.device)
         o = torch.empty_like(q)
         _lib.check(lib.trace_op_attn_decode(_ptr(q), _ptr(kcache), _ptr(vcache), _ptr(pos), _ptr(o), _ptr(ws), Bn, nq, nkv,
                                             max_ctx, nsplit, scale, _stream()))

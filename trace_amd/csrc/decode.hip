@@ -57,7 +57,8 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const bf16_t* __restri
     const bf16_t* gp = NORM ? gamma + g * 16 : nullptr;
     float rs = 1.f;
     Frag wa[UN][NT][2], wb[UN][NT][2], xa[UN][2], xb[UN][2];
-    auto load = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][2], int u) {
+    Frag ga[NORM ? UN : 1][2], gb[NORM ? UN : 1][2];     // gamma fragments travel with their batch (same vmcnt group)
+    auto load = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][2], Frag (&gf)[NORM ? UN : 1][2], int u) {
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
             const bool ok = u + j < u1;
@@ -69,19 +70,23 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const bf16_t* __restri
             }
             xf[j][0].u = (ok && xon) ? *reinterpret_cast<const uint4*>(xp + ko) : make_uint4(0, 0, 0, 0);
             xf[j][1].u = (ok && xon) ? *reinterpret_cast<const uint4*>(xp + ko + 8) : make_uint4(0, 0, 0, 0);
+            if (NORM) {
+                gf[j][0].u = (ok && xon) ? *reinterpret_cast<const uint4*>(gp + ko) : make_uint4(0, 0, 0, 0);
+                gf[j][1].u = (ok && xon) ? *reinterpret_cast<const uint4*>(gp + ko + 8) : make_uint4(0, 0, 0, 0);
+            }
         }
     };
-    auto scale = [&](Frag& x, int ko) {          // x <- bf16(x * rs * gamma[k])
-        const uint4 gq = *reinterpret_cast<const uint4*>(gp + ko);
+    auto scale = [&](Frag& x, const Frag& gfr) {          // x <- bf16(x * rs * gamma[k])
+        const uint4 gq = gfr.u;
         x.u.x = pack2bf(bflo(x.u.x) * rs * bflo(gq.x), bfhi(x.u.x) * rs * bfhi(gq.x));
         x.u.y = pack2bf(bflo(x.u.y) * rs * bflo(gq.y), bfhi(x.u.y) * rs * bfhi(gq.y));
         x.u.z = pack2bf(bflo(x.u.z) * rs * bflo(gq.z), bfhi(x.u.z) * rs * bfhi(gq.z));
         x.u.w = pack2bf(bflo(x.u.w) * rs * bflo(gq.w), bfhi(x.u.w) * rs * bfhi(gq.w));
     };
-    auto mma = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][2], int u) {
+    auto mma = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][2], Frag (&gf)[NORM ? UN : 1][2]) {
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
-            if (NORM && xon && u + j < u1) { scale(xf[j][0], (u + j) * 64); scale(xf[j][1], (u + j) * 64 + 8); }
+            if (NORM && xon) { scale(xf[j][0], gf[j][0]); scale(xf[j][1], gf[j][1]); }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][t][0].v, xf[j][0].v, acc[t], 0, 0, 0);
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const bf16_t* __restri
             }
         }
     };
-    if (u0 < u1) load(wa, xa, u0);                 // weights start streaming before the norm statistics
+    if (u0 < u1) load(wa, xa, ga, u0);             // weights start streaming before the norm statistics
     if (NORM) {
         float ss[16];
 #pragma unroll
@@ -122,11 +127,11 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const bf16_t* __restri
     }
     if (u0 < u1) {
         for (int u = u0; u < u1; u += 2 * UN) {
-            if (u + UN < u1) load(wb, xb, u + UN);
-            mma(wa, xa, u);
+            if (u + UN < u1) load(wb, xb, gb, u + UN);
+            mma(wa, xa, ga);
             if (u + UN < u1) {
-                if (u + 2 * UN < u1) load(wa, xa, u + 2 * UN);
-                mma(wb, xb, u + UN);
+                if (u + 2 * UN < u1) load(wa, xa, ga, u + 2 * UN);
+                mma(wb, xb, gb);
             }
         }
     }
@@ -165,8 +170,9 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const bf16_t* __restri
 // append, the split-context partial attention and the cross-split combine are all in this kernel.
 // grid (nsplit, nkv, B), 256 threads; 16 lanes per cache row (16 B each = one 256-byte row per 16-lane group),
 // every lane pre-loads its K and V rows up front so the two HBM round trips overlap.  Partials go to `ws`
-// ([b][q-head][split][hd + 2] fp32); the last-arriving workgroup of a (b, kv-head) pair — agent-scope release
-// before the ticket, agent-scope acquire after it, counter re-zeroed by that workgroup — merges them.
+// ([b][q-head][split][hd + 2] fp32) with write-through (sc1) stores; every wave drains vmcnt, then one lane takes
+// an agent-scope ticket; the last-arriving workgroup of a (b, kv-head) pair does ONE agent-scope acquire and merges
+// the splits (placement-independent: no assumption on dispatch order or XCD), then re-zeroes the ticket.
 constexpr int AD_MAXIT = 8;            // rows per 16-lane group: chunk <= 16 * AD_MAXIT = 128 rows per split
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ qkv, int ldq, bf16_t* __restrict__ kcache,
                                                           bf16_t* __restrict__ vcache, long slot_stride, long kv_head_stride,
@@ -319,21 +325,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     __syncthreads();
     {
         const size_t base = (((size_t)b * nq + kvh * GQ) * nsplit + sp) * (HD + 2);
+        // write-through (sc1) stores: visible at agent scope once vmcnt drains, no L2 write-back fence needed
         for (int i = tid; i < GQ * HD; i += 256) {
             const int hq = i >> 7, d = i & 127;
-            ws[base + (size_t)hq * nsplit * (HD + 2) + d] = s_o[hq][d];
+            __hip_atomic_store(&ws[base + (size_t)hq * nsplit * (HD + 2) + d], s_o[hq][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (tid < GQ) {
-            ws[base + (size_t)tid * nsplit * (HD + 2) + HD] = mx[tid];
-            ws[base + (size_t)tid * nsplit * (HD + 2) + HD + 1] = s_red[0][tid][1] + s_red[1][tid][1] + s_red[2][tid][1] + s_red[3][tid][1];
+            __hip_atomic_store(&ws[base + (size_t)tid * nsplit * (HD + 2) + HD], mx[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ws[base + (size_t)tid * nsplit * (HD + 2) + HD + 1],
+                               s_red[0][tid][1] + s_red[1][tid][1] + s_red[2][tid][1] + s_red[3][tid][1], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // ---- publish + ticket; the last arriver of this (b, kv-head) merges the splits ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned t = __hip_atomic_fetch_add(&tickets[b * nkv + kvh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (t == (unsigned)(nsplit - 1));
         if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

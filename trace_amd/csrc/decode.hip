@@ -30,14 +30,15 @@ union Frag { uint4 u; bf16x8_t v; };
 // L2) while its first weight loads are in flight, and each lane scales + rounds its activation fragment to bf16
 // (the same rounding point as a separate norm kernel) right before the MFMA.
 template <int EPI, bool NORM>
-__global__ __launch_bounds__(512) void skinny_gemm_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W,
+__global__ __launch_bounds__(512, 4) void skinny_gemm_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W,
                                                           int ldw, bf16_t* __restrict__ out, int ldo,
                                                           const bf16_t* __restrict__ R, int ldr, int B, int N, int K,
                                                           const bf16_t* __restrict__ gamma, float eps) {
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;      // 16-row weight tiles per workgroup
     constexpr int UN = 2;                                // 64-wide k units per batch (4 x 16 B per lane per tile)
     __shared__ float red[8][NT][256];
-    __shared__ float s_ss[8][16];
+    __shared__ float s_rs[16];
+    __shared__ __attribute__((aligned(16))) bf16_t s_gamma[NORM ? 4096 : 8];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16 * NT;
@@ -54,11 +55,9 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const bf16_t* __restri
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const bf16_t* gp = NORM ? gamma + g * 16 : nullptr;
     float rs = 1.f;
     Frag wa[UN][NT][2], wb[UN][NT][2], xa[UN][2], xb[UN][2];
-    Frag ga[NORM ? UN : 1][2], gb[NORM ? UN : 1][2];     // gamma fragments travel with their batch (same vmcnt group)
-    auto load = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][2], Frag (&gf)[NORM ? UN : 1][2], int u) {
+    auto load = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][2], int u) {
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
             const bool ok = u + j < u1;
@@ -70,23 +69,19 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const bf16_t* __restri
             }
             xf[j][0].u = (ok && xon) ? *reinterpret_cast<const uint4*>(xp + ko) : make_uint4(0, 0, 0, 0);
             xf[j][1].u = (ok && xon) ? *reinterpret_cast<const uint4*>(xp + ko + 8) : make_uint4(0, 0, 0, 0);
-            if (NORM) {
-                gf[j][0].u = (ok && xon) ? *reinterpret_cast<const uint4*>(gp + ko) : make_uint4(0, 0, 0, 0);
-                gf[j][1].u = (ok && xon) ? *reinterpret_cast<const uint4*>(gp + ko + 8) : make_uint4(0, 0, 0, 0);
-            }
         }
     };
-    auto scale = [&](Frag& x, const Frag& gfr) {          // x <- bf16(x * rs * gamma[k])
-        const uint4 gq = gfr.u;
+    auto scale = [&](Frag& x, int k) {          // x <- bf16(x * rs * gamma[k..k+8)), gamma from LDS (lgkm queue, not vmcnt)
+        const uint4 gq = *reinterpret_cast<const uint4*>(&s_gamma[k]);
         x.u.x = pack2bf(bflo(x.u.x) * rs * bflo(gq.x), bfhi(x.u.x) * rs * bfhi(gq.x));
         x.u.y = pack2bf(bflo(x.u.y) * rs * bflo(gq.y), bfhi(x.u.y) * rs * bfhi(gq.y));
         x.u.z = pack2bf(bflo(x.u.z) * rs * bflo(gq.z), bfhi(x.u.z) * rs * bfhi(gq.z));
         x.u.w = pack2bf(bflo(x.u.w) * rs * bflo(gq.w), bfhi(x.u.w) * rs * bfhi(gq.w));
     };
-    auto mma = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][2], Frag (&gf)[NORM ? UN : 1][2]) {
+    auto mma = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][2], int u) {
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
-            if (NORM && xon) { scale(xf[j][0], gf[j][0]); scale(xf[j][1], gf[j][1]); }
+            if (NORM && xon && u + j < u1) { scale(xf[j][0], (u + j) * 64 + g * 16); scale(xf[j][1], (u + j) * 64 + g * 16 + 8); }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][t][0].v, xf[j][0].v, acc[t], 0, 0, 0);
@@ -94,44 +89,35 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const bf16_t* __restri
             }
         }
     };
-    if (u0 < u1) load(wa, xa, ga, u0);             // weights start streaming before the norm statistics
+    if (u0 < u1) load(wa, xa, u0);                 // weights start streaming before the norm statistics
     if (NORM) {
-        float ss[16];
+        for (int k = tid * 8; k < K; k += 512 * 8) *reinterpret_cast<uint4*>(&s_gamma[k]) = *reinterpret_cast<const uint4*>(gamma + k);
+        // wave w owns rows w and w + 8
 #pragma unroll
-        for (int m = 0; m < 16; ++m) ss[m] = 0.f;
-        for (int k = tid * 8; k < K; k += 512 * 8) {
-#pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                if (m < B) {
+        for (int rr = 0; rr < 2; ++rr) {
+            const int m = wid + rr * 8;
+            if (m < B) {
+                float ss = 0.f;
+                for (int k = lane * 8; k < K; k += 64 * 8) {
                     const uint4 u = *reinterpret_cast<const uint4*>(X + (size_t)m * ldx + k);
                     const float a0 = bflo(u.x), a1 = bfhi(u.x), a2 = bflo(u.y), a3 = bfhi(u.y);
                     const float a4 = bflo(u.z), a5 = bfhi(u.z), a6 = bflo(u.w), a7 = bfhi(u.w);
-                    ss[m] += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5 + a6 * a6 + a7 * a7;
+                    ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5 + a6 * a6 + a7 * a7;
                 }
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            if (m < B) {
-                const float t = wave_sum(ss[m]);
-                if (lane == 0) s_ss[wid][m] = t;
+                ss = wave_sum(ss);
+                if (lane == 0) s_rs[m] = rsqrtf(ss / (float)K + eps);
             }
         }
         __syncthreads();
-        if (xon) {
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) t += s_ss[w][r];
-            rs = rsqrtf(t / (float)K + eps);
-        }
+        if (xon) rs = s_rs[r];
     }
     if (u0 < u1) {
         for (int u = u0; u < u1; u += 2 * UN) {
-            if (u + UN < u1) load(wb, xb, gb, u + UN);
-            mma(wa, xa, ga);
+            if (u + UN < u1) load(wb, xb, u + UN);
+            mma(wa, xa, u);
             if (u + UN < u1) {
-                if (u + 2 * UN < u1) load(wa, xa, ga, u + 2 * UN);
-                mma(wb, xb, gb);
+                if (u + 2 * UN < u1) load(wa, xa, u + 2 * UN);
+                mma(wb, xb, u + UN);
             }
         }
     }
@@ -180,7 +166,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
                                                           float* __restrict__ ws, unsigned int* __restrict__ tickets,
                                                           bf16_t* __restrict__ O, int ldo, int nq, int nkv, int nsplit,
                                                           float scale, int fuse_rope, const float* __restrict__ cos_t,
-                                                          const float* __restrict__ sin_t) {
+                                                          const float* __restrict__ sin_t, int dbg) {
     constexpr int HD = 128, GQ = 4, CH = 16 * AD_MAXIT;
     __shared__ float s_p[GQ][CH];
     __shared__ float s_o[GQ][HD];
@@ -323,6 +309,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         }
     }
     __syncthreads();
+    if (dbg == 2) return;
     {
         const size_t base = (((size_t)b * nq + kvh * GQ) * nsplit + sp) * (HD + 2);
         // write-through (sc1) stores: visible at agent scope once vmcnt drains, no L2 write-back fence needed
@@ -337,6 +324,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
                                __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (dbg == 1) return;
     // ---- publish + ticket; the last arriver of this (b, kv-head) merges the splits ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -347,19 +335,35 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         s_last = last;
     }
     __syncthreads();
-    if (!s_last) return;
-    for (int i = tid; i < GQ * HD; i += 256) {
-        const int hq = i >> 7, d = i & 127;
+    if (!s_last || dbg == 3) return;
+    {   // wave w merges q-head w: lane owns d = 2*lane, 2*lane+1; split loads are independent -> issued in batches
+        const int hq = wid;
         const float* w = ws + (((size_t)b * nq + kvh * GQ + hq) * nsplit) * (HD + 2);
         float M = -1e30f;
-        for (int s2 = 0; s2 < nsplit; ++s2) M = fmaxf(M, w[s2 * (HD + 2) + HD]);
-        float num = 0.f, den = 0.f;
-        for (int s2 = 0; s2 < nsplit; ++s2) {
-            const float f = __expf(w[s2 * (HD + 2) + HD] - M);
-            num += f * w[s2 * (HD + 2) + d];
-            den += f * w[s2 * (HD + 2) + HD + 1];
+        for (int s2 = lane; s2 < nsplit; s2 += 64) M = fmaxf(M, w[s2 * (HD + 2) + HD]);
+        M = wave_max(M);
+        float num0 = 0.f, num1 = 0.f, den = 0.f;
+        for (int s0 = 0; s0 < nsplit; s0 += 8) {
+            float2 o[8];
+            float mm[8], ll[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s2 = min(s0 + u, nsplit - 1);
+                const float* ws2 = w + (size_t)s2 * (HD + 2);
+                o[u] = *reinterpret_cast<const float2*>(ws2 + 2 * lane);
+                mm[u] = ws2[HD];
+                ll[u] = ws2[HD + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (s0 + u < nsplit) {
+                    const float f = __expf(mm[u] - M);
+                    num0 += f * o[u].x; num1 += f * o[u].y; den += f * ll[u];
+                }
+            }
         }
-        O[(size_t)b * ldo + (kvh * GQ + hq) * HD + d] = f2bf(num / den);
+        const float inv = 1.f / den;
+        *reinterpret_cast<uint32_t*>(O + (size_t)b * ldo + (kvh * GQ + hq) * HD + 2 * lane) = pack2bf(num0 * inv, num1 * inv);
     }
     if (tid == 0) __hip_atomic_store(&tickets[b * nkv + kvh], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -519,6 +523,7 @@ __global__ __launch_bounds__(256) void select_next_kernel(const float* __restric
 int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R, int ldr,
                        int B, int N, int K, int epi, const bf16_t* gamma, float eps, hipStream_t s) {
     if (B < 1 || B > 16 || K % 64 || (ldx % 8) || (ldw % 8)) return TRACE_ERR_ARG;
+    if (gamma && K > 4096) return TRACE_ERR_ARG;
 #define SK(EPI_, NORM_, GRID_) hipLaunchKernelGGL((skinny_gemm_kernel<EPI_, NORM_>), dim3(GRID_), dim3(512), 0, s, X, ldx, W, ldw, out, ldo, R, ldr, B, N, K, gamma, eps)
     switch (epi) {
         case EPI_NONE:
@@ -539,13 +544,15 @@ int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 
+int g_attn_debug = 0;   // microbenchmark-only phase cut-offs (0 = full kernel)
 int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vcache, long slot_stride, long kv_head_stride,
                        const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,
                        int nq, int nkv, int hd, int nsplit, float scale, int fuse_rope, const float* cos_t, const float* sin_t,
                        hipStream_t s) {
     if (hd != 128 || nq != 4 * nkv || nsplit < 1 || B < 1 || !tickets) return TRACE_ERR_ARG;
     hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv, B), dim3(256), 0, s, qkv, ldq, kcache, vcache, slot_stride,
-                       kv_head_stride, slots, pos, ws, tickets, O, ldo, nq, nkv, nsplit, scale, fuse_rope, cos_t, sin_t);
+                       kv_head_stride, slots, pos, ws, tickets, O, ldo, nq, nkv, nsplit, scale, fuse_rope, cos_t, sin_t,
+                       g_attn_debug);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 

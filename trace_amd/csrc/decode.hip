@@ -91,25 +91,59 @@ __global__ __launch_bounds__(512, 4) void skinny_gemm_kernel(const bf16_t* __res
     };
     if (u0 < u1) load(wa, xa, u0);                 // weights start streaming before the norm statistics
     if (NORM) {
-        for (int k = tid * 8; k < K; k += 512 * 8) *reinterpret_cast<uint4*>(&s_gamma[k]) = *reinterpret_cast<const uint4*>(gamma + k);
-        // wave w owns rows w and w + 8
+        // each wave stages only ITS k-slice of gamma (wave-private LDS region: no workgroup barrier needed)
+        uint4 gq[2];
+        const int k0 = u0 * 64, k1 = u1 * 64;
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int m = wid + rr * 8;
-            if (m < B) {
-                float ss = 0.f;
-                for (int k = lane * 8; k < K; k += 64 * 8) {
-                    const uint4 u = *reinterpret_cast<const uint4*>(X + (size_t)m * ldx + k);
-                    const float a0 = bflo(u.x), a1 = bfhi(u.x), a2 = bflo(u.y), a3 = bfhi(u.y);
-                    const float a4 = bflo(u.z), a5 = bfhi(u.z), a6 = bflo(u.w), a7 = bfhi(u.w);
-                    ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5 + a6 * a6 + a7 * a7;
-                }
-                ss = wave_sum(ss);
-                if (lane == 0) s_rs[m] = rsqrtf(ss / (float)K + eps);
-            }
+        for (int i = 0; i < 2; ++i) {
+            const int k = k0 + (i * 64 + lane) * 8;
+            gq[i] = k < k1 ? *reinterpret_cast<const uint4*>(gamma + k) : make_uint4(0, 0, 0, 0);
         }
-        __syncthreads();
-        if (xon) rs = s_rs[r];
+        if (B <= 2) {
+            // every wave recomputes the row statistics it needs (B <= 2 rows, 8 KB each from L2): no barrier at all
+            float ss0 = 0.f, ss1 = 0.f;
+            for (int k = lane * 8; k < K; k += 64 * 8) {
+                const uint4 u = *reinterpret_cast<const uint4*>(X + k);
+                const float a0 = bflo(u.x), a1 = bfhi(u.x), a2 = bflo(u.y), a3 = bfhi(u.y);
+                const float a4 = bflo(u.z), a5 = bfhi(u.z), a6 = bflo(u.w), a7 = bfhi(u.w);
+                ss0 += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5 + a6 * a6 + a7 * a7;
+                if (B == 2) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(X + ldx + k);
+                    const float b0 = bflo(v.x), b1 = bfhi(v.x), b2 = bflo(v.y), b3 = bfhi(v.y);
+                    const float b4 = bflo(v.z), b5 = bfhi(v.z), b6 = bflo(v.w), b7 = bfhi(v.w);
+                    ss1 += b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3 + b4 * b4 + b5 * b5 + b6 * b6 + b7 * b7;
+                }
+            }
+            ss0 = wave_sum(ss0);
+            ss1 = wave_sum(ss1);
+            rs = rsqrtf((r == 0 ? ss0 : ss1) / (float)K + eps);
+        } else {
+            // wave w owns rows w and w + 8; one workgroup barrier
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int m = wid + rr * 8;
+                if (m < B) {
+                    float ss = 0.f;
+                    for (int k = lane * 8; k < K; k += 64 * 8) {
+                        const uint4 u = *reinterpret_cast<const uint4*>(X + (size_t)m * ldx + k);
+                        const float a0 = bflo(u.x), a1 = bfhi(u.x), a2 = bflo(u.y), a3 = bfhi(u.y);
+                        const float a4 = bflo(u.z), a5 = bfhi(u.z), a6 = bflo(u.w), a7 = bfhi(u.w);
+                        ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5 + a6 * a6 + a7 * a7;
+                    }
+                    ss = wave_sum(ss);
+                    if (lane == 0) s_rs[m] = rsqrtf(ss / (float)K + eps);
+                }
+            }
+            __syncthreads();
+            if (xon) rs = s_rs[r];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = k0 + (i * 64 + lane) * 8;
+            if (k < k1) *reinterpret_cast<uint4*>(&s_gamma[k]) = gq[i];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's own gamma slice is in LDS
+        __builtin_amdgcn_wave_barrier();
     }
     if (u0 < u1) {
         for (int u = u0; u < u1; u += 2 * UN) {
@@ -523,7 +557,7 @@ __global__ __launch_bounds__(256) void select_next_kernel(const float* __restric
 int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R, int ldr,
                        int B, int N, int K, int epi, const bf16_t* gamma, float eps, hipStream_t s) {
     if (B < 1 || B > 16 || K % 64 || (ldx % 8) || (ldw % 8)) return TRACE_ERR_ARG;
-    if (gamma && K > 4096) return TRACE_ERR_ARG;
+    if (gamma && K > 4096) return TRACE_ERR_ARG;       // per-wave gamma slice: K/8 <= 2 x 64 lanes x 8 elements
 #define SK(EPI_, NORM_, GRID_) hipLaunchKernelGGL((skinny_gemm_kernel<EPI_, NORM_>), dim3(GRID_), dim3(512), 0, s, X, ldx, W, ldw, out, ldo, R, ldr, B, N, K, gamma, eps)
     switch (epi) {
         case EPI_NONE:

@@ -88,6 +88,11 @@ int trace_decode_begin(trace_ctx* ctx, const int32_t* slots, int B, const int32_
                        const int32_t* forced, float* logits_out, void* stream);
 int trace_decode_steps(trace_ctx* ctx, int n, int use_graph, float* logits_out, void* stream);
 int trace_decode_read(trace_ctx* ctx, int32_t* out_ids, int32_t* out_len, int32_t* heads, void* stream);
+/* Host-driven token selection (do_sample=True in scripts/inference/inference.py:62, stopping criteria): with host
+ * mode on (set before trace_decode_begin), begin/steps stop after the masked head logits; the host picks the ids and
+ * trace_decode_feed applies them (output record, head switch, next-token embedding).  One eager step at a time. */
+int trace_decode_host_mode(trace_ctx* ctx, int on);
+int trace_decode_feed(trace_ctx* ctx, const int32_t* tokens, int B, void* stream);
 
 /* Timing hook for bench.py: average device time (ms, hipEvents on `stream`) of the last trace_decode_steps call
  * per step, and of its skinny-GEMM launches if profiling was enabled with trace_set_profile(ctx, 1). */

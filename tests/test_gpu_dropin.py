@@ -1,0 +1,78 @@
+"""Drop-in surface on the GPU: the reference drivers' call sequence (trace/eval/evaluate.py:241-243,315-410) run
+against trace_amd with a synthetic tiny checkpoint."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+if not torch.cuda.is_available():
+    pytest.skip("needs a HIP device", allow_module_level=True)
+
+from oracle import trace_oracle as O  # noqa: E402  (checker only)
+from trace_amd import config as tcfg, synth  # noqa: E402
+from trace_amd.constants import DEFAULT_MMODAL_TOKEN  # noqa: E402
+from trace_amd.conversation import conv_templates  # noqa: E402
+from trace_amd.mm_utils import get_model_name_from_path, process_video, tokenizer_MMODAL_token_all  # noqa: E402
+from trace_amd.model.builder import load_pretrained_model, save_synthetic_checkpoint  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def loaded(tmp_path_factory):
+    path = str(tmp_path_factory.mktemp("ckpt") / "trace-tiny")
+    cfg = tcfg.tiny(num_frames=4)
+    save_synthetic_checkpoint(path, cfg)
+    tok, model, proc, ctx_len = load_pretrained_model(path, None, get_model_name_from_path(path), max_batch=2, max_new_tokens=64)
+    return cfg, tok, model, proc, ctx_len
+
+
+def _driver_inputs(cfg, tok, proc, seed=0):
+    raw = np.random.RandomState(seed).randint(0, 255, size=(40, 48, 64, 3), dtype=np.uint8)
+    tensor, ts = process_video(raw, proc, "pad", 4, fps=8.0)
+    assert tensor.shape == (4, 3, cfg.vision_image_size, cfg.vision_image_size)
+    conv = conv_templates["llama_2"].copy()
+    conv.append_message(conv.roles[0], DEFAULT_MMODAL_TOKEN["VIDEO"] + "\nfind events")
+    conv.append_message(conv.roles[1], None)
+    prompt = conv.get_prompt() + "<sync>"
+    ids = tokenizer_MMODAL_token_all(prompt, tok, return_tensors="pt")
+    ids = torch.cat([ids[:60], ids[-3:]])          # keep the byte-level prompt short
+    assert (ids == -201).sum() == 1 and ids[-1] == -205
+    return tensor, ts, ids
+
+
+def test_driver_loop_matches_oracle(loaded):
+    cfg, tok, model, proc, ctx_len = loaded
+    assert ctx_len == cfg.max_sequence_length and proc is not None
+    tensor, ts, ids = _driver_inputs(cfg, tok, proc)
+    heads = [1]
+    out = model.generate(ids.unsqueeze(0).to("cuda"), attention_mask=None, images_or_videos=[tensor.to(torch.float16).to("cuda")],
+                         modal_list=["video"], do_sample=False, temperature=0.0, max_new_tokens=12, use_cache=True,
+                         pad_token_id=tok.eos_token_id, video_timestamps=[ts], heads=heads)
+    assert out.shape[0] == 1 and out.dtype == torch.long
+    ora = O.Oracle(cfg, synth.state_dict(cfg), emulate_bf16=True)
+    fr = tensor.to(torch.float16).to(torch.bfloat16).float()
+    ref, lg = ora.generate(ids, fr, ts, head=1, max_new_tokens=12, eos_token_id=cfg.eos_token_id, return_logits=True)
+    srt = torch.sort(torch.where(torch.isfinite(lg), lg, torch.full_like(lg, -1e30)), dim=-1, descending=True).values
+    for i, (a, b) in enumerate(zip(out[0].tolist(), ref)):
+        if (srt[i, 0] - srt[i, 1]) < 0.1:
+            break
+        assert a == b, f"step {i}"
+    # the parser of the drivers only needs decode(int-or-tensor) on the number tokenizers
+    tt = model.get_model().time_tokenizer
+    assert tt.decode(out[0][0] - (cfg.vocab_size + 1)) in "<sync><sep>0123456789."
+    assert heads[0] in (0, 1, 2)
+
+
+def test_sampling_and_asserts(loaded):
+    cfg, tok, model, proc, _ = loaded
+    tensor, ts, ids = _driver_inputs(cfg, tok, proc, seed=1)
+    torch.manual_seed(0)
+    out = model.generate(ids.unsqueeze(0), images_or_videos=[tensor], modal_list=["video"], do_sample=True, temperature=0.2,
+                         max_new_tokens=8, video_timestamps=[ts], heads=[1])
+    assert out.shape == (1, 8) or out.shape[1] <= 8
+    V, Tv = cfg.vocab_size, cfg.time_vocab_size
+    assert V < int(out[0, 0]) <= V + Tv          # generation starts in the time head
+    with pytest.raises(NotImplementedError):
+        model.generate(ids.unsqueeze(0), images_or_videos=[tensor], inputs_embeds=torch.zeros(1), video_timestamps=[ts], heads=[1])
+    with pytest.raises(Exception, match="only have one video"):
+        bad = torch.cat([ids, torch.tensor([-201])])
+        model.generate(bad.unsqueeze(0), images_or_videos=[tensor], modal_list=["video"], video_timestamps=[ts], heads=[1])

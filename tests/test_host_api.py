@@ -1,0 +1,111 @@
+"""Host-side mirror of the reference's Python harness (trace_amd.{constants,conversation,mm_utils,model.encoders})
+against vectors captured from the reference (tests/golden/host_functions.json).  CPU only."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from trace_amd import constants, conversation, mm_utils
+from trace_amd.model.encoders import NumberTokenizer, ScoreTower, TimeTower
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "host_functions.json")))
+
+
+def test_constants(G):
+    for k, v in G["constants"].items():
+        assert getattr(constants, k) == v, k
+
+
+def test_time_score_towers(G):
+    tt, st = TimeTower(), ScoreTower()
+    for c in G["time_encode"]:
+        assert tt.encode(c["in"]).tolist() == c["out"], c
+    for c in G["score_encode"]:
+        assert st.encode(c["in"]).tolist() == c["out"], c
+    tok = NumberTokenizer()
+    for c in G["time_decode"]:
+        assert tok.decode(c["in"]) == c["out"]
+    for c in G["score_decode"]:
+        assert tok.decode(torch.tensor(c["in"])) == c["out"]        # drivers pass 0-d tensors (evaluate.py:395)
+    assert tok.get_vocab() == G["time_vocab"]
+
+
+def test_llama2_prompts(G):
+    for name, c in G["llama2_prompts"].items():
+        if name == "_multi_turn":
+            continue
+        conv = conversation.conv_templates["llama_2"].copy()
+        conv.append_message(conv.roles[0], "<video>\n" + c["question"])
+        conv.append_message(conv.roles[1], None)
+        assert conv.get_prompt() + "<sync>" == c["prompt"], name
+    conv = conversation.conv_templates["llama_2"].copy()
+    conv.append_message(conv.roles[0], "<video>\nhello")
+    conv.append_message(conv.roles[1], "an answer")
+    conv.append_message(conv.roles[0], "second turn")
+    conv.append_message(conv.roles[1], None)
+    assert conv.get_prompt() == G["llama2_prompts"]["_multi_turn"]["prompt"]
+    assert [conv.sep, conv.sep2] == G["llama2_sep"]
+    # copy() must not alias the template's message list
+    assert conversation.conv_templates["llama_2"].messages == []
+
+
+class FakeTok:
+    bos_token_id = 1
+
+    def __call__(self, text):
+        return types.SimpleNamespace(input_ids=[1] + [10 + len(w) for w in text.split()])
+
+
+def test_tokenizer_mmodal(G):
+    for c in G["tokenizer_MMODAL_token_all"]:
+        assert mm_utils.tokenizer_MMODAL_token_all(c["in"], FakeTok(), return_tensors="pt").tolist() == c["out"], c["in"]
+    for c in G["tokenizer_MMODAL_token_video"]:
+        assert mm_utils.tokenizer_MMODAL_token(c["in"], FakeTok(), -201, return_tensors="pt").tolist() == c["out"], c["in"]
+    for c in G["get_model_name_from_path"]:
+        assert mm_utils.get_model_name_from_path(c["in"]) == c["out"]
+
+
+def test_frame_sampling_and_timestamps(G):
+    for c in G["frame_sample_uniform"]:
+        idx, ts = mm_utils.sample_indices_and_timestamps(c["duration"], c["fps"], c["num_frames"])
+        assert idx.tolist() == c["indices"]
+        assert ts == c["timestamps"]
+
+
+def test_expand2square(G):
+    for c in G["expand2square"]:
+        out = mm_utils.expand2square(Image.fromarray(np.array(c["in"], dtype=np.uint8)), tuple(c["bg"]))
+        assert np.array(out).tolist() == c["out"]
+
+
+class FakeProcessor:
+    image_mean = [0.48145466, 0.4578275, 0.40821073]
+
+    def preprocess(self, images, return_tensors="pt"):
+        arr = np.stack([np.asarray(im.resize((28, 28)), dtype=np.float32) / 255.0 for im in images])
+        return {"pixel_values": torch.from_numpy(arr).permute(0, 3, 1, 2)}
+
+
+def test_process_video_from_frames():
+    frames = np.random.RandomState(0).randint(0, 255, size=(50, 20, 30, 3), dtype=np.uint8)
+    vid, ts = mm_utils.process_video(frames, FakeProcessor(), "pad", num_frames=8, fps=10.0)
+    assert vid.shape == (8, 3, 28, 28)
+    assert ts == [[float(i / 10.0)] for i in np.linspace(0, 49, 8, dtype=int)]
+    with pytest.raises(ImportError, match="too long"):
+        mm_utils.process_video(np.zeros((20, 4, 4, 3), np.uint8), FakeProcessor(), None, num_frames=4, fps=0.001)
+
+
+def test_compat_aliases():
+    from trace_amd import compat
+    compat.install()
+    from Trace.trace.conversation import conv_templates, SeparatorStyle  # noqa: F401
+    from Trace.trace.constants import DEFAULT_MMODAL_TOKEN, MMODAL_TOKEN_INDEX  # noqa: F401
+    from Trace.trace.mm_utils import get_model_name_from_path, tokenizer_MMODAL_token_all, process_video, KeywordsStoppingCriteria  # noqa: F401
+    assert MMODAL_TOKEN_INDEX["SYNC"] == -205

@@ -42,6 +42,8 @@ SIGNATURES = {
     "trace_decode_begin": (I, [P, P, I, P, I, I, P, P, P]),
     "trace_decode_steps": (I, [P, I, I, P, P]),
     "trace_decode_read": (I, [P, P, P, P, P]),
+    "trace_decode_host_mode": (I, [P, I]),
+    "trace_decode_feed": (I, [P, P, I, P]),
     "trace_set_profile": (I, [P, I]),
     "trace_get_profile": (I, [P, P, I]),
     "trace_op_gemm": (I, [P, I, P, I, P, I, P, P, I, I, I, I, I, P]),

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void select_next_kernel(const float* __restric
     __shared__ int s_feed;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int step = *st.step;
-    const int max_new = st.params[0], eos = st.params[1];
+    const int max_new = st.params[0], eos = st.params[1], record_feed = st.params[2];
     for (int b = 0; b < B; ++b) {
         float v = -INFINITY;
         int idx = 0x7fffffff;
@@ -522,16 +522,17 @@ __global__ __launch_bounds__(256) void select_next_kernel(const float* __restric
                 if (sv[w] > v || (sv[w] == v && si[w] < idx)) { v = sv[w]; idx = si[w]; }
             int tok = idx;
             if (advance) st.pos[b] += 1;
+            int feed = tok;
+            if (step < max_new) {
+                const int f = st.forced[(size_t)b * max_new + step];
+                if (f >= 0) feed = f;
+            }
+            if (record_feed) tok = feed;          // host-driven sampling: the emitted token is the one fed back
             const bool was_done = st.done[b] != 0;
             if (!was_done && step < max_new) {
                 st.out_ids[(size_t)b * max_new + step] = tok;
                 st.out_len[b] = step + 1;
                 if (eos >= 0 && tok == eos) st.done[b] = 1;
-            }
-            int feed = tok;
-            if (step < max_new) {
-                const int f = st.forced[(size_t)b * max_new + step];
-                if (f >= 0) feed = f;
             }
             // head switch (trace_mistral.py:86-88): V -> time(1), V+1 -> score(2), V+Tv+1 -> text(0)
             int hd = st.heads[b];

@@ -62,6 +62,7 @@ struct trace_ctx {
     int32_t *d_slots, *d_pos, *d_heads, *d_done, *d_out_ids, *d_out_len, *d_step, *d_forced, *d_params;
     int B = 0, max_new = 0, eos = -1, has_forced = 0, ntiles = 0, nsplit = 32;
     int slot_len[16] = {0};
+    int host_mode = 0, fed = 0;        // host-driven token selection (sampling): head logits only, ids fed back by the host
     hipGraphExec_t graphs[17] = {nullptr};
     hipStream_t cap_stream = nullptr;
     // profiling
@@ -522,12 +523,20 @@ static StepState step_state(trace_ctx* c) {
     return st;
 }
 
-static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* logits_out, hipStream_t s) {
+static int head_only(trace_ctx* c, const bf16_t* xn, float* logits_out, hipStream_t s) {
     LCHK(launch_head_logits(xn, c->H, c->wheads, c->H, c->d_heads, c->V, c->Tv, c->Sv, c->part_val, c->part_idx, logits_out,
                             c->B, s));
+    return TRACE_OK;
+}
+static int select_only(trace_ctx* c, int advance, hipStream_t s) {
     LCHK(launch_select_next(c->part_val, c->part_idx, step_state(c), c->embed, c->time_tab, c->score_tab, c->sync_row, c->dX,
                             c->H, c->B, c->H, c->V, c->Tv, c->Sv, advance, s));
     return TRACE_OK;
+}
+static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* logits_out, hipStream_t s) {
+    TRY(head_only(c, xn, logits_out, s));
+    if (c->host_mode) return TRACE_OK;      // the host picks the token and calls trace_decode_feed
+    return select_only(c, advance, s);
 }
 
 // one decode step for the current batch: consumes dX (embedding of the last token), leaves the next one in dX
@@ -537,7 +546,10 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
         const LlmLayer& W = c->llm[l];
         bf16_t* kc = c->kcache + (size_t)l * c->layer_stride;
         bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
-        LCHK(launch_skinny_gemm(c->dX, H, W.wqkv, H, c->dQKV, QKV, nullptr, 0, B, QKV, H, EPI_NONE, W.rms1, c->c.rms_eps, s));
+        // (the GEMV can also apply the RMSNorm itself — launch_skinny_gemm(gamma) — but re-scaling the same activations
+        //  in every one of its ~900 workgroups costs more than this one 5 us row kernel: measured 65 vs 52+6 us)
+        LCHK(launch_rmsnorm(c->dX, H, c->dH, H, W.rms1, B, H, c->c.rms_eps, s));
+        LCHK(launch_skinny_gemm(c->dH, H, W.wqkv, H, c->dQKV, QKV, nullptr, 0, B, QKV, H, EPI_NONE, nullptr, 0.f, s));
         LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->d_slots, c->d_pos, c->dO,
                                 H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, c->nsplit, 1.0f / sqrtf((float)HD), 1,
                                 c->rope_cos, c->rope_sin, s));
@@ -548,8 +560,9 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
             if (s == c->cap_stream) { e0 = c->gev0; e1 = c->gev1; }
             else if (c->kev_used + 2 <= (int)c->kev.size()) { e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2; }
         }
+        LCHK(launch_rmsnorm(c->dX, H, c->dH, H, W.rms2, B, H, c->c.rms_eps, s));
         if (e0) hipEventRecord(e0, s);
-        LCHK(launch_skinny_gemm(c->dX, H, W.wgu, H, c->dACT, I, nullptr, 0, B, 2 * I, H, EPI_SWIGLU, W.rms2, c->c.rms_eps, s));
+        LCHK(launch_skinny_gemm(c->dH, H, W.wgu, H, c->dACT, I, nullptr, 0, B, 2 * I, H, EPI_SWIGLU, nullptr, 0.f, s));
         if (e1) hipEventRecord(e1, s);
         LCHK(launch_skinny_gemm(c->dACT, I, W.wd, I, c->dX, H, c->dX, H, B, H, I, EPI_RESIDUAL, nullptr, 0.f, s));
     }
@@ -579,8 +592,9 @@ extern "C" int trace_decode_begin(trace_ctx* c, const int32_t* slots, int B, con
     HIPCHK(hipMemcpyAsync(c->d_out_len, zero, B * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_step, zero, 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(c->d_out_ids, 0, (size_t)B * max_new * 4, s));
-    const int32_t prm[2] = {max_new, eos};
-    HIPCHK(hipMemcpyAsync(c->d_params, prm, 8, hipMemcpyHostToDevice, s));
+    const int32_t prm[3] = {max_new, eos, c->host_mode};
+    HIPCHK(hipMemcpyAsync(c->d_params, prm, 12, hipMemcpyHostToDevice, s));
+    c->fed = 0;
     if (forced) HIPCHK(hipMemcpyAsync(c->d_forced, forced, (size_t)B * max_new * 4, hipMemcpyHostToDevice, s));
     else HIPCHK(hipMemsetAsync(c->d_forced, 0xff, (size_t)B * max_new * 4, s));      // -1 = not forced
     // gather the prefill hidden rows of the chosen slots into dH, then head + select (no position advance)
@@ -594,6 +608,7 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
     if (!c || c->B < 1) return fail(TRACE_ERR_STATE, "trace_decode_begin not called");
     if (n < 0) return fail(TRACE_ERR_ARG, "bad n");
     if (logits_out && (n != 1 || use_graph)) return fail(TRACE_ERR_ARG, "logits_out needs n == 1 and eager mode");
+    if (c->host_mode && (n != 1 || use_graph)) return fail(TRACE_ERR_ARG, "host-select mode runs one eager step at a time");
     hipStream_t s = (hipStream_t)stream;
     if (c->profile) hipEventRecord(c->ev0, s);
     if (!use_graph) {
@@ -649,6 +664,27 @@ extern "C" int trace_decode_read(trace_ctx* c, int32_t* out_ids, int32_t* out_le
     if (out_len) HIPCHK(hipMemcpyAsync(out_len, c->d_out_len, c->B * 4, hipMemcpyDeviceToHost, s));
     if (heads) HIPCHK(hipMemcpyAsync(heads, c->d_heads, c->B * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    return TRACE_OK;
+}
+
+extern "C" int trace_decode_host_mode(trace_ctx* c, int on) {
+    if (!c) return fail(TRACE_ERR_ARG, "null ctx");
+    c->host_mode = on ? 1 : 0;
+    return TRACE_OK;
+}
+
+extern "C" int trace_decode_feed(trace_ctx* c, const int32_t* tokens, int B, void* stream) {
+    if (!c || c->B < 1 || !c->host_mode) return fail(TRACE_ERR_STATE, "trace_decode_feed needs host-select mode and an active batch");
+    if (!tokens || B != c->B) return fail(TRACE_ERR_ARG, "bad tokens / B");
+    if (c->fed >= c->max_new) return fail(TRACE_ERR_STATE, "max_new tokens already fed");
+    hipStream_t s = (hipStream_t)stream;
+    for (int b = 0; b < B; ++b) {
+        if (tokens[b] < 0 || tokens[b] >= c->NV) return fail(TRACE_ERR_ARG, "token id out of range");
+        HIPCHK(hipMemcpyAsync(c->d_forced + (size_t)b * c->max_new + c->fed, tokens + b, 4, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    TRY(select_only(c, c->fed > 0 ? 1 : 0, s));
+    c->fed += 1;
     return TRACE_OK;
 }
 

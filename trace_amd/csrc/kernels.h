@@ -95,7 +95,7 @@ struct StepState {
     int32_t* out_len;     // [B]
     int32_t* step;        // [1] device step counter
     const int32_t* forced;// [B, max_new] teacher-forcing ids; negative entry = feed the arg-max
-    const int32_t* params;// device [2]: max_new, eos  (device-resident so a captured graph stays valid)
+    const int32_t* params;// device [3]: max_new, eos, record_feed (device-resident so a captured graph stays valid)
 };
 int launch_select_next(const float* part_val, const int32_t* part_idx, const StepState& st, const bf16_t* embed,
                        const bf16_t* time_tab, const bf16_t* score_tab, const bf16_t* sync_row, bf16_t* xnext, int ldx,

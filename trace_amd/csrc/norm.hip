@@ -17,7 +17,16 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
     const int nch = D >> 3;
     const bf16_t* xr = x + (size_t)row * ldx;
     float v[MAXCH][8];
+    uint4 uwv[MAXCH], ubv[MAXCH];
     float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {      // weights first: their latency overlaps the row load + reductions
+        const int c = lane + i * 64;
+        if (c < nch) {
+            uwv[i] = *reinterpret_cast<const uint4*>(w + c * 8);
+            if (!RMS) ubv[i] = *reinterpret_cast<const uint4*>(b + c * 8);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
         const int c = lane + i * 64;
@@ -52,14 +61,14 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
     for (int i = 0; i < MAXCH; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
-            const uint4 uw = *reinterpret_cast<const uint4*>(w + c * 8);
+            const uint4 uw = uwv[i];
             float o[8];
             const float ww[8] = {bflo(uw.x), bfhi(uw.x), bflo(uw.y), bfhi(uw.y), bflo(uw.z), bfhi(uw.z), bflo(uw.w), bfhi(uw.w)};
             if (RMS) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = v[i][e] * rstd * ww[e];
             } else {
-                const uint4 ub = *reinterpret_cast<const uint4*>(b + c * 8);
+                const uint4 ub = ubv[i];
                 const float bb[8] = {bflo(ub.x), bfhi(ub.x), bflo(ub.y), bfhi(ub.y), bflo(ub.z), bfhi(ub.z), bflo(ub.w), bfhi(ub.w)};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * ww[e] + bb[e];

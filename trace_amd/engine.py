@@ -171,6 +171,13 @@ class TraceEngine:
         out = [[ids[b * mn + i] for i in range(ln[b])] for b in range(B)]
         return out, list(hd)
 
+    def host_mode(self, on: bool):
+        """Host-driven token selection (sampling / stopping criteria): logits come back every step, ids go in via feed()."""
+        _lib.check(self.lib.trace_decode_host_mode(self.h, 1 if on else 0))
+
+    def feed(self, tokens: Sequence[int]):
+        _lib.check(self.lib.trace_decode_feed(self.h, _i32(tokens), len(tokens), _stream()))
+
     def set_profile(self, on: bool):
         _lib.check(self.lib.trace_set_profile(self.h, 1 if on else 0))
 

@@ -1,0 +1,191 @@
+"""Host-side `TraceMistralForCausalLM` with the reference's call surface (trace/model/language_model/
+trace_mistral.py): `.generate(inputs, images_or_videos=, modal_list=, video_timestamps=, heads=, max_new_tokens=,
+do_sample=, ...) -> LongTensor[B, n_new]`, `.forward(...)` -> object with `.logits`, `.config`, `.get_model()`,
+`.get_vision_tower()`, `.to()`, `.eval()`.  Everything between the frame tensor and the token ids runs in the HIP
+engine (trace_amd/engine.py -> libtrace_hip.so); this class only adapts arguments."""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import List, Optional, Sequence
+
+import torch
+
+from ..config import TraceConfig
+from ..constants import MMODAL_TOKEN_INDEX, NUM_FRAMES
+from .encoders import NumberTokenizer, ScoreTower, TimeTower
+
+
+class _VisionTower:
+    """Attribute holder standing in for CLIPVisionTower (clip_encoder.py): drivers read `.image_processor`."""
+
+    def __init__(self, cfg: TraceConfig, image_processor):
+        self.config = SimpleNamespace(hidden_size=cfg.vision_hidden_size, image_size=cfg.vision_image_size,
+                                      patch_size=cfg.vision_patch_size)
+        self.image_processor = image_processor
+        self.is_loaded = True
+        self.hidden_size = cfg.vision_hidden_size
+        self.num_patches = cfg.vision_patches
+
+    def load_model(self):
+        return None
+
+    def to(self, *a, **k):
+        return self
+
+
+class _MetaModel:
+    """`model.get_model()`: exposes the tokenizers/towers the drivers touch (trace_arch.py:31-40)."""
+
+    def __init__(self, cfg: TraceConfig, vision_tower: _VisionTower):
+        self.time_tokenizer = NumberTokenizer()
+        self.score_tokenizer = NumberTokenizer()
+        self.time_tower = TimeTower(self.time_tokenizer)
+        self.score_tower = ScoreTower(self.score_tokenizer)
+        self.vision_tower = vision_tower
+
+    def get_vision_tower(self):
+        return self.vision_tower
+
+    def get_time_tower(self):
+        return self.time_tower
+
+    def get_score_tower(self):
+        return self.score_tower
+
+
+class TraceMistralForCausalLM:
+    def __init__(self, config: TraceConfig, engine, image_processor=None):
+        self.config = config
+        self.engine = engine
+        self.vocab_size = config.vocab_size
+        self.time_vocab_size = config.time_vocab_size
+        self.score_vocab_size = config.score_vocab_size
+        # trace_mistral.py:86-88
+        self.swap_tokens = {config.vocab_size: 1, config.vocab_size + 1: 2,
+                            config.vocab_size + config.time_vocab_size + 1: 0}
+        self.model = _MetaModel(config, _VisionTower(config, image_processor))
+        self.device = engine.device
+        self.dtype = torch.bfloat16
+
+    # ---- nn.Module-like conveniences the drivers call ----
+    def get_model(self):
+        return self.model
+
+    def get_vision_tower(self):
+        return self.model.get_vision_tower()
+
+    def to(self, *a, **k):
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+    def half(self):
+        return self
+
+    def eval(self):
+        return self
+
+    def resize_token_embeddings(self, n):
+        if n != self.config.vocab_size:
+            raise NotImplementedError("the engine's embedding table is fixed at load time")
+
+    # ---- generate (trace_mistral.py:268-314) ----
+    @torch.no_grad()
+    def generate(self, inputs=None, images_or_videos=None, times=None, scores=None, video_timestamps=None,
+                 modal_list=None, heads=None, max_new_tokens: int = 128, do_sample: bool = False, temperature: float = 1.0,
+                 eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None, stopping_criteria=None,
+                 use_cache: bool = True, attention_mask=None, position_ids=None, **kwargs):
+        if "inputs_embeds" in kwargs:
+            raise NotImplementedError("`inputs_embeds` is not supported")          # trace_mistral.py:282-283
+        if images_or_videos is None:
+            raise NotImplementedError("text-only generation is outside the accelerated path")
+        cfg, eng = self.config, self.engine
+        ids = inputs if isinstance(inputs, torch.Tensor) else torch.tensor(inputs)
+        if ids.dim() == 1:
+            ids = ids.unsqueeze(0)
+        B = ids.shape[0]
+        if len(images_or_videos) != B:
+            raise ValueError("one video per prompt row")
+        if heads is None:
+            heads = [0] * B
+        assert len(heads) == B                                                    # trace_mistral.py:245
+        if video_timestamps is None:
+            raise ValueError("video_timestamps is required on the TRACE path (time tokens per frame)")
+        nf = cfg.num_frames if hasattr(cfg, "num_frames") else NUM_FRAMES
+        vids = []
+        for x, modal in zip(images_or_videos, modal_list or ["video"] * B):
+            if modal == "image":                                                  # trace_arch.py:221
+                x = x.unsqueeze(0).expand(nf, -1, -1, -1) if x.dim() == 3 else x.expand(nf, -1, -1, -1)
+            vids.append(x)
+        eos = cfg.eos_token_id if eos_token_id is None else eos_token_id
+        if eos is None:
+            eos = -1
+        id_lists = [row.tolist() for row in ids]
+        if B > eng.max_batch:
+            raise ValueError(f"batch {B} exceeds the engine's max_batch {eng.max_batch}")
+        if not do_sample and not stopping_criteria:
+            out, new_heads = eng.generate(vids, video_timestamps, id_lists, list(heads), max_new_tokens, eos=eos)
+        else:
+            out, new_heads = self._generate_stepwise(vids, video_timestamps, id_lists, list(heads), max_new_tokens, eos,
+                                                     do_sample, temperature, stopping_criteria, ids)
+        for b in range(B):                       # the reference mutates `heads` in place (trace_mistral.py:342)
+            heads[b] = int(new_heads[b])
+        pad = eos if pad_token_id is None else pad_token_id
+        n = max(len(x) for x in out)
+        res = torch.full((B, n), pad if pad is not None and pad >= 0 else 0, dtype=torch.long)
+        for b, row in enumerate(out):
+            res[b, : len(row)] = torch.tensor(row, dtype=torch.long)
+        return res.to(self.device)
+
+    def _generate_stepwise(self, vids, timestamps, id_lists, heads, max_new, eos, do_sample, temperature, stopping, prompt_ids):
+        """Sampling / stopping-criteria path: one device step at a time with the masked logits brought back
+        (the reference's HF sampling loop does the same round trip every token)."""
+        eng = self.engine
+        B = len(vids)
+        for b in range(B):
+            eng.encode_video(vids[b], timestamps[b])
+            eng.prefill(b, eng.splice(id_lists[b]))
+        done = [False] * B
+        eng.host_mode(True)
+        try:
+            lg = eng.decode_begin(list(range(B)), heads, max_new, eos=eos, want_logits=True)
+            for step in range(max_new):
+                if do_sample and temperature and temperature > 0:
+                    probs = torch.softmax(lg.float() / temperature, dim=-1)
+                    tok = torch.multinomial(probs, 1).view(-1).tolist()
+                else:
+                    tok = torch.argmax(lg, dim=-1).tolist()
+                eng.feed(tok)
+                for b in range(B):
+                    done[b] = done[b] or (eos >= 0 and tok[b] == eos)
+                if all(done) or step == max_new - 1:
+                    break
+                if stopping:
+                    cur, _ = eng.decode_read()
+                    n = max(len(x) for x in cur)
+                    full = torch.cat([prompt_ids.cpu(), torch.tensor([x + [0] * (n - len(x)) for x in cur])], dim=1)
+                    if all(sc(full, None) for sc in stopping):
+                        break
+                lg = eng.decode_steps(1, use_graph=False, want_logits=True)
+            return eng.decode_read()
+        finally:
+            eng.host_mode(False)
+
+    # ---- forward (trace_mistral.py:114-264), prefill form: last-position masked logits ----
+    @torch.no_grad()
+    def forward(self, input_ids=None, images=None, video_timestamps=None, heads=None, **kwargs):
+        if images is None or input_ids is None:
+            raise NotImplementedError("forward() is provided for the multimodal prefill form only")
+        vids, modals = images
+        eng = self.engine
+        ids = input_ids if input_ids.dim() == 2 else input_ids.unsqueeze(0)
+        B = ids.shape[0]
+        for b in range(B):
+            eng.encode_video(vids[b], video_timestamps[b])
+            eng.prefill(b, eng.splice(ids[b].tolist()))
+        hd = list(heads) if heads is not None else [0] * B
+        lg = eng.decode_begin(list(range(B)), hd, 1, eos=-1, want_logits=True)
+        return SimpleNamespace(logits=lg.unsqueeze(1), past_key_values=None, loss=None)
+
+    __call__ = forward

@@ -34,7 +34,8 @@ def _driver_inputs(cfg, tok, proc, seed=0):
     conv.append_message(conv.roles[1], None)
     prompt = conv.get_prompt() + "<sync>"
     ids = tokenizer_MMODAL_token_all(prompt, tok, return_tensors="pt")
-    ids = torch.cat([ids[:60], ids[-3:]])          # keep the byte-level prompt short
+    vp = int(torch.nonzero(ids == -201)[0])
+    ids = torch.cat([ids[:1], ids[vp - 20: vp + 20], ids[-3:]])          # keep the byte-level prompt short
     assert (ids == -201).sum() == 1 and ids[-1] == -205
     return tensor, ts, ids
 

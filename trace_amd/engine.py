@@ -178,8 +178,9 @@ class TraceEngine:
     def feed(self, tokens: Sequence[int]):
         _lib.check(self.lib.trace_decode_feed(self.h, _i32(tokens), len(tokens), _stream()))
 
-    def set_profile(self, on: bool):
-        _lib.check(self.lib.trace_set_profile(self.h, 1 if on else 0))
+    def set_profile(self, mode: int):
+        """0 off; 1 time decode_steps calls; 2 also bracket one gate|up GEMV launch per decode step with HIP events."""
+        _lib.check(self.lib.trace_set_profile(self.h, int(mode)))
 
     def get_profile(self) -> List[float]:
         buf = (C.c_float * 8)()

@@ -125,24 +125,25 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                     S[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], S[st], 0, 0, 0);
                 }
             }
-            // ---- online softmax (base 2) ----
+            // ---- online softmax (base 2; the score scale is folded into the exp2 argument: p = 2^(s*sc - m)) ----
             const bool edge = (kv0 + BKV > a.nkv_rows) || (a.causal && (kv0 + BKV - 1 > q0 + off));
             float mloc = -1e30f;
+            if (edge) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = kv0 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const bool ok = kv < a.nkv_rows && (!a.causal || kv <= qabs + off);
+                        S[st][r] = ok ? S[st][r] : -1e30f;
+                    }
+            }
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float s = S[st][r] * sc;
-                    if (edge) {
-                        const int kv = kv0 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const bool ok = kv < a.nkv_rows && (!a.causal || kv <= qabs + off);
-                        s = ok ? s : -1e30f;
-                    }
-                    S[st][r] = s;
-                    mloc = fmaxf(mloc, s);
-                }
+                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, S[st][r]);
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float mnew = fmaxf(m, mloc);
+            const float mnew = fmaxf(m, mloc * sc);           // running max in the scaled (base-2) domain
             const float alpha = exp2f(m - mnew);
             m = mnew;
             float lsum = 0.f;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             for (int st = 0; st < 2; ++st)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = exp2f(S[st][r] - mnew);
+                    const float p = exp2f(fmaf(S[st][r], sc, -mnew));
                     lsum += p;
                     S[st][r] = p;
                 }

@@ -13,14 +13,14 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;               // 32
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ float bflo(uint32_t v) { return __uint_as_float(v << 16); }          // low half of a packed pair
 __device__ __forceinline__ float bfhi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }  // high half
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even: the native __bf16 conversion lowers to ONE v_cvt_pk_bf16_f32 on gfx950
+// (a hand-rolled integer rounding sequence costs ~16 VALU ops per pair and dominated epilogues / softmax packing).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_native_t;
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    const bf16x2_native_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -28,7 +28,7 @@ __device__ __forceinline__ int kswz(int row, int kc) {
 }
 
 template <int HD, bool GQA>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     constexpr int KT_BYTES = BKV * HD * 2;
     constexpr int VT_BYTES = HD * VROW;
     constexpr int BUF = KT_BYTES + VT_BYTES;

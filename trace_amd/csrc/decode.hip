@@ -193,19 +193,16 @@ __global__ __launch_bounds__(512, 4) void skinny_gemm_kernel(const bf16_t* __res
 // ([b][q-head][split][hd + 2] fp32) with write-through (sc1) stores; every wave drains vmcnt, then one lane takes
 // an agent-scope ticket; the last-arriving workgroup of a (b, kv-head) pair does ONE agent-scope acquire and merges
 // the splits (placement-independent: no assumption on dispatch order or XCD), then re-zeroes the ticket.
-constexpr int AD_MAXIT = 8;            // rows per 16-lane group: chunk <= 16 * AD_MAXIT = 128 rows per split
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ qkv, int ldq, bf16_t* __restrict__ kcache,
-                                                          bf16_t* __restrict__ vcache, long slot_stride, long kv_head_stride,
-                                                          const int32_t* __restrict__ slots, const int32_t* __restrict__ pos,
-                                                          float* __restrict__ ws, unsigned int* __restrict__ tickets,
-                                                          bf16_t* __restrict__ O, int ldo, int nq, int nkv, int nsplit,
-                                                          float scale, int fuse_rope, const float* __restrict__ cos_t,
-                                                          const float* __restrict__ sin_t, int dbg) {
-    constexpr int HD = 128, GQ = 4, CH = 16 * AD_MAXIT;
-    __shared__ float s_p[GQ][CH];
-    __shared__ float s_o[GQ][HD];
-    __shared__ float s_red[4][GQ][2];
-    __shared__ float s_ml[GQ][2];
+__global__ __launch_bounds__(256, 2) void attn_decode_kernel(const bf16_t* __restrict__ qkv, int ldq, bf16_t* __restrict__ kcache,
+                                                             bf16_t* __restrict__ vcache, long slot_stride, long kv_head_stride,
+                                                             const int32_t* __restrict__ slots, const int32_t* __restrict__ pos,
+                                                             float* __restrict__ ws, unsigned int* __restrict__ tickets,
+                                                             bf16_t* __restrict__ O, int ldo, int nq, int nkv, int nsplit,
+                                                             float scale, int fuse_rope, const float* __restrict__ cos_t,
+                                                             const float* __restrict__ sin_t, int dbg) {
+    constexpr int HD = 128, GQ = 4, PF = 4;          // PF = cache rows per 16-lane group per prefetch batch
+    __shared__ float s_acc[4][GQ][HD];
+    __shared__ float s_m[4][GQ], s_l[4][GQ];
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane >> 4, c = lane & 15;
@@ -216,19 +213,21 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     chunk = (chunk + 15) & ~15;
     const int beg = sp * chunk, end = min(ctx, beg + chunk);
     const int len = max(end - beg, 0);
+    const int nit = (len + 15) >> 4;                  // 16 rows per workgroup iteration (4 waves x 4 groups)
     bf16_t* kb = kcache + (size_t)slots[b] * slot_stride + (size_t)kvh * kv_head_stride;
     bf16_t* vb = vcache + (size_t)slots[b] * slot_stride + (size_t)kvh * kv_head_stride;
 
-    // ---- issue the cache loads first (rows beg + it*16 + wid*4 + j) ----
-    uint4 kr[AD_MAXIT], vr[AD_MAXIT];
+    uint4 kA[PF], vA[PF], kB[PF], vB[PF];
+    auto load = [&](uint4 (&kr)[PF], uint4 (&vr)[PF], int it0) {
 #pragma unroll
-    for (int it = 0; it < AD_MAXIT; ++it) {
-        const int i = it * 16 + wid * 4 + j;
-        const bool ok = i < len && !(fuse_rope && beg + i == p_new);
-        kr[it] = ok ? *reinterpret_cast<const uint4*>(kb + (size_t)(beg + i) * HD + c * 8) : make_uint4(0, 0, 0, 0);
-        vr[it] = ok ? *reinterpret_cast<const uint4*>(vb + (size_t)(beg + i) * HD + c * 8) : make_uint4(0, 0, 0, 0);
-    }
-    for (int i = tid; i < GQ * HD; i += 256) (&s_o[0][0])[i] = 0.f;
+        for (int u = 0; u < PF; ++u) {
+            const int i = (it0 + u) * 16 + wid * 4 + j;
+            const bool ok = i < len && !(fuse_rope && beg + i == p_new);
+            kr[u] = ok ? *reinterpret_cast<const uint4*>(kb + (size_t)(beg + i) * HD + c * 8) : make_uint4(0, 0, 0, 0);
+            vr[u] = ok ? *reinterpret_cast<const uint4*>(vb + (size_t)(beg + i) * HD + c * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    if (nit > 0) load(kA, vA, 0);                     // cache rows start streaming before anything else
 
     // ---- q (4 heads of this kv group) and, when fused, RoPE + the new k/v row ----
     float qv[GQ][8];
@@ -269,77 +268,75 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
                 *reinterpret_cast<uint4*>(vb + (size_t)p_new * HD + c * 8) = vnew;
             }
         }
+#pragma unroll
+        for (int hq = 0; hq < GQ; ++hq)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qv[hq][e] *= scale;
     }
-    // ---- scores ----
-    float mloc[GQ] = {-1e30f, -1e30f, -1e30f, -1e30f};
-#pragma unroll
-    for (int it = 0; it < AD_MAXIT; ++it) {
-        if (it * 16 >= len) break;
-        const int i = it * 16 + wid * 4 + j;
-        const uint4 u = (fuse_rope && beg + i == p_new) ? knew : kr[it];
-        const float kv[8] = {bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y), bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
-        float part[GQ];
-#pragma unroll
-        for (int hq = 0; hq < GQ; ++hq) {
-            float a = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a += qv[hq][e] * kv[e];
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-            part[hq] = i < len ? a * scale : -1e30f;
-            mloc[hq] = fmaxf(mloc[hq], part[hq]);
-        }
-        if (c == 0 && i < len) {
-#pragma unroll
-            for (int hq = 0; hq < GQ; ++hq) s_p[hq][i] = part[hq];
-        }
-    }
-    // block max per head
+    // ---- online softmax per 16-lane group: running max m, sum l, and this lane's 8-wide slice of o, per q-head ----
+    float m[GQ], l[GQ], acc[GQ][8];
 #pragma unroll
     for (int hq = 0; hq < GQ; ++hq) {
-        float m = fmaxf(mloc[hq], __shfl_xor(mloc[hq], 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        if (lane == 0) s_red[wid][hq][0] = m;
-    }
-    __syncthreads();
-    float mx[GQ];
-#pragma unroll
-    for (int hq = 0; hq < GQ; ++hq) mx[hq] = fmaxf(fmaxf(s_red[0][hq][0], s_red[1][hq][0]), fmaxf(s_red[2][hq][0], s_red[3][hq][0]));
-    // ---- p = exp(s - max), o += p * V, l += p ----
-    float acc[GQ][8];
-    float lsum[GQ] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int hq = 0; hq < GQ; ++hq)
+        m[hq] = -1e30f; l[hq] = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[hq][e] = 0.f;
+    }
+    auto process = [&](uint4 (&kr)[PF], uint4 (&vr)[PF], int it0) {
 #pragma unroll
-    for (int it = 0; it < AD_MAXIT; ++it) {
-        if (it * 16 >= len) break;
-        const int i = it * 16 + wid * 4 + j;
-        if (i < len) {
-            const uint4 u = (fuse_rope && beg + i == p_new) ? vnew : vr[it];
-            const float vv[8] = {bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y), bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
+        for (int u = 0; u < PF; ++u) {
+            if (it0 + u >= nit) break;
+            const int i = (it0 + u) * 16 + wid * 4 + j;
+            const bool fresh = fuse_rope && beg + i == p_new;
+            const uint4 ku = fresh ? knew : kr[u];
+            const uint4 vu = fresh ? vnew : vr[u];
+            const float kv[8] = {bflo(ku.x), bfhi(ku.x), bflo(ku.y), bfhi(ku.y), bflo(ku.z), bfhi(ku.z), bflo(ku.w), bfhi(ku.w)};
+            const float vv[8] = {bflo(vu.x), bfhi(vu.x), bflo(vu.y), bfhi(vu.y), bflo(vu.z), bfhi(vu.z), bflo(vu.w), bfhi(vu.w)};
 #pragma unroll
             for (int hq = 0; hq < GQ; ++hq) {
-                const float p = __expf(s_p[hq][i] - mx[hq]);
-                lsum[hq] += p;
+                float sc = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[hq][e] += p * vv[e];
+                for (int e = 0; e < 8; ++e) sc += qv[hq][e] * kv[e];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) sc += __shfl_xor(sc, o, 64);
+                if (i < len) {
+                    const float mn = fmaxf(m[hq], sc);
+                    const float a = __expf(m[hq] - mn), p = __expf(sc - mn);
+                    m[hq] = mn;
+                    l[hq] = l[hq] * a + p;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[hq][e] = acc[hq][e] * a + p * vv[e];
+                }
             }
         }
+    };
+    for (int it0 = 0; it0 < nit; it0 += 2 * PF) {
+        if (it0 + PF < nit) load(kB, vB, it0 + PF);
+        process(kA, vA, it0);
+        if (it0 + PF < nit) {
+            if (it0 + 2 * PF < nit) load(kA, vA, it0 + 2 * PF);
+            process(kB, vB, it0 + PF);
+        }
     }
+    // ---- merge the 4 groups of the wave (xor 16, 32), then the 4 waves through LDS ----
 #pragma unroll
-    for (int hq = 0; hq < GQ; ++hq) {
-        float l = lsum[hq];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        if (lane == 0) s_red[wid][hq][1] = l;          // every 16-lane group holds the same p's: take group c==0 of each j
+    for (int o = 16; o <= 32; o <<= 1) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v = acc[hq][e];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (j == 0) atomicAdd(&s_o[hq][c * 8 + e], v);
+        for (int hq = 0; hq < GQ; ++hq) {
+            const float mo = __shfl_xor(m[hq], o, 64), lo = __shfl_xor(l[hq], o, 64);
+            const float M = fmaxf(m[hq], mo);
+            const float fa = __expf(m[hq] - M), fb = __expf(mo - M);
+            l[hq] = l[hq] * fa + lo * fb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[hq][e] = acc[hq][e] * fa + __shfl_xor(acc[hq][e], o, 64) * fb;
+            m[hq] = M;
+        }
+    }
+    if (j == 0) {
+#pragma unroll
+        for (int hq = 0; hq < GQ; ++hq) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_acc[wid][hq][c * 8 + e] = acc[hq][e];
+            if (c == 0) { s_m[wid][hq] = m[hq]; s_l[wid][hq] = l[hq]; }
         }
     }
     __syncthreads();
@@ -349,13 +346,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         // write-through (sc1) stores: visible at agent scope once vmcnt drains, no L2 write-back fence needed
         for (int i = tid; i < GQ * HD; i += 256) {
             const int hq = i >> 7, d = i & 127;
-            __hip_atomic_store(&ws[base + (size_t)hq * nsplit * (HD + 2) + d], s_o[hq][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (tid < GQ) {
-            __hip_atomic_store(&ws[base + (size_t)tid * nsplit * (HD + 2) + HD], mx[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ws[base + (size_t)tid * nsplit * (HD + 2) + HD + 1],
-                               s_red[0][tid][1] + s_red[1][tid][1] + s_red[2][tid][1] + s_red[3][tid][1], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            const float M = fmaxf(fmaxf(s_m[0][hq], s_m[1][hq]), fmaxf(s_m[2][hq], s_m[3][hq]));
+            float o = 0.f, L = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float f = __expf(s_m[w][hq] - M);
+                o += f * s_acc[w][hq][d];
+                L += f * s_l[w][hq];
+            }
+            __hip_atomic_store(&ws[base + (size_t)hq * nsplit * (HD + 2) + d], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == 0) {
+                __hip_atomic_store(&ws[base + (size_t)hq * nsplit * (HD + 2) + HD], M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ws[base + (size_t)hq * nsplit * (HD + 2) + HD + 1], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     if (dbg == 1) return;

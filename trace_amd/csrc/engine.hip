@@ -116,8 +116,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     if (c->H % 128 || c->I % 128 || c->vh % 128 || c->vi % 128 || c->QKV % 128) return bad("dims must be multiples of 128");
     if (c->S != 8 || c->vh > 1024) return bad("slot pool kernel needs 8 slots and mm_hidden <= 1024");
     if (c->max_B < 1 || c->max_B > 16) return bad("max_batch must be in [1,16]");
-    c->nsplit = 32;
-    while (c->nsplit * 128 < c->max_ctx) c->nsplit *= 2;      // decode attention: <= 128 cache rows per split
+    c->nsplit = 32;                                           // upper bound (workspace size); per-batch value below
     if (cfg->max_frames < 1 || cfg->max_frames * c->TPF > c->max_ctx) return bad("max_frames*14 exceeds max_ctx");
     if (c->Tv != 13 || c->Sv != 13) { /* any size works; kept for clarity */ }
 
@@ -539,6 +538,10 @@ static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* l
     return select_only(c, advance, s);
 }
 
+// decode attention context split: ~256-512 workgroups (8 kv heads x B x nsplit) keep every CU busy without paying
+// the per-workgroup latency chain more often than needed
+static int decode_nsplit(int B) { return B <= 1 ? 32 : B <= 2 ? 16 : B <= 4 ? 8 : B <= 8 ? 8 : 4; }
+
 // one decode step for the current batch: consumes dX (embedding of the last token), leaves the next one in dX
 static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
     const int H = c->H, I = c->I, HD = c->HD, QKV = c->QKV, B = c->B;
@@ -551,7 +554,7 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
         LCHK(launch_rmsnorm(c->dX, H, c->dH, H, W.rms1, B, H, c->c.rms_eps, s));
         LCHK(launch_skinny_gemm(c->dH, H, W.wqkv, H, c->dQKV, QKV, nullptr, 0, B, QKV, H, EPI_NONE, nullptr, 0.f, s));
         LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->d_slots, c->d_pos, c->dO,
-                                H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, c->nsplit, 1.0f / sqrtf((float)HD), 1,
+                                H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, decode_nsplit(B), 1.0f / sqrtf((float)HD), 1,
                                 c->rope_cos, c->rope_sin, s));
         LCHK(launch_skinny_gemm(c->dO, H, W.wo, H, c->dX, H, c->dX, H, B, H, H, EPI_RESIDUAL, nullptr, 0.f, s));
         // roofline probe: HIP events around ONE launch of the dominant kernel (layer 0 gate|up GEMV) per step
@@ -762,7 +765,6 @@ extern "C" int trace_op_attn_decode(const void* q, const void* kcache, const voi
         HIPCHK(hipMalloc((void**)&d_tickets, 16 * 64 * 4));
         HIPCHK(hipMemset(d_tickets, 0, 16 * 64 * 4));
     }
-    if (nsplit * 128 < max_ctx) return fail(TRACE_ERR_ARG, "nsplit too small: at most 128 cache rows per split");
     LCHK(launch_attn_decode((const bf16_t*)q, nq * 128, (bf16_t*)kcache, (bf16_t*)vcache, (long)nkv * max_ctx * 128,
                             (long)max_ctx * 128, d_slots, pos, (bf16_t*)O, nq * 128, ws, d_tickets, B, nq, nkv, 128, nsplit, scale, 0,
                             nullptr, nullptr, (hipStream_t)stream));

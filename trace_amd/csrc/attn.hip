@@ -28,7 +28,7 @@ __device__ __forceinline__ int kswz(int row, int kc) {
 }
 
 template <int HD, bool GQA>
-__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_kernel(AttnArgs a) {
     constexpr int KT_BYTES = BKV * HD * 2;
     constexpr int VT_BYTES = HD * VROW;
     constexpr int BUF = KT_BYTES + VT_BYTES;
@@ -72,27 +72,31 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
         krow[i] = c / CPR; kkc[i] = c % CPR;
         vrow[i] = c >> 3; vkc[i] = c & 7;
     }
-    uint4 rk[NCH], rv[NCH];
-    auto gload = [&](int t) {
-        const int kv0 = t * BKV;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int kr = min(kv0 + krow[i], a.nkv_rows - 1);
-            rk[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)kr * a.k_rs + kkc[i] * 8);
-            rv[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)vrow[i] * a.v_rs + kv0 + vkc[i] * 8);
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* kb = smem + buf * BUF;
-        char* vb = kb + KT_BYTES;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            *reinterpret_cast<uint4*>(kb + kswz<HD>(krow[i], kkc[i])) = rk[i];
-            char* vp = vb + vrow[i] * VROW + vkc[i] * 16;
-            *reinterpret_cast<uint2*>(vp) = make_uint2(rv[i].x, rv[i].y);
-            *reinterpret_cast<uint2*>(vp + 8) = make_uint2(rv[i].z, rv[i].w);
-        }
-    };
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    u32x4 rk[NCH], rv[NCH];
+    // (macros, not lambdas: with by-reference lambda captures hipcc kept rk/rv in scratch memory and the prefetch
+    //  registers were spilled right after the loads, serialising the global-load latency)
+#define ATTN_GLOAD(T_)                                                                                         \
+    {                                                                                                          \
+        const int kv0_ = (T_) * BKV;                                                                           \
+        _Pragma("unroll") for (int i = 0; i < NCH; ++i) {                                                      \
+            const int kr_ = min(kv0_ + krow[i], a.nkv_rows - 1);                                               \
+            rk[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)kr_ * a.k_rs + kkc[i] * 8);                \
+            rv[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)vrow[i] * a.v_rs + kv0_ + vkc[i] * 8);     \
+        }                                                                                                      \
+    }
+#define ATTN_LSTORE(BUF_)                                                                                      \
+    {                                                                                                          \
+        char* kb_ = smem + (BUF_) * BUF;                                                                       \
+        char* vb_ = kb_ + KT_BYTES;                                                                            \
+        _Pragma("unroll") for (int i = 0; i < NCH; ++i) {                                                      \
+            *reinterpret_cast<u32x4*>(kb_ + kswz<HD>(krow[i], kkc[i])) = rk[i];                                \
+            char* vp_ = vb_ + vrow[i] * VROW + vkc[i] * 16;                                                    \
+            *reinterpret_cast<u32x2*>(vp_) = u32x2{rv[i][0], rv[i][1]};                                     \
+            *reinterpret_cast<u32x2*>(vp_ + 8) = u32x2{rv[i][2], rv[i][3]};                                 \
+        }                                                                                                      \
+    }
 
     f32x16_t oacc[HD / 32];
 #pragma unroll
@@ -102,13 +106,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     float m = -1e30f, l = 0.f;
     const float sc = a.scale * 1.4426950408889634f;
 
-    gload(0);
-    lstore(0);
+    ATTN_GLOAD(0)
+    ATTN_LSTORE(0)
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
         const bool more = t + 1 < nt;
-        if (more) gload(t + 1);
+        if (more) ATTN_GLOAD(t + 1)
         const char* kb = smem + (t & 1) * BUF;
         const char* vb = kb + KT_BYTES;
         const int kv0 = t * BKV;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
                 }
             }
         }
-        if (more) lstore((t + 1) & 1);
+        if (more) ATTN_LSTORE((t + 1) & 1)
         __syncthreads();
     }
 

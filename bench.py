@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--videos-per-step", type=int, default=int(os.environ.get("TRACE_BENCH_BATCH", "8")))
+    ap.add_argument("--videos-per-step", type=int, default=int(os.environ.get("TRACE_BENCH_BATCH", "16")))
     ap.add_argument("--frames", type=int, default=128)
     ap.add_argument("--max-new", type=int, default=256)
     ap.add_argument("--eager", action="store_true", help="launch decode steps eagerly instead of replaying the hipGraph")

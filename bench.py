@@ -68,7 +68,9 @@ def main():
     ap.add_argument("--videos-per-step", type=int, default=int(os.environ.get("TRACE_BENCH_BATCH", "16")))
     ap.add_argument("--frames", type=int, default=128)
     ap.add_argument("--max-new", type=int, default=256)
-    ap.add_argument("--eager", action="store_true", help="launch decode steps eagerly instead of replaying the hipGraph")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the captured hipGraph for decode steps (default: eager launches, which run at the same speed "
+                         "— the step is GPU-bound — and allow the per-launch HIP-event roofline probe in the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="tiny geometry (plumbing check)")
     args = ap.parse_args()
@@ -98,7 +100,7 @@ def main():
     heads = [1] * B
 
     def step():
-        out, _ = eng.generate(videos, ts, prompt, heads, n_new, eos=-1, use_graph=not args.eager)
+        out, _ = eng.generate(videos, ts, prompt, heads, n_new, eos=-1, use_graph=args.graph)
         if world > 1:
             tdist.gather_outputs(out, n_new, B, dev)
         return out
@@ -126,7 +128,7 @@ def main():
     for b in range(1, B):
         eng.encode_video(videos[b], ts[b]); eng.prefill(b, eng.splice(ids))
     eng.decode_begin(list(range(B)), heads, n_new)
-    t_dec = ev_time(lambda: eng.decode_steps(n_new - 1, use_graph=not args.eager))
+    t_dec = ev_time(lambda: eng.decode_steps(n_new - 1, use_graph=args.graph))
 
     if rank == 0:
         vps = world * B * args.steps / dt
@@ -150,7 +152,7 @@ def main():
                                     "C2: TRACE-7B bf16 (CLIP-ViT-L/14-336 23 layers + SpatialSlotPool + Mistral-7B), "
                                     f"{args.frames}x336^2 frames, prefill L={Ls}, {n_new} greedy tokens, heads=[1]"),
                        "videos_per_step_per_gpu": B, "frames": args.frames, "prefill_len": Ls, "new_tokens": n_new,
-                       "decode_launch": "eager" if args.eager else "hipGraph", "parallelism": f"dp{world} (replica per GPU)",
+                       "decode_launch": "hipGraph" if args.graph else "eager", "parallelism": f"dp{world} (replica per GPU)",
                        "weights": "random-init (device RNG), reference architecture"},
             "decode_tok_s": world * B * (n_new - 1) / (t_dec * 1e-3),
             "stages_ms": {"vit_slotpool_per_video": t_enc, "prefill_per_video": t_pre, f"decode_{n_new - 1}_steps_batch{B}": t_dec,

@@ -560,8 +560,8 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
         // roofline probe: HIP events around ONE launch of the dominant kernel (layer 0 gate|up GEMV) per step
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (l == 0 && c->profile == 2) {
-            if (s == c->cap_stream) { e0 = c->gev0; e1 = c->gev1; }
-            else if (c->kev_used + 2 <= (int)c->kev.size()) { e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2; }
+            // (event-record nodes captured into a hipGraph do not yield usable timestamps on ROCm 7.2: eager launches only)
+            if (s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) { e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2; }
         }
         LCHK(launch_rmsnorm(c->dX, H, c->dH, H, W.rms2, B, H, c->c.rms_eps, s));
         if (e0) hipEventRecord(e0, s);
@@ -618,7 +618,7 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
         for (int i = 0; i < n; ++i) TRY(decode_step(c, logits_out, s));
     } else {
         const int key = c->B;
-        hipGraphExec_t* slot_g = c->profile == 2 ? &c->graphs_prof[key] : &c->graphs[key];
+        hipGraphExec_t* slot_g = &c->graphs[key];
         if (!*slot_g) {
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamSynchronize(s));
@@ -632,11 +632,6 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
             if (e != hipSuccess) { *slot_g = nullptr; return fail(TRACE_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
         }
         for (int i = 0; i < n; ++i) HIPCHK(hipGraphLaunch(*slot_g, s));
-        if (c->profile == 2 && n > 0) {      // the pair recorded by the last replay
-            hipStreamSynchronize(s);
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, c->gev0, c->gev1) == hipSuccess && ms > 0.f) { c->ksum_ms += ms; c->ksamples += 1; }
-        }
     }
     if (c->profile == 2 && c->kev_used > 0) {   // drain the eager-mode brackets
         hipStreamSynchronize(s);

@@ -34,7 +34,7 @@ typedef struct trace_config {
     float slot_eps, slot_rope_base;
     int32_t max_frames;      /* largest T per video                                    */
     int32_t max_ctx;         /* KV-cache length per sequence slot (prefill + new tokens) */
-    int32_t max_batch;       /* sequence slots (videos decoded together), <= 16          */
+    int32_t max_batch;       /* sequence slots (videos decoded together), <= 32          */
     int32_t max_new_tokens;  /* capacity of the on-device output id buffer               */
 } trace_config;
 
@@ -109,7 +109,7 @@ int trace_op_rmsnorm(const void* x, void* y, const void* w, int rows, int D, flo
 int trace_op_attention(const void* Q, const void* K, const void* V, void* O, void* vt_scratch, int batch, int heads,
                        int kv_heads, int nq, int nkv, int head_dim, int causal, float scale, void* stream);
 int trace_op_skinny_gemm(const void* X, const void* W, void* out, const void* R, int B, int N, int K, int epilogue,
-                         const void* rms_gamma, float rms_eps, void* stream);
+                         void* stream);
 int trace_op_attn_decode(const void* q, const void* kcache, const void* vcache, const int32_t* pos, void* O, float* ws,
                          int B, int nq, int nkv, int max_ctx, int nsplit, float scale, void* stream);
 

@@ -51,7 +51,7 @@ SIGNATURES = {
     "trace_op_layernorm": (I, [P, P, P, P, I, I, F, P]),
     "trace_op_rmsnorm": (I, [P, P, P, I, I, F, P]),
     "trace_op_attention": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
-    "trace_op_skinny_gemm": (I, [P, P, P, P, I, I, I, I, P, F, P]),
+    "trace_op_skinny_gemm": (I, [P, P, P, P, I, I, I, I, P]),
     "trace_op_attn_decode": (I, [P, P, P, P, P, P, I, I, I, I, I, F, P]),
 }
 

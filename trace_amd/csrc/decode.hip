@@ -25,20 +25,15 @@ __device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
 union Frag { uint4 u; bf16x8_t v; };
 
 // ---------------------------------------------------------------------------------------------------------
-// NORM: X is the raw residual stream; the RMSNorm (gamma, eps) of the reference's input_layernorm /
-// post_attention_layernorm is applied on the fly: every workgroup recomputes the B row scales (8 KB per row from
-// L2) while its first weight loads are in flight, and each lane scales + rounds its activation fragment to bf16
-// (the same rounding point as a separate norm kernel) right before the MFMA.
-template <int EPI, bool NORM>
-__global__ __launch_bounds__(512, 4) void skinny_gemm_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W,
-                                                          int ldw, bf16_t* __restrict__ out, int ldo,
-                                                          const bf16_t* __restrict__ R, int ldr, int B, int N, int K,
-                                                          const bf16_t* __restrict__ gamma, float eps) {
+// NB = number of 16-row activation groups (1: B <= 16, 2: B <= 32): the weight fragment is reused for both.
+template <int EPI, int NB>
+__global__ __launch_bounds__(512, NB == 1 ? 4 : 2) void skinny_gemm_kernel(const bf16_t* __restrict__ X, int ldx,
+                                                                            const bf16_t* __restrict__ W, int ldw,
+                                                                            bf16_t* __restrict__ out, int ldo,
+                                                                            const bf16_t* __restrict__ R, int ldr, int B, int N, int K) {
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;      // 16-row weight tiles per workgroup
     constexpr int UN = 2;                                // 64-wide k units per batch (4 x 16 B per lane per tile)
-    __shared__ float red[8][NT][256];
-    __shared__ float s_rs[16];
-    __shared__ __attribute__((aligned(16))) bf16_t s_gamma[NORM ? 4096 : 8];
+    __shared__ float red[8][NT * NB][256];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16 * NT;
@@ -48,16 +43,22 @@ __global__ __launch_bounds__(512, 4) void skinny_gemm_kernel(const bf16_t* __res
     const bf16_t* wp[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) wp[t] = W + (size_t)(n0 + t * 16 + r) * ldw + g * 16;
-    const bool xon = r < B;
-    const bf16_t* xp = X + (size_t)(xon ? r : 0) * ldx + g * 16;
-
-    f32x4_t acc[NT];
+    bool xon[NB];
+    const bf16_t* xp[NB];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int nb = 0; nb < NB; ++nb) {
+        xon[nb] = r + 16 * nb < B;
+        xp[nb] = X + (size_t)(xon[nb] ? r + 16 * nb : 0) * ldx + g * 16;
+    }
 
-    float rs = 1.f;
-    Frag wa[UN][NT][2], wb[UN][NT][2], xa[UN][2], xb[UN][2];
-    auto load = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][2], int u) {
+    f32x4_t acc[NT][NB];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    Frag wa[UN][NT][2], wb[UN][NT][2], xa[UN][NB][2], xb[UN][NB][2];
+    auto load = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][NB][2], int u) {
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
             const bool ok = u + j < u1;
@@ -67,119 +68,66 @@ __global__ __launch_bounds__(512, 4) void skinny_gemm_kernel(const bf16_t* __res
                 wf[j][t][0].u = ok ? ldg_nt(wp[t] + ko) : make_uint4(0, 0, 0, 0);
                 wf[j][t][1].u = ok ? ldg_nt(wp[t] + ko + 8) : make_uint4(0, 0, 0, 0);
             }
-            xf[j][0].u = (ok && xon) ? *reinterpret_cast<const uint4*>(xp + ko) : make_uint4(0, 0, 0, 0);
-            xf[j][1].u = (ok && xon) ? *reinterpret_cast<const uint4*>(xp + ko + 8) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto scale = [&](Frag& x, int k) {          // x <- bf16(x * rs * gamma[k..k+8)), gamma from LDS (lgkm queue, not vmcnt)
-        const uint4 gq = *reinterpret_cast<const uint4*>(&s_gamma[k]);
-        x.u.x = pack2bf(bflo(x.u.x) * rs * bflo(gq.x), bfhi(x.u.x) * rs * bfhi(gq.x));
-        x.u.y = pack2bf(bflo(x.u.y) * rs * bflo(gq.y), bfhi(x.u.y) * rs * bfhi(gq.y));
-        x.u.z = pack2bf(bflo(x.u.z) * rs * bflo(gq.z), bfhi(x.u.z) * rs * bfhi(gq.z));
-        x.u.w = pack2bf(bflo(x.u.w) * rs * bflo(gq.w), bfhi(x.u.w) * rs * bfhi(gq.w));
-    };
-    auto mma = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][2], int u) {
 #pragma unroll
-        for (int j = 0; j < UN; ++j) {
-            if (NORM && xon && u + j < u1) { scale(xf[j][0], (u + j) * 64 + g * 16); scale(xf[j][1], (u + j) * 64 + g * 16 + 8); }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][t][0].v, xf[j][0].v, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][t][1].v, xf[j][1].v, acc[t], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb) {
+                xf[j][nb][0].u = (ok && xon[nb]) ? *reinterpret_cast<const uint4*>(xp[nb] + ko) : make_uint4(0, 0, 0, 0);
+                xf[j][nb][1].u = (ok && xon[nb]) ? *reinterpret_cast<const uint4*>(xp[nb] + ko + 8) : make_uint4(0, 0, 0, 0);
             }
         }
     };
-    if (u0 < u1) load(wa, xa, u0);                 // weights start streaming before the norm statistics
-    if (NORM) {
-        // each wave stages only ITS k-slice of gamma (wave-private LDS region: no workgroup barrier needed)
-        uint4 gq[2];
-        const int k0 = u0 * 64, k1 = u1 * 64;
+    auto mma = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][NB][2]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int k = k0 + (i * 64 + lane) * 8;
-            gq[i] = k < k1 ? *reinterpret_cast<const uint4*>(gamma + k) : make_uint4(0, 0, 0, 0);
-        }
-        if (B <= 2) {
-            // every wave recomputes the row statistics it needs (B <= 2 rows, 8 KB each from L2): no barrier at all
-            float ss0 = 0.f, ss1 = 0.f;
-            for (int k = lane * 8; k < K; k += 64 * 8) {
-                const uint4 u = *reinterpret_cast<const uint4*>(X + k);
-                const float a0 = bflo(u.x), a1 = bfhi(u.x), a2 = bflo(u.y), a3 = bfhi(u.y);
-                const float a4 = bflo(u.z), a5 = bfhi(u.z), a6 = bflo(u.w), a7 = bfhi(u.w);
-                ss0 += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5 + a6 * a6 + a7 * a7;
-                if (B == 2) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(X + ldx + k);
-                    const float b0 = bflo(v.x), b1 = bfhi(v.x), b2 = bflo(v.y), b3 = bfhi(v.y);
-                    const float b4 = bflo(v.z), b5 = bfhi(v.z), b6 = bflo(v.w), b7 = bfhi(v.w);
-                    ss1 += b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3 + b4 * b4 + b5 * b5 + b6 * b6 + b7 * b7;
+        for (int j = 0; j < UN; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][t][0].v, xf[j][nb][0].v, acc[t][nb], 0, 0, 0);
+                    acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][t][1].v, xf[j][nb][1].v, acc[t][nb], 0, 0, 0);
                 }
-            }
-            ss0 = wave_sum(ss0);
-            ss1 = wave_sum(ss1);
-            rs = rsqrtf((r == 0 ? ss0 : ss1) / (float)K + eps);
-        } else {
-            // wave w owns rows w and w + 8; one workgroup barrier
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int m = wid + rr * 8;
-                if (m < B) {
-                    float ss = 0.f;
-                    for (int k = lane * 8; k < K; k += 64 * 8) {
-                        const uint4 u = *reinterpret_cast<const uint4*>(X + (size_t)m * ldx + k);
-                        const float a0 = bflo(u.x), a1 = bfhi(u.x), a2 = bflo(u.y), a3 = bfhi(u.y);
-                        const float a4 = bflo(u.z), a5 = bfhi(u.z), a6 = bflo(u.w), a7 = bfhi(u.w);
-                        ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5 + a6 * a6 + a7 * a7;
-                    }
-                    ss = wave_sum(ss);
-                    if (lane == 0) s_rs[m] = rsqrtf(ss / (float)K + eps);
-                }
-            }
-            __syncthreads();
-            if (xon) rs = s_rs[r];
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int k = k0 + (i * 64 + lane) * 8;
-            if (k < k1) *reinterpret_cast<uint4*>(&s_gamma[k]) = gq[i];
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's own gamma slice is in LDS
-        __builtin_amdgcn_wave_barrier();
-    }
+    };
     if (u0 < u1) {
+        load(wa, xa, u0);
         for (int u = u0; u < u1; u += 2 * UN) {
             if (u + UN < u1) load(wb, xb, u + UN);
-            mma(wa, xa, u);
+            mma(wa, xa);
             if (u + UN < u1) {
                 if (u + 2 * UN < u1) load(wa, xa, u + 2 * UN);
-                mma(wb, xb, u + UN);
+                mma(wb, xb);
             }
         }
     }
-    // acc[t][i] = partial out[m = r][n = n0 + t*16 + g*4 + i]
+    // acc[t][nb][i] = partial out[m = 16*nb + r][n = n0 + t*16 + g*4 + i]
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) red[wid][t][i * 64 + lane] = acc[t][i];
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wid][t * NB + nb][i * 64 + lane] = acc[t][nb][i];
     __syncthreads();
     if (tid < 256) {
         const int i = tid >> 6, l = tid & 63;
-        const int m = l & 15, nl = (l >> 4) * 4 + i;
-        float v[NT];
+        const int nl = (l >> 4) * 4 + i;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            float s = 0.f;
+        for (int nb = 0; nb < NB; ++nb) {
+            const int m = (l & 15) + 16 * nb;
+            float v[NT];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) s += red[w][t][tid];
-            v[t] = s;
-        }
-        if (m < B) {
-            if (EPI == EPI_SWIGLU) {
-                const float gt = v[0], up = v[NT - 1];
-                out[(size_t)m * ldo + (n0 >> 1) + nl] = f2bf(gt / (1.f + __expf(-gt)) * up);
-            } else {
-                float o = v[0];
-                if (EPI == EPI_RESIDUAL) o = bf2f(f2bf(o)) + bf2f(R[(size_t)m * ldr + n0 + nl]);
-                out[(size_t)m * ldo + n0 + nl] = f2bf(o);
+            for (int t = 0; t < NT; ++t) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) s += red[w][t * NB + nb][tid];
+                v[t] = s;
+            }
+            if (m < B) {
+                if (EPI == EPI_SWIGLU) {
+                    const float gt = v[0], up = v[NT - 1];
+                    out[(size_t)m * ldo + (n0 >> 1) + nl] = f2bf(gt / (1.f + __expf(-gt)) * up);
+                } else {
+                    float o = v[0];
+                    if (EPI == EPI_RESIDUAL) o = bf2f(f2bf(o)) + bf2f(R[(size_t)m * ldr + n0 + nl]);
+                    out[(size_t)m * ldo + n0 + nl] = f2bf(o);
+                }
             }
         }
     }
@@ -416,12 +364,13 @@ __global__ __launch_bounds__(512) void head_logits_kernel(const bf16_t* __restri
                                                           int H, const int32_t* __restrict__ heads, int V, int Tv, int Sv,
                                                           float* __restrict__ part_val, int32_t* __restrict__ part_idx,
                                                           float* __restrict__ logits_out, int B, int ntiles) {
-    __shared__ float red[8][256];
-    __shared__ float fin[256];
+    __shared__ float red[8][2][256];
+    __shared__ float fin[2][256];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int NV = V + 1 + Tv + Sv;
+    const int NB = B > 16 ? 2 : 1;
     bool any = false;
     for (int b = 0; b < B; ++b) {
         int lo, hi;
@@ -441,36 +390,45 @@ __global__ __launch_bounds__(512) void head_logits_kernel(const bf16_t* __restri
     const int U = H >> 6;
     const int u0 = (wid * U) >> 3, u1 = ((wid + 1) * U) >> 3;
     const bf16_t* wp = Wh + (size_t)(n0 + r) * H + g * 16;
-    const bool xon = r < B;
-    const bf16_t* xp = X + (size_t)(xon ? r : 0) * ldx + g * 16;
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const bool xon0 = r < B, xon1 = r + 16 < B;
+    const bf16_t* xp0 = X + (size_t)(xon0 ? r : 0) * ldx + g * 16;
+    const bf16_t* xp1 = X + (size_t)(xon1 ? r + 16 : 0) * ldx + g * 16;
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     for (int u = u0; u < u1; u += 4) {
-        Frag w[4][2], x[4][2];
+        Frag w[4][2], x0[4][2], x1[4][2];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const bool ok = u + jj < u1;
             const int ko = (u + jj) * 64;
             w[jj][0].u = ok ? ldg_nt(wp + ko) : make_uint4(0, 0, 0, 0);
             w[jj][1].u = ok ? ldg_nt(wp + ko + 8) : make_uint4(0, 0, 0, 0);
-            x[jj][0].u = (ok && xon) ? *reinterpret_cast<const uint4*>(xp + ko) : make_uint4(0, 0, 0, 0);
-            x[jj][1].u = (ok && xon) ? *reinterpret_cast<const uint4*>(xp + ko + 8) : make_uint4(0, 0, 0, 0);
+            x0[jj][0].u = (ok && xon0) ? *reinterpret_cast<const uint4*>(xp0 + ko) : make_uint4(0, 0, 0, 0);
+            x0[jj][1].u = (ok && xon0) ? *reinterpret_cast<const uint4*>(xp0 + ko + 8) : make_uint4(0, 0, 0, 0);
+            x1[jj][0].u = (ok && xon1) ? *reinterpret_cast<const uint4*>(xp1 + ko) : make_uint4(0, 0, 0, 0);
+            x1[jj][1].u = (ok && xon1) ? *reinterpret_cast<const uint4*>(xp1 + ko + 8) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][0].v, x[jj][0].v, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][1].v, x[jj][1].v, acc, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][0].v, x0[jj][0].v, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][1].v, x0[jj][1].v, acc0, 0, 0, 0);
+            if (NB == 2) {
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][0].v, x1[jj][0].v, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][1].v, x1[jj][1].v, acc1, 0, 0, 0);
+            }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) red[wid][i * 64 + lane] = acc[i];
+    for (int i = 0; i < 4; ++i) { red[wid][0][i * 64 + lane] = acc0[i]; red[wid][1][i * 64 + lane] = acc1[i]; }
     __syncthreads();
     if (tid < 256) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) s += red[w][tid];
-        // tid = i*64 + l  ->  m = l&15, n_local = (l>>4)*4 + i ; store as fin[m*16 + n_local]
+        // tid = i*64 + l  ->  m = l&15, n_local = (l>>4)*4 + i ; store as fin[nb][m*16 + n_local]
         const int i = tid >> 6, l = tid & 63;
-        fin[(l & 15) * 16 + (l >> 4) * 4 + i] = s;
+        for (int nb = 0; nb < NB; ++nb) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += red[w][nb][tid];
+            fin[nb][(l & 15) * 16 + (l >> 4) * 4 + i] = s;
+        }
     }
     __syncthreads();
     if (tid < B * 16) {
@@ -478,7 +436,7 @@ __global__ __launch_bounds__(512) void head_logits_kernel(const bf16_t* __restri
         int lo, hi;
         head_bounds(heads[b], V, Tv, Sv, lo, hi);
         const bool ok = n >= lo && n < hi;
-        float v = ok ? fin[b * 16 + nl] : -INFINITY;
+        float v = ok ? fin[b >> 4][(b & 15) * 16 + nl] : -INFINITY;
         if (logits_out && n < NV) logits_out[(size_t)b * NV + n] = v;
         // arg-max over the 16 rows of this tile for sequence b (lowest index wins ties)
         int idx = n;
@@ -559,22 +517,21 @@ __global__ __launch_bounds__(256) void select_next_kernel(const float* __restric
 }  // namespace
 
 int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R, int ldr,
-                       int B, int N, int K, int epi, const bf16_t* gamma, float eps, hipStream_t s) {
-    if (B < 1 || B > 16 || K % 64 || (ldx % 8) || (ldw % 8)) return TRACE_ERR_ARG;
-    if (gamma && K > 4096) return TRACE_ERR_ARG;       // per-wave gamma slice: K/8 <= 2 x 64 lanes x 8 elements
-#define SK(EPI_, NORM_, GRID_) hipLaunchKernelGGL((skinny_gemm_kernel<EPI_, NORM_>), dim3(GRID_), dim3(512), 0, s, X, ldx, W, ldw, out, ldo, R, ldr, B, N, K, gamma, eps)
+                       int B, int N, int K, int epi, hipStream_t s) {
+    if (B < 1 || B > 32 || K % 64 || (ldx % 8) || (ldw % 8)) return TRACE_ERR_ARG;
+#define SK(EPI_, NB_, GRID_) hipLaunchKernelGGL((skinny_gemm_kernel<EPI_, NB_>), dim3(GRID_), dim3(512), 0, s, X, ldx, W, ldw, out, ldo, R, ldr, B, N, K)
     switch (epi) {
         case EPI_NONE:
             if (N % 16) return TRACE_ERR_ARG;
-            if (gamma) SK(EPI_NONE, true, N / 16); else SK(EPI_NONE, false, N / 16);
+            if (B <= 16) SK(EPI_NONE, 1, N / 16); else SK(EPI_NONE, 2, N / 16);
             break;
         case EPI_RESIDUAL:
-            if (N % 16 || !R || gamma) return TRACE_ERR_ARG;
-            SK(EPI_RESIDUAL, false, N / 16);
+            if (N % 16 || !R) return TRACE_ERR_ARG;
+            if (B <= 16) SK(EPI_RESIDUAL, 1, N / 16); else SK(EPI_RESIDUAL, 2, N / 16);
             break;
         case EPI_SWIGLU:
             if (N % 32) return TRACE_ERR_ARG;
-            if (gamma) SK(EPI_SWIGLU, true, N / 32); else SK(EPI_SWIGLU, false, N / 32);
+            if (B <= 16) SK(EPI_SWIGLU, 1, N / 32); else SK(EPI_SWIGLU, 2, N / 32);
             break;
         default: return TRACE_ERR_ARG;
     }
@@ -596,7 +553,7 @@ int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vcach
 
 int launch_head_logits(const bf16_t* X, int ldx, const bf16_t* Wh, int H, const int32_t* heads, int V, int Tv, int Sv,
                        float* part_val, int32_t* part_idx, float* logits_out, int B, hipStream_t s) {
-    if (B < 1 || B > 16 || H % 64) return TRACE_ERR_ARG;
+    if (B < 1 || B > 32 || H % 64) return TRACE_ERR_ARG;
     const int ntiles = (V + 1 + Tv + Sv + 15) / 16;
     hipLaunchKernelGGL(head_logits_kernel, dim3(ntiles), dim3(512), 0, s, X, ldx, Wh, H, heads, V, Tv, Sv, part_val, part_idx,
                        logits_out, B, ntiles);
@@ -606,7 +563,7 @@ int launch_head_logits(const bf16_t* X, int ldx, const bf16_t* Wh, int H, const 
 int launch_select_next(const float* part_val, const int32_t* part_idx, const StepState& st, const bf16_t* embed,
                        const bf16_t* time_tab, const bf16_t* score_tab, const bf16_t* sync_row, bf16_t* xnext, int ldx, int B,
                        int H, int V, int Tv, int Sv, int advance, hipStream_t s) {
-    if (B < 1 || B > 16 || H % 8) return TRACE_ERR_ARG;
+    if (B < 1 || B > 32 || H % 8) return TRACE_ERR_ARG;
     const int ntiles = (V + 1 + Tv + Sv + 15) / 16;
     hipLaunchKernelGGL(select_next_kernel, dim3(1), dim3(256), 0, s, part_val, part_idx, st, embed, time_tab, score_tab,
                        sync_row, xnext, ldx, B, H, V, Tv, Sv, ntiles, advance);

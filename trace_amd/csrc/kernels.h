@@ -70,10 +70,9 @@ int launch_rope_kv(bf16_t* qkv, int ld, bf16_t* kcache, bf16_t* vcache, long slo
                    const float* cos_t, const float* sin_t, hipStream_t s);
 
 // ---- decode (decode.hip) ----
-// out[b, n] = sum_k X'[b,k] W[n,k]  (B <= 16) (+ residual / SwiGLU on interleaved W); gamma != null fuses
-// X' = bf16(RMSNorm(X) * gamma) (eps), else X' = X
+// out[b, n] = sum_k X[b,k] W[n,k]  (B <= 32) (+ residual / SwiGLU on interleaved W)
 int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R,
-                       int ldr, int B, int N, int K, int epi, const bf16_t* gamma, float eps, hipStream_t s);
+                       int ldr, int B, int N, int K, int epi, hipStream_t s);
 // single-query GQA attention over the cache (context = pos[b] + 1 rows, split nsplit ways, <= 128 rows per split).
 // fuse_rope = 1: `qkv` rows are the raw [q | k | v] projections of the new token: q and the new k are rotated here
 // (RoPE at pos[b]) and k/v appended to the cache at row pos[b].  fuse_rope = 0: `qkv` holds ready q rows (ld ldq)

@@ -259,13 +259,13 @@ class ops:
         return o
 
     @staticmethod
-    def skinny_gemm(X, W, R=None, epilogue=EPI_NONE, gamma=None, eps=0.0):
+    def skinny_gemm(X, W, R=None, epilogue=EPI_NONE):
         lib = _lib.load()
         Bn, K = X.shape
         N = W.shape[0]
         No = N // 2 if epilogue == EPI_SWIGLU else N
         out = torch.empty((Bn, No), dtype=torch.bfloat16, device=X.device)
-        _lib.check(lib.trace_op_skinny_gemm(_ptr(X), _ptr(W), _ptr(out), _ptr(R), Bn, N, K, epilogue, _ptr(gamma), eps, _stream()))
+        _lib.check(lib.trace_op_skinny_gemm(_ptr(X), _ptr(W), _ptr(out), _ptr(R), Bn, N, K, epilogue, _stream()))
         return out
 
     @staticmethod

@@ -34,7 +34,7 @@ typedef struct trace_config {
     float slot_eps, slot_rope_base;
     int32_t max_frames;      /* largest T per video                                    */
     int32_t max_ctx;         /* KV-cache length per sequence slot (prefill + new tokens) */
-    int32_t max_batch;       /* sequence slots (videos decoded together), <= 32          */
+    int32_t max_batch;       /* KV-cache sequence slots, <= 64 (at most 32 decode together) */
     int32_t max_new_tokens;  /* capacity of the on-device output id buffer               */
 } trace_config;
 

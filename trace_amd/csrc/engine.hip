@@ -61,7 +61,7 @@ struct trace_ctx {
     float* part_val; int32_t* part_idx;
     int32_t *d_slots, *d_pos, *d_heads, *d_done, *d_out_ids, *d_out_len, *d_step, *d_forced, *d_params;
     int B = 0, max_new = 0, eos = -1, has_forced = 0, ntiles = 0, nsplit = 32;
-    int slot_len[32] = {0};
+    int slot_len[64] = {0};
     int host_mode = 0, fed = 0;        // host-driven token selection (sampling): head logits only, ids fed back by the host
     hipGraphExec_t graphs[33] = {nullptr};
     hipStream_t cap_stream = nullptr;
@@ -114,7 +114,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     if (c->vh / c->vheads != 64) return bad("ViT kernels need head_dim 64");
     if (c->H % 128 || c->I % 128 || c->vh % 128 || c->vi % 128 || c->QKV % 128) return bad("dims must be multiples of 128");
     if (c->S != 8 || c->vh > 1024) return bad("slot pool kernel needs 8 slots and mm_hidden <= 1024");
-    if (c->max_B < 1 || c->max_B > 32) return bad("max_batch must be in [1,32]");
+    if (c->max_B < 1 || c->max_B > 64) return bad("max_batch (KV slots) must be in [1,64]");
     c->nsplit = 32;                                           // upper bound (workspace size); per-batch value below
     if (cfg->max_frames < 1 || cfg->max_frames * c->TPF > c->max_ctx) return bad("max_frames*14 exceeds max_ctx");
     if (c->Tv != 13 || c->Sv != 13) { /* any size works; kept for clarity */ }
@@ -158,7 +158,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     A(c->d_kind, Lm); A(c->d_row, Lm);
     // --- decode ---
     A(c->dX, 32 * H); A(c->dH, 32 * H); A(c->dQKV, 32 * (size_t)c->QKV); A(c->dO, 32 * H); A(c->dACT, 32 * I);
-    A(c->xlast, 32 * H);
+    A(c->xlast, 64 * H);
     A(c->attn_ws, (size_t)32 * c->NQ * c->nsplit * (c->HD + 2)); A(c->tickets, 32 * c->NKV);
     c->ntiles = c->NVpad / 16;
     A(c->part_val, (size_t)32 * c->ntiles); A(c->part_idx, (size_t)32 * c->ntiles);
@@ -574,7 +574,7 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
 extern "C" int trace_decode_begin(trace_ctx* c, const int32_t* slots, int B, const int32_t* heads, int max_new, int eos,
                                   const int32_t* forced, float* logits_out, void* stream) {
     if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
-    if (!slots || !heads || B < 1 || B > c->max_B) return fail(TRACE_ERR_ARG, "bad batch");
+    if (!slots || !heads || B < 1 || B > c->max_B || B > 32) return fail(TRACE_ERR_ARG, "bad batch (at most 32 sequences decode together)");
     if (max_new < 1 || max_new > c->c.max_new_tokens) return fail(TRACE_ERR_ARG, "max_new exceeds capacity");
     hipStream_t s = (hipStream_t)stream;
     int32_t pos[32], zero[32] = {0};

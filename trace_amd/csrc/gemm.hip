@@ -23,7 +23,12 @@ __device__ __forceinline__ int swz(int row, int kc) { return row * 128 + ((kc ^ 
 // the read side).  One barrier per K-tile: tile kt+1 streams into the other buffer while tile kt feeds the MFMAs.
 // Tile order: XCD-contiguous, then grouped (8 row panels x all column panels) so the ~32 workgroups resident on
 // one XCD share A row-panels and W column-panels through that XCD's L2.
-template <int BM, int BN, int WM, int WN, int EPI>
+// DEEP = true: the streamed activation operand A is triple-buffered and prefetched TWO K-tiles ahead (it comes from
+// HBM / Infinity Cache), the weight operand W (L2-resident, shared by every workgroup of a column panel) stays
+// double-buffered one tile ahead.  The loads are issued W(kt+1) first, A(kt+2) second, so a counted
+// `s_waitcnt vmcnt(A_IT)` retires everything except the youngest A tile, and a raw s_barrier (not
+// __syncthreads, which would drain vmcnt to 0) publishes the tile: A(kt+2) stays in flight across the barrier.
+template <int BM, int BN, int WM, int WN, int EPI, bool DEEP>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     constexpr int NW = WM * WN, NTHR = NW * 64;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -62,17 +67,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
         const int slot = i * NTHR + tid, row = slot >> 3, kc = (slot & 7) ^ ((row >> 1) & 7);
         wsrc[i] = p.W + (size_t)(n0 + row) * p.ldw + kc * 8;
     }
-    auto issue = [&](int kt, int buf) {
-        char* sa = smem + buf * STAGE;
+    constexpr int NA = DEEP ? 3 : 2;                       // A stages
+    constexpr int W_BASE = DEEP ? NA * A_BYTES : 0;        // DEEP: [A0 A1 A2 | W0 W1]; else [A0 W0 | A1 W1]
+    auto a_stage = [&](int i) -> char* { return smem + (DEEP ? i * A_BYTES : i * STAGE); };
+    auto w_stage = [&](int i) -> char* { return smem + (DEEP ? W_BASE + i * W_BYTES : i * STAGE + A_BYTES); };
+    auto issue_a = [&](int kt) {
+        char* sa = a_stage(kt % NA);
         const int ko = kt * BK;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + ko),
                                              (__attribute__((address_space(3))) void*)(sa + (i * NTHR + wid * 64) * 16), 16, 0, 0);
+    };
+    auto issue_w = [&](int kt) {
+        char* sw = w_stage(kt & 1);
+        const int ko = kt * BK;
 #pragma unroll
         for (int i = 0; i < W_IT; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + ko),
-                                             (__attribute__((address_space(3))) void*)(sa + A_BYTES + (i * NTHR + wid * 64) * 16), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sw + (i * NTHR + wid * 64) * 16), 16, 0, 0);
     };
 
     f32x4_t acc[TM][TN];
@@ -87,12 +100,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     for (int j = 0; j < TN; ++j) woff[j] = swz(wn * (BN / WN) + j * 16 + r, g);
 
     const int nk = p.K / BK;
-    issue(0, 0);
+    if (DEEP) {
+        issue_a(0); issue_w(0);
+        if (nk > 1) issue_a(1);
+    } else {
+        issue_a(0); issue_w(0);
+    }
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                       // tile kt landed (vmcnt(0) + barrier); everyone is done with tile kt-1
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const char* sa = smem + (kt & 1) * STAGE;
-        const char* sw = sa + A_BYTES;
+        if (DEEP) {
+            // outstanding, oldest first: ... W(kt), A(kt+1)  ->  keep only A(kt+1) (A_IT loads) in flight
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // tile kt landed for every wave; tile kt-1 fully consumed
+            if (kt + 1 < nk) issue_w(kt + 1);
+            if (kt + 2 < nk) issue_a(kt + 2);
+        } else {
+            __syncthreads();                               // tile kt landed (vmcnt(0) + barrier); everyone is done with tile kt-1
+            if (kt + 1 < nk) { issue_a(kt + 1); issue_w(kt + 1); }
+        }
+        const char* sa = a_stage(kt % NA);
+        const char* sw = w_stage(kt & 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8_t af[TM], wf[TN];
@@ -108,7 +135,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
         }
     }
     __syncthreads();
-    // ---- epilogue (same scheme as v1): fp32 bias/activation -> bf16 -> LDS rows -> 16-byte stores ----
+    // ---- epilogue: fp32 bias/activation -> bf16 -> LDS rows -> 16-byte stores ----
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mrow = wm * (BM / WM) + i * 16 + r;
@@ -160,26 +187,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool DEEP>
 int launch_glds(const GemmArgs& p, int epi, hipStream_t s) {
     constexpr int STAGE = (BM + BN) * 128;
+    constexpr int LOOPB = DEEP ? (3 * BM + 2 * BN) * 128 : 2 * STAGE;
     constexpr int OBYTES = BM * (BN * 2 + 16);
-    constexpr size_t lds = (2 * STAGE > OBYTES) ? 2 * STAGE : OBYTES;
+    constexpr size_t lds = (LOOPB > OBYTES) ? LOOPB : OBYTES;
     constexpr int NTHR = WM * WN * 64;
     const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_RESIDUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_QUICKGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_SWIGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_NONE, DEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_RESIDUAL, DEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_QUICKGELU, DEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_SWIGLU, DEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     switch (epi) {
-        case EPI_NONE: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_NONE>), dim3(nblk), dim3(NTHR), lds, s, p); break;
-        case EPI_RESIDUAL: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_RESIDUAL>), dim3(nblk), dim3(NTHR), lds, s, p); break;
-        case EPI_QUICKGELU: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_QUICKGELU>), dim3(nblk), dim3(NTHR), lds, s, p); break;
-        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_SWIGLU>), dim3(nblk), dim3(NTHR), lds, s, p); break;
+        case EPI_NONE: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_NONE, DEEP>), dim3(nblk), dim3(NTHR), lds, s, p); break;
+        case EPI_RESIDUAL: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_RESIDUAL, DEEP>), dim3(nblk), dim3(NTHR), lds, s, p); break;
+        case EPI_QUICKGELU: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_QUICKGELU, DEEP>), dim3(nblk), dim3(NTHR), lds, s, p); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_SWIGLU, DEEP>), dim3(nblk), dim3(NTHR), lds, s, p); break;
         default: return TRACE_ERR_ARG;
     }
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
@@ -187,7 +215,7 @@ int launch_glds(const GemmArgs& p, int epi, hipStream_t s) {
 
 }  // namespace
 
-int g_gemm_variant = 0;   // 0 = auto, 2 = 128^2 tiles, 3 = 256^2 tiles (tests / microbench)
+int g_gemm_variant = 0;   // 0 = auto, 2 = 128^2, 3 = 256^2, 4 = 256^2 deep prefetch, 5 = 128^2 deep prefetch (tests / microbench)
 
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
     if (p.M <= 0 || p.N % BN || p.K % BK || p.K < BK) return TRACE_ERR_ARG;
@@ -199,8 +227,9 @@ int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
             const long blocks256 = (long)((p.M + 255) / 256) * (p.N / 256);
             v = (p.N % 256 == 0 && p.M >= 1024 && blocks256 >= 200) ? 3 : 2;
         }
-        if (v == 3 && p.N % 256 == 0) return launch_glds<256, 256, 2, 4>(p, epi, s);
-        if (v == 2) return launch_glds<128, 128, 2, 2>(p, epi, s);
+        if (v == 4 && p.N % 256 == 0) return launch_glds<256, 256, 2, 4, true>(p, epi, s);
+        if (v == 3 && p.N % 256 == 0) return launch_glds<256, 256, 2, 4, false>(p, epi, s);
+        if (v == 5) return launch_glds<128, 128, 2, 2, true>(p, epi, s);
     }
-    return launch_glds<128, 128, 2, 2>(p, epi, s);
+    return launch_glds<128, 128, 2, 2, false>(p, epi, s);
 }

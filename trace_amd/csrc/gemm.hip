@@ -68,6 +68,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
         wsrc[i] = p.W + (size_t)(n0 + row) * p.ldw + kc * 8;
     }
     constexpr int NA = DEEP ? 3 : 2;                       // A stages
+    // SPREAD: issue the next tile's LDS-DMA pieces between the MFMA groups (pays on the 8-wave 256^2 tile: +3..5 %;
+    // on the 4-wave 128^2 tile with 2-3 workgroups per CU it measured -19 %, so that one issues them up front)
+    constexpr bool SPREAD = (BM == 256) && !DEEP;
     constexpr int W_BASE = DEEP ? NA * A_BYTES : 0;        // DEEP: [A0 A1 A2 | W0 W1]; else [A0 W0 | A1 W1]
     auto a_stage = [&](int i) -> char* { return smem + (DEEP ? i * A_BYTES : i * STAGE); };
     auto w_stage = [&](int i) -> char* { return smem + (DEEP ? W_BASE + i * W_BYTES : i * STAGE + A_BYTES); };
@@ -78,6 +81,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
         for (int i = 0; i < A_IT; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + ko),
                                              (__attribute__((address_space(3))) void*)(sa + (i * NTHR + wid * 64) * 16), 16, 0, 0);
+    };
+    // one 1-KiB-per-wave piece of tile kt (pieces 0..A_IT-1 = A, A_IT.. = W); issued BETWEEN MFMA groups so the
+    // ~100-cycle issue cost of each LDS-DMA hides under the matrix pipe instead of delaying the first MFMA of the tile
+    auto issue_piece = [&](int kt, int piece) {
+        const int ko = kt * BK;
+        if (piece < A_IT) {
+            char* sa = a_stage(kt % NA);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[piece] + ko),
+                                             (__attribute__((address_space(3))) void*)(sa + (piece * NTHR + wid * 64) * 16), 16, 0, 0);
+        } else {
+            const int i = piece - A_IT;
+            char* sw = w_stage(kt & 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + ko),
+                                             (__attribute__((address_space(3))) void*)(sw + (i * NTHR + wid * 64) * 16), 16, 0, 0);
+        }
     };
     auto issue_w = [&](int kt) {
         char* sw = w_stage(kt & 1);
@@ -116,22 +134,42 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
             if (kt + 2 < nk) issue_a(kt + 2);
         } else {
             __syncthreads();                               // tile kt landed (vmcnt(0) + barrier); everyone is done with tile kt-1
-            if (kt + 1 < nk) { issue_a(kt + 1); issue_w(kt + 1); }
+            if (!SPREAD && kt + 1 < nk) { issue_a(kt + 1); issue_w(kt + 1); }
         }
+        const bool more = SPREAD && !DEEP && kt + 1 < nk;
         const char* sa = a_stage(kt % NA);
         const char* sw = w_stage(kt & 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t af[TM], wf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[i] ^ (ks << 6)));
+            // fragment reads run one pair of m-tiles AHEAD of the MFMAs that consume them (register double buffer),
+            // pinned with sched_group_barrier so the LDS latency of pair p+1 hides under the 2*TN MFMAs of pair p
+            bf16x8_t wf[TN], ac[2], an[2];
 #pragma unroll
             for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(sw + (woff[j] ^ (ks << 6)));
+            ac[0] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[0] ^ (ks << 6)));
+            ac[1] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[1] ^ (ks << 6)));
+            __builtin_amdgcn_sched_group_barrier(0x100, TN + 2, 0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int ip = 0; ip < TM / 2; ++ip) {
+                if (ip + 1 < TM / 2) {
+                    an[0] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[2 * ip + 2] ^ (ks << 6)));
+                    an[1] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[2 * ip + 3] ^ (ks << 6)));
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[2 * ip + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], ac[ii], acc[2 * ip + ii][j], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);
+                if (more) {
+                    constexpr int PPG = (A_IT + W_IT) / TM;            // pieces per MFMA group
+#pragma unroll
+                    for (int q = 0; q < PPG; ++q) issue_piece(kt + 1, (ks * (TM / 2) + ip) * PPG + q);
+                    __builtin_amdgcn_sched_group_barrier(0x020, PPG, 0);
+                }
+                if (ip + 1 < TM / 2) { ac[0] = an[0]; ac[1] = an[1]; }
+            }
         }
     }
     __syncthreads();

@@ -27,12 +27,12 @@ union Frag { uint4 u; bf16x8_t v; };
 // ---------------------------------------------------------------------------------------------------------
 // NB = number of 16-row activation groups (1: B <= 16, 2: B <= 32): the weight fragment is reused for both.
 template <int EPI, int NB>
-__global__ __launch_bounds__(512, NB == 1 ? 4 : 2) void skinny_gemm_kernel(const bf16_t* __restrict__ X, int ldx,
+__global__ __launch_bounds__(512, 4) void skinny_gemm_kernel(const bf16_t* __restrict__ X, int ldx,
                                                                             const bf16_t* __restrict__ W, int ldw,
                                                                             bf16_t* __restrict__ out, int ldo,
                                                                             const bf16_t* __restrict__ R, int ldr, int B, int N, int K) {
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;      // 16-row weight tiles per workgroup
-    constexpr int UN = 2;                                // 64-wide k units per batch (4 x 16 B per lane per tile)
+    constexpr int UN = NB == 1 ? 2 : 1;                  // 64-wide k units per load batch (keeps <= 128 VGPRs: 2 workgroups/CU)
     __shared__ float red[8][NT * NB][256];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 15, g = lane >> 4;

@@ -148,14 +148,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, S[st][r]);
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             const float mnew = fmaxf(m, mloc * sc);           // running max in the scaled (base-2) domain
-            const float alpha = exp2f(m - mnew);
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
             m = mnew;
             float lsum = 0.f;
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = exp2f(fmaf(S[st][r], sc, -mnew));
+                    const float p = __builtin_amdgcn_exp2f(fmaf(S[st][r], sc, -mnew));   // raw v_exp_f32 (exp2f() adds a denormal-range fix-up: 5 ops)
                     lsum += p;
                     S[st][r] = p;
                 }

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
                 for (int q = 0; q < 4; ++q) {
                     float x = acc[i][j][q];
                     if (p.bias) x += bf2f(p.bias[n0 + nl + q]);
-                    if (EPI == EPI_QUICKGELU) x = x / (1.f + __expf(-1.702f * x));
+                    if (EPI == EPI_QUICKGELU) x = x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x));   // x*sigmoid(1.702x)
                     v[q] = x;
                 }
                 *reinterpret_cast<uint2*>(smem + mrow * OSTRIDE + nl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float gt = acc[i][2 * jj][q], up = acc[i][2 * jj + 1][q];
-                    v[q] = gt / (1.f + __expf(-gt)) * up;
+                    v[q] = gt * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gt)) * up;   // silu(g)*u
                 }
                 *reinterpret_cast<uint2*>(smem + mrow * OSTRIDE + nl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
             }

@@ -101,7 +101,7 @@ def main():
 
     def step():
         out, _ = eng.generate(videos, ts, prompt, heads, n_new, eos=-1, use_graph=args.graph)
-        if world > 1:
+        if world > 1 or torch.distributed.is_initialized():
             tdist.gather_outputs(out, n_new, B, dev)
         return out
 
@@ -173,7 +173,7 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     eng.close()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

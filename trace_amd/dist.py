@@ -19,7 +19,8 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("TRACE_FORCE_PG") == "1"      # exercise the RCCL path with a single rank (tests)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -52,7 +53,7 @@ def unpack_ids(packed: torch.Tensor) -> List[List[int]]:
 def gather_outputs(local_ids: Sequence[Sequence[int]], max_new: int, per_rank: int, device=None) -> List[List[List[int]]]:
     """All-gather of the packed ids; returns [world][per_rank] id lists (ranks with fewer videos pad with empties)."""
     packed = pack_ids(list(local_ids) + [[]] * (per_rank - len(local_ids)), max_new)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [unpack_ids(packed)]
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")

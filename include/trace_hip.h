@@ -102,7 +102,7 @@ int trace_get_profile(trace_ctx* ctx, float* out, int n);
 /* ---- kernel-level entry points (unit tests / microbenchmarks; raw device pointers) ---- */
 int trace_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* R,
                   int ldr, int M, int N, int K, int epilogue, void* stream);
-/* GEMM kernel selection for tests/microbenchmarks: 0 auto, 2 = 128^2 tiles, 3 = 256^2 tiles, 4 = persistent 256^2. */
+/* GEMM tile selection for tests/microbenchmarks: 0 auto, 2 = 128^2 tiles, 3 = 256^2 tiles. */
 int trace_op_set_gemm_variant(int variant);
 int trace_op_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, float eps, void* stream);
 int trace_op_rmsnorm(const void* x, void* y, const void* w, int rows, int D, float eps, void* stream);

@@ -40,7 +40,7 @@ def check(name, got, ref, atol, rtol):
         pytest.fail(msg)
 
 
-@pytest.fixture(params=[0, 2, 3, 4], ids=["auto", "tile128", "tile256", "persist256"])
+@pytest.fixture(params=[0, 2, 3], ids=["auto", "tile128", "tile256"])
 def gemm_variant(request):
     ops.set_gemm_variant(request.param)
     yield request.param

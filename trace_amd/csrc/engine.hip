@@ -705,7 +705,7 @@ extern int g_gemm_variant;
 extern int g_attn_debug;
 extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 100 && variant < 104) { g_attn_debug = variant - 100; return TRACE_OK; }   // microbench: attention phase cut-offs
-    if (variant < 0 || variant > 4) return fail(TRACE_ERR_ARG, "variant must be 0..4");
+    if (variant < 0 || variant > 3) return fail(TRACE_ERR_ARG, "variant must be 0..3");
     g_gemm_variant = variant;
     return TRACE_OK;
 }

@@ -23,8 +23,11 @@ __device__ __forceinline__ int swz(int row, int kc) { return row * 128 + ((kc ^ 
 // the read side).  One barrier per K-tile: tile kt+1 streams into the other buffer while tile kt feeds the MFMAs.
 // Tile order: XCD-contiguous, then grouped (8 row panels x all column panels) so the ~32 workgroups resident on
 // one XCD share A row-panels and W column-panels through that XCD's L2.
-// (A deeper pipeline — A triple-buffered two tiles ahead with counted vmcnt + raw s_barrier — was measured and gave
-// nothing: the loop is not load-latency bound.  What costs is the per-tile fixed part, see gemm_persist_kernel.)
+// Measured dead ends (kept out of the code): (1) a deeper pipeline — A triple-buffered two tiles ahead with counted
+// vmcnt + raw s_barrier — gave nothing: the loop is not load-latency bound; (2) a persistent one-workgroup-per-CU
+// version that prefetches the next output tile's first K-tile under a two-half epilogue was 5-15 % SLOWER on the
+// K = 1024 ViT shapes than letting the dispatcher place fresh workgroups (static tile assignment + two extra
+// epilogue barriers cost more than the hidden prologue).  Per-tile fixed cost is ~13 us vs ~1.6 us per K-tile.
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     constexpr int NW = WM * WN, NTHR = NW * 64;
@@ -207,216 +210,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
 }
 
 
-// =========================================================================================================
-// Persistent 256x256x64 kernel for the short-K (K = 1024) ViT projections, where the per-tile fixed cost (dispatch
-// of a 136-KB-LDS workgroup, first-tile load latency, epilogue) is ~1/3 of a tile: one workgroup per CU walks the
-// tiles of its XCD, the first K-tile of the NEXT output tile streams into the idle LDS stage while the epilogue
-// of the current one runs, and epilogue barriers wait on LDS only (raw s_barrier + lgkmcnt), so neither that
-// prefetch nor the tile's own global stores are drained.  LDS: [stage0 64K | spare 32K | stage1 64K]; the epilogue
-// staging window is the just-consumed stage plus the spare (96 KB contiguous either way), used in two 128-row halves.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p) {
-    constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NTHR = 512;
-    constexpr int TM = 8, TN = 4, A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES, SPARE = 32768;
-    constexpr int A_IT = 4, W_IT = 4;
-    constexpr bool GLU = (EPI == EPI_SWIGLU);
-    constexpr int OSTRIDE = BN * 2 + 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r = lane & 15, g = lane >> 4;
-    const int wm = wid / WN, wn = wid % WN;
-    const int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM, nblk = ntm * ntn;
-    // tiles of this workgroup: XCD-contiguous logical range (as xcd_remap), strided by the workgroups per XCD
-    const int xcd = blockIdx.x & 7, idx0 = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-    const int q8 = nblk >> 3, r8 = nblk & 7;
-    const int xbase = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int xcount = q8 + (xcd < r8 ? 1 : 0);
-
-    auto stage = [&](int i) -> char* { return smem + (i ? STAGE + SPARE : 0); };
-    const bf16_t* asrc[A_IT];
-    const bf16_t* wsrc[W_IT];
-    int m0 = 0, n0 = 0;
-    auto setup = [&](int local, int& om0, int& on0) {
-        const int t = xbase + local;
-        constexpr int GM = 8;
-        const int per_group = GM * ntn;
-        const int gid = t / per_group, first = gid * GM;
-        const int gsz = min(ntm - first, GM);
-        const int in_g = t - gid * per_group;
-        om0 = (first + in_g % gsz) * BM;
-        on0 = (in_g / gsz) * BN;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int slot = i * NTHR + tid, row = slot >> 3, kc = (slot & 7) ^ ((row >> 1) & 7);
-            asrc[i] = p.A + (size_t)min(om0 + row, p.M - 1) * p.lda + kc * 8;
-        }
-#pragma unroll
-        for (int i = 0; i < W_IT; ++i) {
-            const int slot = i * NTHR + tid, row = slot >> 3, kc = (slot & 7) ^ ((row >> 1) & 7);
-            wsrc[i] = p.W + (size_t)(on0 + row) * p.ldw + kc * 8;
-        }
-    };
-    auto issue_piece = [&](int kt, int piece, int st) {
-        const int ko = kt * BK;
-        char* sb = stage(st);
-        if (piece < A_IT)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[piece] + ko),
-                                             (__attribute__((address_space(3))) void*)(sb + (piece * NTHR + wid * 64) * 16), 16, 0, 0);
-        else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[piece - A_IT] + ko),
-                                             (__attribute__((address_space(3))) void*)(sb + A_BYTES + ((piece - A_IT) * NTHR + wid * 64) * 16), 16, 0, 0);
-    };
-    int aoff[TM], woff[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) aoff[i] = swz(wm * (BM / WM) + i * 16 + r, g);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) woff[j] = swz(wn * (BN / WN) + j * 16 + r, g);
-
-    const int nk = p.K / BK;
-    int gi = 0;                                            // global K-tile counter -> LDS stage parity
-    int local = idx0;
-    if (local >= xcount) return;
-    setup(local, m0, n0);
-#pragma unroll
-    for (int pc = 0; pc < A_IT + W_IT; ++pc) issue_piece(0, pc, 0);
-
-    while (true) {
-        f32x4_t acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; ++kt, ++gi) {
-            __syncthreads();                               // K-tile landed (vmcnt(0)); previous stage / staging reads done
-            const bool more = kt + 1 < nk;
-            const char* sa = stage(gi & 1);
-            const char* sw = sa + A_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8_t wf[TN], ac[2], an[2];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(sw + (woff[j] ^ (ks << 6)));
-                ac[0] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[0] ^ (ks << 6)));
-                ac[1] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[1] ^ (ks << 6)));
-                __builtin_amdgcn_sched_group_barrier(0x100, TN + 2, 0);
-#pragma unroll
-                for (int ip = 0; ip < TM / 2; ++ip) {
-                    if (ip + 1 < TM / 2) {
-                        an[0] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[2 * ip + 2] ^ (ks << 6)));
-                        an[1] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[2 * ip + 3] ^ (ks << 6)));
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    }
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[2 * ip + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], ac[ii], acc[2 * ip + ii][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);
-                    if (more) {
-                        issue_piece(kt + 1, ks * (TM / 2) + ip, (gi + 1) & 1);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    }
-                    if (ip + 1 < TM / 2) { ac[0] = an[0]; ac[1] = an[1]; }
-                }
-            }
-        }
-        // ---- tile done.  consumed stage = (gi-1)&1, idle stage = gi&1: start the next tile's first K-tile there ----
-        const int cm0 = m0, cn0 = n0;
-        local += per_xcd;
-        const bool have_next = local < xcount;
-        // the idle stage was consumed one K-tile ago and every wave has crossed a __syncthreads since -> overwrite now
-        if (have_next) {
-            setup(local, m0, n0);
-#pragma unroll
-            for (int pc = 0; pc < A_IT + W_IT; ++pc) issue_piece(0, pc, gi & 1);
-        }
-        char* stg = smem + (((gi - 1) & 1) ? STAGE : 0);  // 96 KB window: consumed stage + spare
-        constexpr int OUTW = GLU ? BN / 2 : BN;
-        constexpr int CPR = OUTW / 8;
-        const int on0 = GLU ? cn0 / 2 : cn0;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            // all waves must have finished reading the consumed stage (half 0) / the staging rows (half 1)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (wm == half) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int mrow = i * 16 + r;           // row within this 128-row half
-                    if (!GLU) {
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            const int nl = wn * (BN / WN) + j * 16 + g * 4;
-                            float v[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                float x = acc[i][j][q];
-                                if (p.bias) x += bf2f(p.bias[cn0 + nl + q]);
-                                if (EPI == EPI_QUICKGELU) x = x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x));
-                                v[q] = x;
-                            }
-                            *reinterpret_cast<uint2*>(stg + mrow * OSTRIDE + nl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-                        }
-                    } else {
-#pragma unroll
-                        for (int jj = 0; jj < TN / 2; ++jj) {
-                            const int nl = wn * (BN / WN / 2) + jj * 16 + g * 4;
-                            float v[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float gt = acc[i][2 * jj][q], up = acc[i][2 * jj + 1][q];
-                                v[q] = gt * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gt)) * up;
-                            }
-                            *reinterpret_cast<uint2*>(stg + mrow * OSTRIDE + nl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-                        }
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            for (int c = tid; c < (BM / 2) * CPR; c += NTHR) {
-                const int row = c / CPR, ch = c - row * CPR;
-                const int m = cm0 + half * (BM / 2) + row;
-                if (m >= p.M) continue;
-                uint4 v = *reinterpret_cast<const uint4*>(stg + row * OSTRIDE + ch * 16);
-                if (EPI == EPI_RESIDUAL) {
-                    const uint4 rr = *reinterpret_cast<const uint4*>(p.R + (size_t)m * p.ldr + on0 + ch * 8);
-                    v.x = pack2bf(bflo(v.x) + bflo(rr.x), bfhi(v.x) + bfhi(rr.x));
-                    v.y = pack2bf(bflo(v.y) + bflo(rr.y), bfhi(v.y) + bfhi(rr.y));
-                    v.z = pack2bf(bflo(v.z) + bflo(rr.z), bfhi(v.z) + bfhi(rr.z));
-                    v.w = pack2bf(bflo(v.w) + bflo(rr.w), bfhi(v.w) + bfhi(rr.w));
-                }
-                *reinterpret_cast<uint4*>(p.C + (size_t)m * p.ldc + on0 + ch * 8) = v;
-            }
-        }
-        if (!have_next) break;
-    }
-}
-
-int launch_persist(const GemmArgs& p, int epi, hipStream_t s) {
-    constexpr size_t lds = 2 * (256 + 256) * 128 + 32768;          // 160 KiB
-    const int nblk = ((p.M + 255) / 256) * (p.N / 256);
-    int grid = 256;
-    if (nblk < grid) grid = nblk & ~7;
-    if (grid < 8) return TRACE_ERR_ARG;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_persist_kernel<EPI_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_persist_kernel<EPI_RESIDUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_persist_kernel<EPI_QUICKGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_persist_kernel<EPI_SWIGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    switch (epi) {
-        case EPI_NONE: hipLaunchKernelGGL(gemm_persist_kernel<EPI_NONE>, dim3(grid), dim3(512), lds, s, p); break;
-        case EPI_RESIDUAL: hipLaunchKernelGGL(gemm_persist_kernel<EPI_RESIDUAL>, dim3(grid), dim3(512), lds, s, p); break;
-        case EPI_QUICKGELU: hipLaunchKernelGGL(gemm_persist_kernel<EPI_QUICKGELU>, dim3(grid), dim3(512), lds, s, p); break;
-        case EPI_SWIGLU: hipLaunchKernelGGL(gemm_persist_kernel<EPI_SWIGLU>, dim3(grid), dim3(512), lds, s, p); break;
-        default: return TRACE_ERR_ARG;
-    }
-    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
-}
-
 template <int BM, int BN, int WM, int WN>
 int launch_glds(const GemmArgs& p, int epi, hipStream_t s) {
     constexpr int STAGE = (BM + BN) * 128;
@@ -445,7 +238,7 @@ int launch_glds(const GemmArgs& p, int epi, hipStream_t s) {
 
 }  // namespace
 
-int g_gemm_variant = 0;   // 0 = auto, 2 = 128^2, 3 = 256^2, 4 = 256^2 persistent (tests / microbench)
+int g_gemm_variant = 0;   // 0 = auto, 2 = 128^2 tiles, 3 = 256^2 tiles (tests / microbench)
 
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
     if (p.M <= 0 || p.N % BN || p.K % BK || p.K < BK) return TRACE_ERR_ARG;
@@ -457,7 +250,6 @@ int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
             const long blocks256 = (long)((p.M + 255) / 256) * (p.N / 256);
             v = (p.N % 256 == 0 && p.M >= 1024 && blocks256 >= 200) ? 3 : 2;
         }
-        if (v == 4 && p.N % 256 == 0) return launch_persist(p, epi, s);
         if (v == 3 && p.N % 256 == 0) return launch_glds<256, 256, 2, 4>(p, epi, s);
     }
     return launch_glds<128, 128, 2, 2>(p, epi, s);

@@ -143,6 +143,8 @@ def main():
                 traffic = json.load(open(tf)).get("skinny_gateup_bytes_per_launch")
             except Exception:
                 traffic = None
+        g_ms, g_n, g_gf = prof[5], int(prof[6]), prof[7]
+        g_tf = (g_gf / g_ms) if g_ms > 0 else None             # GFLOP / ms = TFLOP/s
         line = {
             "metric": "videos/sec + decode tok/s, TRACE-7B 128-frame, 1/2/4/8 MI355X",
             "value": vps, "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -162,6 +164,9 @@ def main():
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
                          "traffic": traffic, "algorithmic_bytes_per_launch": k_bytes, "avg_launch_ms": k_ms, "samples": k_n},
         }
+        line["roofline_mfma"] = {"bound": "mfma", "kernel": "gemm_glds_kernel<256,256,EPI_QUICKGELU> (ViT fc1, 1 bracketed launch per video)",
+                                 "achieved": g_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": (g_tf / 2500.0) if g_tf else None,
+                                 "algorithmic_gflop_per_launch": g_gf, "avg_launch_ms": g_ms, "samples": g_n, "traffic": None}
         if not args.no_cpu_baseline and not args.tiny:
             try:
                 cores = len(os.sched_getaffinity(0))

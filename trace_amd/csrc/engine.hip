@@ -72,6 +72,8 @@ struct trace_ctx {
     int kev_used = 0;
     hipEvent_t gev0 = nullptr, gev1 = nullptr;   // pair recorded from inside the captured graph
     double ksum_ms = 0.0; int ksamples = 0;
+    hipEvent_t mev0 = nullptr, mev1 = nullptr;   // bracket of one ViT fc1 GEMM launch per trace_vit_forward (profile == 2)
+    double msum_ms = 0.0; int msamples = 0; double mflops = 0.0;
     float prof[8] = {0};
 };
 
@@ -171,6 +173,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking);
     hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
     hipEventCreate(&c->gev0); hipEventCreate(&c->gev1);
+    hipEventCreate(&c->mev0); hipEventCreate(&c->mev1);
     c->kev.resize(1024);
     for (auto& e : c->kev) hipEventCreate(&e);
     *out = c;
@@ -182,6 +185,8 @@ extern "C" int trace_ctx_destroy(trace_ctx* c) {
     hipDeviceSynchronize();
     for (auto& g : c->graphs) if (g) hipGraphExecDestroy(g);
     for (auto& e : c->kev) if (e) hipEventDestroy(e);
+    if (c->mev0) hipEventDestroy(c->mev0);
+    if (c->mev1) hipEventDestroy(c->mev1);
     if (c->gev0) hipEventDestroy(c->gev0);
     if (c->gev1) hipEventDestroy(c->gev1);
     for (void* p : c->allocs) hipFree(p);
@@ -381,8 +386,19 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
         LCHK(launch_attn_vit(a, s));
         TRY(gemm(c->vH, vh, L.wo, vh, c->vX, vh, L.bo, c->vX, vh, Mv, vh, vh, EPI_RESIDUAL, s));
         LCHK(launch_layernorm(c->vX, vh, c->vH, vh, L.ln2w, L.ln2b, Mv, vh, c->c.v_eps, s));
+        const bool probe = (l == 0 && c->profile == 2);      // MFMA roofline probe: HIP events around ONE fc1 GEMM launch
+        if (probe) hipEventRecord(c->mev0, s);
         TRY(gemm(c->vH, vh, L.w1, vh, c->vMLP, vi, L.b1, nullptr, 0, Mv, vi, vh, EPI_QUICKGELU, s));
+        if (probe) { hipEventRecord(c->mev1, s); c->mflops = 2.0 * Mv * (double)vi * vh; }
         TRY(gemm(c->vMLP, vi, L.w2, vi, c->vX, vh, L.b2, c->vX, vh, Mv, vh, vi, EPI_RESIDUAL, s));
+    }
+    if (c->profile == 2 && c->vL > 0) {
+        hipEventSynchronize(c->mev1);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->mev0, c->mev1) == hipSuccess) { c->msum_ms += ms; c->msamples += 1; }
+        c->prof[5] = (float)(c->msum_ms / c->msamples);
+        c->prof[6] = (float)c->msamples;
+        c->prof[7] = (float)(c->mflops / 1e9);               // GFLOP of the bracketed launch
     }
     if (feats_out)   // drop CLS: [T, GG, vh]
         HIPCHK(hipMemcpy2DAsync(feats_out, (size_t)GG * vh * 2, c->vX + vh, (size_t)NT * vh * 2, (size_t)GG * vh * 2, T,
@@ -686,7 +702,7 @@ extern "C" int trace_decode_feed(trace_ctx* c, const int32_t* tokens, int B, voi
 
 extern "C" int trace_set_profile(trace_ctx* c, int on) {
     if (!c) return fail(TRACE_ERR_ARG, "null ctx");
-    c->profile = on; c->ksum_ms = 0.0; c->ksamples = 0; c->kev_used = 0;
+    c->profile = on; c->ksum_ms = 0.0; c->ksamples = 0; c->kev_used = 0; c->msum_ms = 0.0; c->msamples = 0;
     return TRACE_OK;
 }
 extern "C" int trace_get_profile(trace_ctx* c, float* out, int n) {

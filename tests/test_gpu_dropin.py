@@ -1,5 +1,7 @@
 """Drop-in surface on the GPU: the reference drivers' call sequence (trace/eval/evaluate.py:241-243,315-410) run
 against trace_amd with a synthetic tiny checkpoint."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -77,3 +79,30 @@ def test_sampling_and_asserts(loaded):
     with pytest.raises(Exception, match="only have one video"):
         bad = torch.cat([ids, torch.tensor([-201])])
         model.generate(bad.unsqueeze(0), images_or_videos=[tensor], modal_list=["video"], video_timestamps=[ts], heads=[1])
+
+
+def test_safetensors_checkpoint_loader(tmp_path_factory, loaded):
+    """HF-format checkpoint path: weights saved as sharded safetensors under the reference's
+    state-dict names — CLIP keys in the transformers-5 layout (no `.vision_model`) in one shard to exercise both
+    spellings — must load to exactly the same model as the synthetic path."""
+    from safetensors.torch import save_file
+    cfg, tok, model, proc, _ = loaded
+    path = str(tmp_path_factory.mktemp("ckpt_st") / "trace-tiny-st")
+    os.makedirs(path)
+    cfg.save_pretrained(path)
+    sd = synth.state_dict(cfg)
+    a, b = {}, {}
+    for i, (k, v) in enumerate(sd.items()):
+        if "vision_tower.vision_tower.vision_model." in k and "encoder.layers.1." in k:
+            k = k.replace("vision_tower.vision_tower.vision_model.", "vision_tower.vision_tower.")
+        (a if i % 2 else b)[k] = v.contiguous()
+    save_file(a, os.path.join(path, "model-00001-of-00002.safetensors"))
+    save_file(b, os.path.join(path, "model-00002-of-00002.safetensors"))
+    with pytest.warns(UserWarning, match="byte-level"):
+        tok2, model2, proc2, _ = load_pretrained_model(path, None, get_model_name_from_path(path), max_batch=1, max_new_tokens=32)
+    tensor, ts, ids = _driver_inputs(cfg, tok, proc)
+    kw = dict(images_or_videos=[tensor], modal_list=["video"], do_sample=False, max_new_tokens=10, video_timestamps=[ts])
+    o1 = model.generate(ids.unsqueeze(0), heads=[1], **kw)
+    o2 = model2.generate(ids.unsqueeze(0), heads=[1], **kw)
+    assert torch.equal(o1, o2)
+    model2.engine.close()

@@ -108,8 +108,14 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
         tokenizer = ByteTokenizer(cfg.vocab_size)
     else:
         eng.load_weights(_iter_safetensors(model_path))
-        from transformers import AutoTokenizer
-        tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=False, token=kwargs.get("token"))
+        has_tok = any(os.path.exists(os.path.join(model_path, f)) for f in ("tokenizer.model", "tokenizer.json", "tokenizer_config.json"))
+        if has_tok:
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=False, token=kwargs.get("token"))
+        else:
+            import warnings
+            warnings.warn(f"no tokenizer files under {model_path}: falling back to the byte-level stand-in tokenizer")
+            tokenizer = ByteTokenizer(cfg.vocab_size)
     processor = _image_processor(cfg, model_path)
     model = TraceMistralForCausalLM(cfg, eng, processor)
     # builder.py:135-149: optional extra tokens must not change the embedding table the engine already holds

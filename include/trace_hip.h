@@ -36,6 +36,7 @@ typedef struct trace_config {
     int32_t max_ctx;         /* KV-cache length per sequence slot (prefill + new tokens) */
     int32_t max_batch;       /* KV-cache sequence slots, <= 64 (at most 32 decode together) */
     int32_t max_new_tokens;  /* capacity of the on-device output id buffer               */
+    int32_t projector_type;  /* 0 = spatial_slot (TRACE), 1 = stc_connector (legacy API) */
 } trace_config;
 
 const char* trace_last_error(void);
@@ -58,6 +59,12 @@ int trace_vit_forward(trace_ctx* ctx, const void* frames, int frames_dtype, int 
 /* SpatialSlotPool.forward (trace/model/multimodal_projector/builder.py:427-467): feats (NULL = the internal
  * buffer of the last trace_vit_forward) -> slots_out [T, num_slots, hidden]; slots_out may be NULL. */
 int trace_slot_pool(trace_ctx* ctx, const void* feats, int T, void* slots_out, void* stream);
+
+/* STCConnector.forward (trace/model/multimodal_projector/builder.py:208-249), legacy trace.infer() path only
+ * (projector_type = 1): feats [T, patches, v_hidden] (NULL = internal buffer of the last trace_vit_forward) ->
+ * out [(T/2+1) * (g/2+1)^2, hidden] (may be NULL; the result also becomes the internal video rows for
+ * trace_splice_embeds).  *rows_out receives the row count.  Parity of this connector is unpinned (timm absent). */
+int trace_stc_connector(trace_ctx* ctx, const void* feats, int T, void* out, int* rows_out, void* stream);
 
 /* encode_images_or_videos (trace/model/trace_arch.py:218-266): ViT + slot pool + per-frame time-token embedding;
  * time_ids is HOST int32 [T, 6] (TimeTower.encode(t)[:-1]).  Result [T*(slots+6), hidden] stays internal;

@@ -198,6 +198,57 @@ class Oracle:
         res = r(torch.einsum("tnd,tns->tsd", x, p))                              # :462
         return r(res @ W["model.mm_projector.readout.weight"].t())               # :467
 
+    # -- STCConnector (multimodal_projector/builder.py:138-249), legacy trace.infer() path -----------
+    # PARITY UNPINNED: timm.models.regnet.RegStage is not importable in the build container, so the block
+    # below follows timm 0.6.x `Bottleneck` from memory (1x1 conv -> LN2d -> SiLU; depthwise 3x3 -> LN2d -> SiLU;
+    # SE with rd = round(in_chs/4), SiLU, sigmoid gate; 1x1 conv -> LN2d; + shortcut (1x1 conv + LN2d when the
+    # channel count changes); SiLU).  It pins the HIP path against THIS restatement only.
+    def _ln2d(self, x, w, b):
+        # LayerNorm2d: normalise over channels at every pixel (eps 1e-6); x [N,C,H,W]
+        xp = x.permute(0, 2, 3, 1)
+        return self._ln(xp, w, b, 1e-6).permute(0, 3, 1, 2)
+
+    def _reg_block(self, x, q):
+        import torch.nn.functional as F
+        W, r = self.W, self.r
+        silu = torch.nn.functional.silu
+        sc = x
+        y = r(F.conv2d(x, W[q + "conv1.conv.weight"]))
+        y = r(silu(r(self._ln2d(y, W[q + "conv1.bn.weight"], W[q + "conv1.bn.bias"]))))
+        y = r(F.conv2d(y, W[q + "conv2.conv.weight"], padding=1, groups=y.shape[1]))
+        y = r(silu(r(self._ln2d(y, W[q + "conv2.bn.weight"], W[q + "conv2.bn.bias"]))))
+        se = r(y.mean((2, 3), keepdim=True))
+        se = r(silu(r(F.conv2d(se, W[q + "se.fc1.weight"])) + W[q + "se.fc1.bias"].view(1, -1, 1, 1)))
+        se = r(torch.sigmoid(r(F.conv2d(se, W[q + "se.fc2.weight"])) + W[q + "se.fc2.bias"].view(1, -1, 1, 1)))
+        y = r(y * se)
+        y = r(F.conv2d(y, W[q + "conv3.conv.weight"]))
+        y = r(self._ln2d(y, W[q + "conv3.bn.weight"], W[q + "conv3.bn.bias"]))
+        if (q + "downsample.conv.weight") in W:
+            sc = r(F.conv2d(sc, W[q + "downsample.conv.weight"]))
+            sc = r(self._ln2d(sc, W[q + "downsample.bn.weight"], W[q + "downsample.bn.bias"]))
+        return r(silu(y + sc))
+
+    def stc_connector(self, feats: torch.Tensor) -> torch.Tensor:
+        """feats [T, n, d] (one video) -> [(T//2+1) * (h//2+1)^2, H]   (builder.py:208-231)."""
+        import torch.nn.functional as F
+        W, r = self.W, self.r
+        P = "model.mm_projector."
+        T, n, d = feats.shape
+        h = int(n ** 0.5)
+        x = feats.float().permute(0, 2, 1).reshape(T, d, h, h)                        # (b t) d h w
+        for b in range(4):
+            x = self._reg_block(x, f"{P}s1.b{b + 1}.")
+        x = x.permute(1, 0, 2, 3)[None]                                               # b d t h w
+        x = r(F.conv3d(x, W[P + "sampler.0.weight"], W[P + "sampler.0.bias"], stride=2, padding=1))
+        x = r(torch.nn.functional.silu(x))
+        nt = x.shape[2]
+        x = x[0].permute(1, 0, 2, 3)                                                  # (b t) d h w
+        for b in range(4):
+            x = self._reg_block(x, f"{P}s2.b{b + 1}.")
+        x = x.permute(0, 2, 3, 1).reshape(nt * x.shape[2] * x.shape[3], -1)           # (t h w) d
+        x = r(torch.nn.functional.gelu(r(x @ W[P + "readout.0.weight"].t() + W[P + "readout.0.bias"])))
+        return r(x @ W[P + "readout.2.weight"].t() + W[P + "readout.2.bias"])
+
     # -- encode_images_or_videos (trace_arch.py:218-266) -------------------------------------------
     def encode_video(self, frames: torch.Tensor, timestamps: Sequence[Sequence[float]]) -> torch.Tensor:
         """frames [T,3,S,S], timestamps [[t]]*T -> [T*(slots+6), H]: per frame slots then time tokens."""

@@ -1,0 +1,46 @@
+"""STC connector (legacy trace.infer() path; north_star names it) on the GPU against the oracle's restatement.
+PARITY UNPINNED with respect to the reference: timm's RegStage is not importable in the build container, so both
+sides follow timm 0.6.x from memory; this test pins the HIP kernels to the oracle only."""
+import dataclasses
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+if not torch.cuda.is_available():
+    pytest.skip("needs a HIP device", allow_module_level=True)
+
+from oracle import trace_oracle as O  # noqa: E402
+from trace_amd import config as tcfg, synth  # noqa: E402
+from trace_amd.engine import TraceEngine  # noqa: E402
+
+
+def test_stc_connector_vs_oracle():
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), mm_projector_type="stc_connector", vision_image_size=84)   # 6x6 patch grid
+    sd = synth.state_dict(cfg)
+    eng = TraceEngine(cfg, max_batch=1, max_ctx=256, max_frames=4, max_new_tokens=8)
+    eng.load_weights(sd.items())
+    ora = O.Oracle(cfg, sd, emulate_bf16=True)
+    g = torch.Generator().manual_seed(3)
+    feats = (torch.randn(4, cfg.vision_patches, cfg.vision_hidden_size, generator=g)).to(torch.bfloat16)
+    got = eng.stc_connector(feats.cuda(), 4)
+    ref = ora.stc_connector(feats.float())
+    assert got.shape == ref.shape == ((4 // 2 + 1) * 4 * 4, cfg.hidden_size)
+    err = (got.float().cpu() - ref).abs()
+    tol = 6e-2 + 6e-2 * ref.abs()
+    assert torch.isfinite(got).all()
+    assert (err > tol).float().mean().item() < 5e-3, f"max err {err.max().item()}, ref max {ref.abs().max().item()}"
+    # legacy flow: ViT -> STC -> splice (no time tokens) -> text-head decode
+    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16)
+    eng.vit_forward(frames)
+    vid = eng.stc_connector(None, 4)
+    ids = synth.synth_prompt_ids(cfg, n_text=16, video_pos=5).tolist()
+    ids[-1] = 7                                   # legacy prompts carry no <sync>
+    L = eng.splice(ids)
+    assert L == 15 + vid.shape[0]
+    eng.prefill(0, L)
+    eng.decode_begin([0], [0], 6)
+    eng.decode_steps(5)
+    out, heads = eng.decode_read()
+    assert len(out[0]) == 6 and all(0 <= t <= cfg.vocab_size for t in out[0])
+    eng.close()

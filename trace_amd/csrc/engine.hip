@@ -23,6 +23,7 @@ static int fail(int code, const std::string& m) { g_err = m; return code; }
 
 struct VitLayer { bf16_t *ln1w, *ln1b, *wqkv, *bqkv, *wo, *bo, *ln2w, *ln2b, *w1, *b1, *w2, *b2; };
 struct LlmLayer { bf16_t *rms1, *wqkv, *wo, *rms2, *wgu, *wd; };
+struct StcBlock { bf16_t *w1, *n1w, *n1b, *wdw, *n2w, *n2b, *fc1w, *fc1b, *fc2w, *fc2b, *w3, *n3w, *n3b, *wd, *ndw, *ndb; int cin, rd; };
 
 struct trace_ctx {
     trace_config c{};
@@ -40,6 +41,11 @@ struct trace_ctx {
     bf16_t *patch_w, *cls, *pos_emb, *pre_w, *pre_b;
     std::vector<VitLayer> vit;
     bf16_t *sl_lnw, *sl_lnb, *sl_slots, *sl_readout;
+    // STC connector (projector_type == 1)
+    int stc = 0, stc_loaded = 0;
+    StcBlock stc_blk[2][4];
+    bf16_t *stc_w3d, *stc_b3d, *stc_r0w, *stc_r0b, *stc_r2w, *stc_r2b;
+    bf16_t *stc_x, *stc_y, *stc_z, *stc_sc, *stc_col, *stc_pool, *stc_g1, *stc_g2, *stc_tmp;
     bf16_t *embed, *final_norm, *wheads, *time_tab, *score_tab, *sync_row;
     std::vector<LlmLayer> llm;
     float *slot_cos, *slot_sin, *rope_cos, *rope_sin;
@@ -115,10 +121,16 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     if (c->HD != 128 || c->NQ != 4 * c->NKV) return bad("LLM kernels need head_dim 128 and 4:1 GQA");
     if (c->vh / c->vheads != 64) return bad("ViT kernels need head_dim 64");
     if (c->H % 128 || c->I % 128 || c->vh % 128 || c->vi % 128 || c->QKV % 128) return bad("dims must be multiples of 128");
-    if (c->S != 8 || c->vh > 1024) return bad("slot pool kernel needs 8 slots and mm_hidden <= 1024");
+    c->stc = cfg->projector_type == 1;
+    if (!c->stc && (c->S != 8 || c->vh > 1024)) return bad("slot pool kernel needs 8 slots and mm_hidden <= 1024");
     if (c->max_B < 1 || c->max_B > 64) return bad("max_batch (KV slots) must be in [1,64]");
     c->nsplit = 32;                                           // upper bound (workspace size); per-batch value below
-    if (cfg->max_frames < 1 || cfg->max_frames * c->TPF > c->max_ctx) return bad("max_frames*14 exceeds max_ctx");
+    {
+        const int g2 = c->G / 2 + 1;
+        const int vis_rows = c->stc ? (cfg->max_frames / 2 + 1) * g2 * g2 : cfg->max_frames * c->TPF;
+        if (cfg->max_frames < 1 || vis_rows > c->max_ctx) return bad("visual tokens of max_frames exceed max_ctx");
+        if (c->stc && cfg->max_frames > 32) return bad("STC connector path supports at most 32 frames");
+    }
     if (c->Tv != 13 || c->Sv != 13) { /* any size works; kept for clarity */ }
 
     const size_t H = c->H, I = c->I, vh = c->vh, vi = c->vi;
@@ -131,7 +143,25 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
         A(l.ln1w, vh); A(l.ln1b, vh); A(l.wqkv, 3 * vh * vh); A(l.bqkv, 3 * vh); A(l.wo, vh * vh); A(l.bo, vh);
         A(l.ln2w, vh); A(l.ln2b, vh); A(l.w1, vi * vh); A(l.b1, vi); A(l.w2, vh * vi); A(l.b2, vh);
     }
-    A(c->sl_lnw, vh); A(c->sl_lnb, vh); A(c->sl_slots, vh * c->S); A(c->sl_readout, H * vh);
+    if (!c->stc) { A(c->sl_lnw, vh); A(c->sl_lnb, vh); A(c->sl_slots, vh * c->S); A(c->sl_readout, H * vh); }
+    else {
+        for (int st = 0; st < 2; ++st)
+            for (int b = 0; b < 4; ++b) {
+                StcBlock& k = c->stc_blk[st][b];
+                k.cin = (st == 0 && b == 0) ? (int)vh : (int)H;
+                k.rd = (int)lround(k.cin * 0.25);
+                A(k.w1, H * k.cin); A(k.n1w, H); A(k.n1b, H); A(k.wdw, H * 9); A(k.n2w, H); A(k.n2b, H);
+                A(k.fc1w, (size_t)k.rd * H); A(k.fc1b, k.rd); A(k.fc2w, H * k.rd); A(k.fc2b, H);
+                A(k.w3, H * H); A(k.n3w, H); A(k.n3b, H);
+                if (k.cin != (int)H) { A(k.wd, H * k.cin); A(k.ndw, H); A(k.ndb, H); } else { k.wd = k.ndw = k.ndb = nullptr; }
+            }
+        A(c->stc_w3d, 8 * H * H); A(c->stc_b3d, H); A(c->stc_r0w, H * H); A(c->stc_r0b, H); A(c->stc_r2w, H * H); A(c->stc_r2b, H);
+        const size_t rows = (size_t)cfg->max_frames * c->GG;
+        const int g2 = c->G / 2 + 1;
+        const size_t rows2 = (size_t)(cfg->max_frames / 2 + 1) * g2 * g2;
+        A(c->stc_x, rows * H); A(c->stc_y, rows * H); A(c->stc_z, rows * H); A(c->stc_sc, rows * H);
+        A(c->stc_col, rows2 * 8 * H); A(c->stc_pool, 32 * H); A(c->stc_g1, 32 * H); A(c->stc_g2, 32 * H); A(c->stc_tmp, 8 * H * H);
+    }
     A(c->embed, (size_t)c->V * H); A(c->final_norm, H); A(c->wheads, (size_t)c->NVpad * H);
     A(c->time_tab, (size_t)c->Tv * H); A(c->score_tab, (size_t)c->Sv * H); A(c->sync_row, H);
     c->llm.resize(c->NL);
@@ -152,7 +182,12 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
         const size_t mlp = Mv * vi, im2 = Tm * c->GG * c->Kpad;
         A(c->vMLP, mlp > im2 ? mlp : im2);
     }
-    A(c->sl_res, Tm * c->S * vh); A(c->sl_out, Tm * c->S * H); A(c->video, Tm * c->TPF * H);
+    A(c->sl_res, Tm * c->S * vh); A(c->sl_out, Tm * c->S * H);
+    {
+        const int g2 = c->G / 2 + 1;
+        const size_t vr = c->stc ? (size_t)(Tm / 2 + 1) * g2 * g2 : Tm * c->TPF;
+        A(c->video, vr * H);
+    }
     // --- prefill workspaces ---
     const size_t Lm = c->max_ctx;
     A(c->pX, Lm * H); A(c->pH, Lm * H); A(c->pQKV, Lm * c->QKV); A(c->pVT, (size_t)c->NKV * c->HD * c->ctx_pad);
@@ -234,6 +269,44 @@ extern "C" int trace_ctx_load_tensor(trace_ctx* c, const char* name_, const void
     if (name == "model.time_tower.embed_tokens.weight") return flat(c->time_tab, (int64_t)c->Tv * H);
     if (name == "model.score_tower.embed_tokens.weight") return flat(c->score_tab, (int64_t)c->Sv * H);
     if (name == "model.sync_tower.embed_tokens.weight") return flat(c->sync_row, H);
+    if (c->stc && starts(name, "model.mm_projector.")) {
+        const std::string k = name.substr(strlen("model.mm_projector."));
+        if (k == "sampler.0.bias") return flat(c->stc_b3d, H);
+        if (k == "readout.0.weight") return flat(c->stc_r0w, H * H);
+        if (k == "readout.0.bias") return flat(c->stc_r0b, H);
+        if (k == "readout.2.weight") return flat(c->stc_r2w, H * H);
+        if (k == "readout.2.bias") return flat(c->stc_r2b, H);
+        if (k == "sampler.0.weight") {      // [Co, Ci, 2,2,2] -> [Co][tap][Ci] for the im2col GEMM
+            TRY(expect(8 * (int64_t)H * H));
+            TRY(copy1d(c->stc_tmp, data, 8 * H * H * E, on_device));
+            if (launch_permute_conv3d_w(c->stc_tmp, c->stc_w3d, (int)H, (int)H, 0) != TRACE_OK) return fail(TRACE_ERR_HIP, "permute launch");
+            HIPCHK(hipDeviceSynchronize());
+            return done();
+        }
+        if ((k[0] == 's') && (k[1] == '1' || k[1] == '2') && k[2] == '.' && k[3] == 'b' && k[5] == '.') {
+            const int st = k[1] - '1', b = k[4] - '1';
+            if (b < 0 || b > 3) return fail(TRACE_ERR_ARG, "bad STC block in " + name);
+            StcBlock& q = c->stc_blk[st][b];
+            const std::string t = k.substr(6);
+            if (t == "conv1.conv.weight") return flat(q.w1, (int64_t)H * q.cin);
+            if (t == "conv1.bn.weight") return flat(q.n1w, H);
+            if (t == "conv1.bn.bias") return flat(q.n1b, H);
+            if (t == "conv2.conv.weight") return flat(q.wdw, H * 9);
+            if (t == "conv2.bn.weight") return flat(q.n2w, H);
+            if (t == "conv2.bn.bias") return flat(q.n2b, H);
+            if (t == "se.fc1.weight") return flat(q.fc1w, (int64_t)q.rd * H);
+            if (t == "se.fc1.bias") return flat(q.fc1b, q.rd);
+            if (t == "se.fc2.weight") return flat(q.fc2w, (int64_t)H * q.rd);
+            if (t == "se.fc2.bias") return flat(q.fc2b, H);
+            if (t == "conv3.conv.weight") return flat(q.w3, H * H);
+            if (t == "conv3.bn.weight") return flat(q.n3w, H);
+            if (t == "conv3.bn.bias") return flat(q.n3b, H);
+            if (q.wd && t == "downsample.conv.weight") return flat(q.wd, (int64_t)H * q.cin);
+            if (q.wd && t == "downsample.bn.weight") return flat(q.ndw, H);
+            if (q.wd && t == "downsample.bn.bias") return flat(q.ndb, H);
+        }
+        return fail(TRACE_ERR_ARG, "unknown tensor " + name);
+    }
     if (name == "model.mm_projector.slots") return flat(c->sl_slots, (int64_t)vh * c->S);
     if (name == "model.mm_projector.ln_vision.weight") return flat(c->sl_lnw, vh);
     if (name == "model.mm_projector.ln_vision.bias") return flat(c->sl_lnb, vh);
@@ -313,7 +386,7 @@ extern "C" int trace_ctx_load_tensor(trace_ctx* c, const char* name_, const void
 
 extern "C" int trace_ctx_finalize(trace_ctx* c) {
     if (!c) return fail(TRACE_ERR_ARG, "null ctx");
-    const int expected = 13 + 9 * c->NL + 5 + 16 * c->vL;
+    const int expected = (c->stc ? 9 + 8 * 13 + 3 + 6 : 13) + 9 * c->NL + 5 + 16 * c->vL;
     if ((int)c->loaded.size() != expected)
         return fail(TRACE_ERR_STATE, "weights incomplete: " + std::to_string(c->loaded.size()) + " of " + std::to_string(expected) + " tensors loaded");
     // RoPE tables, computed the way the reference does (fp32 inv_freq, fp32 angle, cos/sin of that angle)
@@ -409,6 +482,7 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
 extern "C" int trace_slot_pool(trace_ctx* c, const void* feats, int T, void* slots_out, void* stream) {
     if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
     if (T < 1 || T > c->c.max_frames) return fail(TRACE_ERR_ARG, "bad T");
+    if (c->stc) return fail(TRACE_ERR_STATE, "this context holds the STC connector, not SpatialSlotPool");
     hipStream_t s = (hipStream_t)stream;
     const int vh = c->vh;
     const bf16_t* f = feats ? (const bf16_t*)feats : c->vX + vh;
@@ -417,6 +491,62 @@ extern "C" int trace_slot_pool(trace_ctx* c, const void* feats, int T, void* slo
                           c->S, c->c.slot_eps, s));
     TRY(gemm(c->sl_res, vh, c->sl_readout, vh, c->sl_out, c->H, nullptr, nullptr, 0, T * c->S, c->H, vh, EPI_NONE, s));
     if (slots_out) HIPCHK(hipMemcpyAsync(slots_out, c->sl_out, (size_t)T * c->S * c->H * 2, hipMemcpyDeviceToDevice, s));
+    return TRACE_OK;
+}
+
+// one timm-style RegNet bottleneck on channels-last rows: x [N*HW, cin] -> out [N*HW, H] (out may alias nothing of x)
+static int stc_block(trace_ctx* c, const StcBlock& k, const bf16_t* x, bf16_t* out, int N, int hh, int ww, hipStream_t s) {
+    const int H = c->H, HW = hh * ww, rows = N * HW;
+    bf16_t *y = c->stc_y, *z = c->stc_z, *sc = c->stc_sc;
+    TRY(gemm(x, k.cin, k.w1, k.cin, y, H, nullptr, nullptr, 0, rows, H, k.cin, EPI_NONE, s));
+    LCHK(launch_layernorm(y, H, y, H, k.n1w, k.n1b, rows, H, 1e-6f, s, 1));
+    LCHK(launch_dwconv3x3(y, k.wdw, z, N, hh, ww, H, s));
+    LCHK(launch_layernorm(z, H, z, H, k.n2w, k.n2b, rows, H, 1e-6f, s, 1));
+    LCHK(launch_avgpool(z, c->stc_pool, N, HW, H, s));
+    LCHK(launch_skinny_gemm(c->stc_pool, H, k.fc1w, H, c->stc_g1, k.rd, nullptr, 0, N, k.rd, H, EPI_NONE, s));
+    LCHK(launch_bias_act(c->stc_g1, k.fc1b, N, k.rd, ACT_SILU, s));
+    LCHK(launch_skinny_gemm(c->stc_g1, k.rd, k.fc2w, k.rd, c->stc_g2, H, nullptr, 0, N, H, k.rd, EPI_NONE, s));
+    LCHK(launch_bias_act(c->stc_g2, k.fc2b, N, H, ACT_SIGMOID, s));
+    LCHK(launch_scale_rows(z, c->stc_g2, N, HW, H, s));
+    TRY(gemm(z, H, k.w3, H, y, H, nullptr, nullptr, 0, rows, H, H, EPI_NONE, s));
+    LCHK(launch_layernorm(y, H, y, H, k.n3w, k.n3b, rows, H, 1e-6f, s, 0));
+    const bf16_t* shortcut = x;
+    if (k.wd) {
+        TRY(gemm(x, k.cin, k.wd, k.cin, sc, H, nullptr, nullptr, 0, rows, H, k.cin, EPI_NONE, s));
+        LCHK(launch_layernorm(sc, H, sc, H, k.ndw, k.ndb, rows, H, 1e-6f, s, 0));
+        shortcut = sc;
+    }
+    LCHK(launch_add_act(y, shortcut, (long)rows * H, ACT_SILU, s));          // y = SiLU(y + shortcut); x is dead after this
+    if (out != y) HIPCHK(hipMemcpyAsync(out, y, (size_t)rows * H * 2, hipMemcpyDeviceToDevice, s));
+    return TRACE_OK;
+}
+
+extern "C" int trace_stc_connector(trace_ctx* c, const void* feats, int T, void* out, int* rows_out, void* stream) {
+    if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
+    if (!c->stc) return fail(TRACE_ERR_STATE, "context was not created with projector_type = stc_connector");
+    if (T < 1 || T > c->c.max_frames || T > 32) return fail(TRACE_ERR_ARG, "bad T");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = c->H, vh = c->vh, G = c->G, GG = c->GG;
+    // gather the patch rows (drop CLS) into a dense [T*GG, vh] buffer
+    if (feats) HIPCHK(hipMemcpyAsync(c->stc_x, feats, (size_t)T * GG * vh * 2, hipMemcpyDeviceToDevice, s));
+    else HIPCHK(hipMemcpy2DAsync(c->stc_x, (size_t)GG * vh * 2, c->vX + vh, (size_t)c->NT * vh * 2, (size_t)GG * vh * 2, T,
+                                 hipMemcpyDeviceToDevice, s));
+    // s1: 4 blocks on [T, G, G]; every block reads stc_x and leaves its result there (block 0 reads it with row
+    // pitch vh and writes pitch H: the result is produced in stc_y and copied once x is dead)
+    for (int b = 0; b < 4; ++b) TRY(stc_block(c, c->stc_blk[0][b], c->stc_x, c->stc_x, T, G, G, s));
+    // sampler: Conv3d k = s = 2, p = 1 (+bias) + SiLU as an im2col GEMM
+    const int To = T / 2 + 1, Go = G / 2 + 1, rows2 = To * Go * Go;
+    LCHK(launch_im2col3d(c->stc_x, c->stc_col, T, G, G, H, To, Go, Go, s));
+    TRY(gemm(c->stc_col, 8 * H, c->stc_w3d, 8 * H, c->stc_x, H, c->stc_b3d, nullptr, 0, rows2, H, 8 * H, EPI_NONE, s));
+    LCHK(launch_bias_act(c->stc_x, nullptr, rows2, H, ACT_SILU, s));
+    for (int b = 0; b < 4; ++b) TRY(stc_block(c, c->stc_blk[1][b], c->stc_x, c->stc_x, To, Go, Go, s));
+    // readout MLP
+    TRY(gemm(c->stc_x, H, c->stc_r0w, H, c->stc_y, H, c->stc_r0b, nullptr, 0, rows2, H, H, EPI_NONE, s));
+    LCHK(launch_bias_act(c->stc_y, nullptr, rows2, H, ACT_GELU, s));
+    TRY(gemm(c->stc_y, H, c->stc_r2w, H, c->video, H, c->stc_r2b, nullptr, 0, rows2, H, H, EPI_NONE, s));
+    c->video_rows = rows2;
+    if (rows_out) *rows_out = rows2;
+    if (out) HIPCHK(hipMemcpyAsync(out, c->video, (size_t)rows2 * H * 2, hipMemcpyDeviceToDevice, s));
     return TRACE_OK;
 }
 

@@ -17,10 +17,12 @@ struct GemmArgs {
 };
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s);
 
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_SIGMOID = 2, ACT_GELU = 3 };
+
 // ---- norms (norm.hip) ----
 // y = LN(x) * w + b over the last dim D (D % 8 == 0, D <= 8192); rows independent; x,y bf16, stats fp32.
 int launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w, const bf16_t* b,
-                     int rows, int D, float eps, hipStream_t s);
+                     int rows, int D, float eps, hipStream_t s, int silu = 0);   // silu = 1: y = SiLU(LN(x))
 int launch_rmsnorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w, int rows, int D, float eps,
                    hipStream_t s);
 
@@ -99,3 +101,12 @@ struct StepState {
 int launch_select_next(const float* part_val, const int32_t* part_idx, const StepState& st, const bf16_t* embed,
                        const bf16_t* time_tab, const bf16_t* score_tab, const bf16_t* sync_row, bf16_t* xnext, int ldx,
                        int B, int H, int V, int Tv, int Sv, int advance, hipStream_t s);
+
+// ---- STC connector support (stc.hip): channels-last [n][h][w][C] row kernels ----
+int launch_dwconv3x3(const bf16_t* x, const bf16_t* w /*[C][9]*/, bf16_t* y, int N, int H, int W, int C, hipStream_t s);
+int launch_avgpool(const bf16_t* x, bf16_t* y /*[N][C]*/, int N, int HW, int C, hipStream_t s);
+int launch_bias_act(bf16_t* x, const bf16_t* bias, long rows, int C, int act, hipStream_t s);
+int launch_scale_rows(bf16_t* x, const bf16_t* gate /*[N][C]*/, int N, int HW, int C, hipStream_t s);
+int launch_add_act(bf16_t* x, const bf16_t* y, long n, int act, hipStream_t s);
+int launch_im2col3d(const bf16_t* x, bf16_t* A, int T, int H, int W, int C, int To, int Ho, int Wo, hipStream_t s);
+int launch_permute_conv3d_w(const bf16_t* w, bf16_t* out, int Co, int Ci, hipStream_t s);

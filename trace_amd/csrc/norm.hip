@@ -10,7 +10,7 @@ constexpr int MAXCH = 8;   // 8 chunks x 64 lanes x 8 elements = 4096
 template <bool RMS>
 __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
                                                    const bf16_t* __restrict__ w, const bf16_t* __restrict__ b, int rows,
-                                                   int D, float eps) {
+                                                   int D, float eps, int silu) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -72,6 +72,10 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
                 const float bb[8] = {bflo(ub.x), bfhi(ub.x), bflo(ub.y), bfhi(ub.y), bflo(ub.z), bfhi(ub.z), bflo(ub.w), bfhi(ub.w)};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * ww[e] + bb[e];
+                if (silu) {             // LayerNorm2d + SiLU of timm's ConvNormAct (STC connector): LN output rounded like a separate op
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float t = bf2f(f2bf(o[e])); o[e] = t / (1.f + __expf(-t)); }
+                }
             }
             uint4 out;
             out.x = pack2bf(o[0], o[1]); out.y = pack2bf(o[2], o[3]); out.z = pack2bf(o[4], o[5]); out.w = pack2bf(o[6], o[7]);
@@ -82,15 +86,15 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
 }  // namespace
 
 int launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w, const bf16_t* b, int rows, int D,
-                     float eps, hipStream_t s) {
+                     float eps, hipStream_t s, int silu) {
     if (D % 8 || D > MAXCH * 512 || (ldx % 8) || (ldy % 8) || rows <= 0) return TRACE_ERR_ARG;
-    hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, w, b, rows, D, eps);
+    hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, w, b, rows, D, eps, silu);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 
 int launch_rmsnorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w, int rows, int D, float eps,
                    hipStream_t s) {
     if (D % 8 || D > MAXCH * 512 || (ldx % 8) || (ldy % 8) || rows <= 0) return TRACE_ERR_ARG;
-    hipLaunchKernelGGL(norm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, w, nullptr, rows, D, eps);
+    hipLaunchKernelGGL(norm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, w, nullptr, rows, D, eps, 0);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }

@@ -44,7 +44,8 @@ class TraceEngine:
             cfg.num_key_value_heads, cfg.time_vocab_size, cfg.score_vocab_size, cfg.rms_norm_eps, cfg.rope_theta,
             cfg.vision_hidden_size, cfg.vision_intermediate_size, cfg.vision_layers_used, cfg.vision_num_heads,
             cfg.vision_image_size, cfg.vision_patch_size, cfg.vision_layer_norm_eps, cfg.num_slots, cfg.slot_ln_eps,
-            cfg.slot_rope_base, max_frames, max_ctx, max_batch, max_new_tokens)
+            cfg.slot_rope_base, max_frames, max_ctx, max_batch, max_new_tokens,
+            1 if cfg.mm_projector_type == "stc_connector" else 0)
         h = C.c_void_p()
         _lib.check(self.lib.trace_ctx_create(C.byref(c), device, C.byref(h)))
         self.h = h
@@ -100,6 +101,18 @@ class TraceEngine:
         if feats is not None:
             feats = feats.to(self.device, torch.bfloat16).contiguous()
         _lib.check(self.lib.trace_slot_pool(self.h, _ptr(feats), T, _ptr(out), _stream()))
+        return out
+
+    def stc_connector(self, feats: Optional[torch.Tensor], T: int) -> torch.Tensor:
+        """Legacy STC connector (projector_type 'stc_connector'); result also becomes the video rows for splice()."""
+        g = self.cfg.vision_grid // 2 + 1
+        rows = (T // 2 + 1) * g * g
+        out = torch.empty((rows, self.cfg.hidden_size), dtype=torch.bfloat16, device=self.device)
+        if feats is not None:
+            feats = feats.to(self.device, torch.bfloat16).contiguous()
+        n = C.c_int(0)
+        _lib.check(self.lib.trace_stc_connector(self.h, _ptr(feats), T, _ptr(out), C.byref(n), _stream()))
+        assert n.value == rows
         return out
 
     def time_ids(self, timestamps: Sequence[Sequence[float]]) -> List[int]:

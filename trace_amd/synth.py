@@ -69,11 +69,16 @@ def weight_specs(cfg: TraceConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
             (p + "layer_norm2.weight", (vh,), "norm"), (p + "layer_norm2.bias", (vh,), "bias"),
         ]
     s += [(VIS + "post_layernorm.weight", (vh,), "norm"), (VIS + "post_layernorm.bias", (vh,), "bias")]
+    if cfg.mm_projector_type == "stc_connector":
+        s += stc_specs(cfg)
+    else:
+        s += [
+            ("model.mm_projector.slots", (cfg.mm_hidden_size, cfg.num_slots), "slots"),
+            ("model.mm_projector.ln_vision.weight", (cfg.mm_hidden_size,), "norm"),
+            ("model.mm_projector.ln_vision.bias", (cfg.mm_hidden_size,), "bias"),
+            ("model.mm_projector.readout.weight", (H, cfg.mm_hidden_size), "w"),
+        ]
     s += [
-        ("model.mm_projector.slots", (cfg.mm_hidden_size, cfg.num_slots), "slots"),
-        ("model.mm_projector.ln_vision.weight", (cfg.mm_hidden_size,), "norm"),
-        ("model.mm_projector.ln_vision.bias", (cfg.mm_hidden_size,), "bias"),
-        ("model.mm_projector.readout.weight", (H, cfg.mm_hidden_size), "w"),
         ("model.time_tower.embed_tokens.weight", (cfg.time_vocab_size, H), "w"),
         ("model.score_tower.embed_tokens.weight", (cfg.score_vocab_size, H), "w"),
         ("model.sync_tower.embed_tokens.weight", (1, H), "w"),
@@ -82,6 +87,35 @@ def weight_specs(cfg: TraceConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
         ("time_head.weight", (cfg.time_vocab_size, H), "w"),
         ("score_head.weight", (cfg.score_vocab_size, H), "w"),
     ]
+    return s
+
+
+def stc_specs(cfg: TraceConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """STCConnector (reference multimodal_projector/builder.py:138-205): RegStage(depth 4, SiLU, LayerNorm2d) ->
+    Conv3d k=s=2 p=1 + SiLU -> RegStage -> MLP(GELU).  Module/key names follow timm 0.6.x `regnet.Bottleneck`
+    (conv1/conv2/se/conv3/downsample, each ConvNormAct = .conv + .bn) as recalled — timm is not installed here, so
+    these names (like the STC arithmetic) are unpinned."""
+    C, Cin = cfg.hidden_size, cfg.mm_hidden_size
+    P = "model.mm_projector."
+    s: List[Tuple[str, Tuple[int, ...], str]] = []
+    for stage, cin0 in (("s1", Cin), ("s2", C)):
+        for b in range(4):
+            cin = cin0 if b == 0 else C
+            rd = int(round(cin * 0.25))
+            q = f"{P}{stage}.b{b + 1}."
+            s += [
+                (q + "conv1.conv.weight", (C, cin, 1, 1), "w"), (q + "conv1.bn.weight", (C,), "norm"), (q + "conv1.bn.bias", (C,), "bias"),
+                (q + "conv2.conv.weight", (C, 1, 3, 3), "dw"), (q + "conv2.bn.weight", (C,), "norm"), (q + "conv2.bn.bias", (C,), "bias"),
+                (q + "se.fc1.weight", (rd, C, 1, 1), "w"), (q + "se.fc1.bias", (rd,), "bias"),
+                (q + "se.fc2.weight", (C, rd, 1, 1), "w"), (q + "se.fc2.bias", (C,), "bias"),
+                (q + "conv3.conv.weight", (C, C, 1, 1), "w"), (q + "conv3.bn.weight", (C,), "norm"), (q + "conv3.bn.bias", (C,), "bias"),
+            ]
+            if cin != C:
+                s += [(q + "downsample.conv.weight", (C, cin, 1, 1), "w"), (q + "downsample.bn.weight", (C,), "norm"),
+                      (q + "downsample.bn.bias", (C,), "bias")]
+    s += [(P + "sampler.0.weight", (C, C, 2, 2, 2), "w3"), (P + "sampler.0.bias", (C,), "bias"),
+          (P + "readout.0.weight", (C, C), "w"), (P + "readout.0.bias", (C,), "bias"),
+          (P + "readout.2.weight", (C, C), "w"), (P + "readout.2.bias", (C,), "bias")]
     return s
 
 
@@ -99,6 +133,10 @@ def synth_tensor(name: str, shape: Tuple[int, ...], kind: str, dtype=torch.bfloa
         x = 1.0 + 0.1 * x
     elif kind == "bias":
         x = x * 0.02
+    elif kind == "dw":
+        x = x * 0.3            # 9-tap depthwise kernels: keep the activation scale O(1)
+    elif kind == "w3":
+        x = x * 0.006          # fan-in 8*C
     elif kind == "slots":
         # randn as in the reference, scaled: with unit-variance LN output over 1024 channels an
         # N(0,1) slot matrix gives logits of std 32 and a one-hot 576-way softmax whose value is

@@ -16,7 +16,8 @@ from trace_amd.engine import TraceEngine  # noqa: E402
 
 
 def test_stc_connector_vs_oracle():
-    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), mm_projector_type="stc_connector", vision_image_size=84)   # 6x6 patch grid
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), mm_projector_type="stc_connector", vision_image_size=84,   # 6x6 patch grid
+                              vision_hidden_size=256, vision_num_heads=4, mm_hidden_size=256)             # SE reduce width 64
     sd = synth.state_dict(cfg)
     eng = TraceEngine(cfg, max_batch=1, max_ctx=256, max_frames=4, max_new_tokens=8)
     eng.load_weights(sd.items())

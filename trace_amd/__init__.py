@@ -31,6 +31,14 @@ def infer(model, video, instruct, tokenizer, do_sample=False, video_timestamps=N
     conv = conv_templates["llama_2"].copy()
     conv.append_message(conv.roles[0], DEFAULT_MMODAL_TOKEN["VIDEO"] + "\n" + instruct)
     conv.append_message(conv.roles[1], None)
+    if getattr(model.config, "mm_projector_type", "") == "stc_connector":
+        # the reference's legacy flow verbatim: STC connector, no <sync>, no timestamps, text head (trace/__init__.py:46-71)
+        from .constants import MMODAL_TOKEN_INDEX
+        from .mm_utils import tokenizer_MMODAL_token
+        ids = tokenizer_MMODAL_token(conv.get_prompt(), tokenizer, MMODAL_TOKEN_INDEX["VIDEO"], return_tensors="pt").unsqueeze(0)
+        with torch.inference_mode():
+            return model.generate(ids, images_or_videos=[video], modal_list=["video"], do_sample=do_sample,
+                                  temperature=0.2 if do_sample else 0.0, max_new_tokens=max_new_tokens, use_cache=True)
     prompt = conv.get_prompt() + "<sync>"
     ids = tokenizer_MMODAL_token_all(prompt, tokenizer, return_tensors="pt").unsqueeze(0)
     ts = video_timestamps or [[float(i)] for i in range(video.shape[0])]

@@ -89,9 +89,12 @@ class TraceEngine:
         frames = frames.to(self.device).contiguous()
         return frames, (1 if frames.dtype == torch.float32 else 0)
 
-    def vit_forward(self, frames: torch.Tensor) -> torch.Tensor:
+    def vit_forward(self, frames: torch.Tensor, want_output: bool = True) -> Optional[torch.Tensor]:
         frames, dt = self._frames(frames)
         T = frames.shape[0]
+        if not want_output:
+            _lib.check(self.lib.trace_vit_forward(self.h, _ptr(frames), dt, T, None, _stream()))
+            return None
         out = torch.empty((T, self.cfg.vision_patches, self.cfg.vision_hidden_size), dtype=torch.bfloat16, device=self.device)
         _lib.check(self.lib.trace_vit_forward(self.h, _ptr(frames), dt, T, _ptr(out), _stream()))
         return out

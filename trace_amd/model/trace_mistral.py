@@ -110,7 +110,8 @@ class TraceMistralForCausalLM:
         if heads is None:
             heads = [0] * B
         assert len(heads) == B                                                    # trace_mistral.py:245
-        if video_timestamps is None:
+        legacy_stc = video_timestamps is None and cfg.mm_projector_type == "stc_connector"
+        if video_timestamps is None and not legacy_stc:
             raise ValueError("video_timestamps is required on the TRACE path (time tokens per frame)")
         nf = cfg.num_frames if hasattr(cfg, "num_frames") else NUM_FRAMES
         vids = []
@@ -124,7 +125,17 @@ class TraceMistralForCausalLM:
         id_lists = [row.tolist() for row in ids]
         if B > eng.max_batch:
             raise ValueError(f"batch {B} exceeds the engine's max_batch {eng.max_batch}")
-        if not do_sample and not stopping_criteria:
+        if legacy_stc:
+            # legacy trace.infer() flow (trace/__init__.py:23-75): STC connector, no time tokens, text head only
+            for b in range(B):
+                eng.vit_forward(vids[b])
+                eng.stc_connector(None, vids[b].shape[0])
+                eng.prefill(b, eng.splice(id_lists[b]))
+            eng.decode_begin(list(range(B)), [0] * B, max_new_tokens, eos)
+            if max_new_tokens > 1:
+                eng.decode_steps(max_new_tokens - 1)
+            out, new_heads = eng.decode_read()
+        elif not do_sample and not stopping_criteria:
             out, new_heads = eng.generate(vids, video_timestamps, id_lists, list(heads), max_new_tokens, eos=eos)
         else:
             out, new_heads = self._generate_stepwise(vids, video_timestamps, id_lists, list(heads), max_new_tokens, eos,

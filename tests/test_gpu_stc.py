@@ -45,3 +45,21 @@ def test_stc_connector_vs_oracle():
     out, heads = eng.decode_read()
     assert len(out[0]) == 6 and all(0 <= t <= cfg.vocab_size for t in out[0])
     eng.close()
+
+
+def test_legacy_infer_api(tmp_path):
+    """trace.model_init / trace.infer (trace/__init__.py:13-75) with an STC checkpoint: text-head ids only."""
+    import numpy as np
+    import trace_amd
+    from trace_amd.model.builder import save_synthetic_checkpoint
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), mm_projector_type="stc_connector", vision_image_size=84,
+                              vision_hidden_size=256, vision_num_heads=4, mm_hidden_size=256)
+    path = save_synthetic_checkpoint(str(tmp_path / "trace-stc-tiny"), cfg)
+    model, processor, tokenizer = trace_amd.model_init(path, max_new_tokens=16)
+    raw = np.random.RandomState(0).randint(0, 255, size=(12, 40, 56, 3), dtype=np.uint8)
+    video, _ = processor(raw, fps=4.0)
+    assert video.shape == (4, 3, 84, 84)
+    out = trace_amd.infer(model, video, "what happens?", tokenizer, max_new_tokens=6)
+    assert out.shape[0] == 1 and out.shape[1] <= 6
+    assert int(out.max()) <= cfg.vocab_size            # text head + <sync> only: no time/score ids on the legacy path
+    model.engine.close()

@@ -98,7 +98,11 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
     elif isinstance(device, torch.device) and device.index is not None:
         dev_index = device.index
     T = cfg.num_frames
-    max_ctx = min(cfg.max_position_embeddings, T * cfg.tokens_per_frame + 512 + max_new_tokens)
+    if cfg.mm_projector_type == "stc_connector":
+        vis = (T // 2 + 1) * (cfg.vision_grid // 2 + 1) ** 2
+    else:
+        vis = T * cfg.tokens_per_frame
+    max_ctx = min(cfg.max_position_embeddings, vis + 512 + max_new_tokens)
     eng = TraceEngine(cfg, device=dev_index, max_batch=max_batch, max_ctx=max_ctx, max_frames=max(T, 1),
                       max_new_tokens=max_new_tokens)
     if raw.get("synthetic_weights"):

@@ -40,7 +40,7 @@ class TraceEngine:
         if max_ctx is None:
             vis = ((max_frames // 2 + 1) * (cfg.vision_grid // 2 + 1) ** 2 if cfg.mm_projector_type == "stc_connector"
                    else max_frames * cfg.tokens_per_frame)
-            max_ctx = min(cfg.max_position_embeddings, vis + 512 + max_new_tokens)
+            max_ctx = min(cfg.max_position_embeddings, vis + 1024 + max_new_tokens)
         self.max_batch, self.max_ctx, self.max_frames, self.max_new_tokens = max_batch, max_ctx, max_frames, max_new_tokens
         c = _lib.TraceConfigC(
             cfg.vocab_size, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.num_attention_heads,

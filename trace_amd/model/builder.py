@@ -102,7 +102,7 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
         vis = (T // 2 + 1) * (cfg.vision_grid // 2 + 1) ** 2
     else:
         vis = T * cfg.tokens_per_frame
-    max_ctx = min(cfg.max_position_embeddings, vis + 512 + max_new_tokens)
+    max_ctx = min(cfg.max_position_embeddings, vis + 1024 + max_new_tokens)
     eng = TraceEngine(cfg, device=dev_index, max_batch=max_batch, max_ctx=max_ctx, max_frames=max(T, 1),
                       max_new_tokens=max_new_tokens)
     if raw.get("synthetic_weights"):

@@ -117,7 +117,9 @@ int trace_op_attention(const void* Q, const void* K, const void* V, void* O, voi
                        int kv_heads, int nq, int nkv, int head_dim, int causal, float scale, void* stream);
 int trace_op_skinny_gemm(const void* X, const void* W, void* out, const void* R, int B, int N, int K, int epilogue,
                          void* stream);
-int trace_op_attn_decode(const void* q, const void* kcache, const void* vcache, const int32_t* pos, void* O, float* ws,
+/* kcache [B, nkv, max_ctx, 128] row-major; vtcache [B, nkv, 128, max_ctx] = V transposed (the engine's cache layout,
+   max_ctx % 32 == 0); pos[b] = newest position, already in both caches; q [B, nq*128] rotated; ws B*nq*nsplit*130 floats. */
+int trace_op_attn_decode(const void* q, const void* kcache, const void* vtcache, const int32_t* pos, void* O, float* ws,
                          int B, int nq, int nkv, int max_ctx, int nsplit, float scale, void* stream);
 
 #ifdef __cplusplus

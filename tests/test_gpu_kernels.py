@@ -163,6 +163,9 @@ def test_attn_decode(Bn, ctxs):
     out = ops.attn_decode(q, kc, vc, pos, 16, sc)
     out2 = ops.attn_decode(q, kc, vc, pos, 32, sc)      # second launch re-uses the ticket counters
     assert torch.equal(out, out2) or (out.float() - out2.float()).abs().max() < 2e-2
+    for ns in (1, 2, 5):                                 # 1 = the no-merge shortcut; 5 = ragged chunks
+        o3 = ops.attn_decode(q, kc, vc, pos, ns, sc)
+        assert (out.float() - o3.float()).abs().max() < 2e-2, ns
     for b, ctx in enumerate(ctxs):
         qq = q[b].view(1, 1, nq, 128)
         kk = kc[b, :, :ctx].permute(1, 0, 2).unsqueeze(0)

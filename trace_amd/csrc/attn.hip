@@ -263,7 +263,7 @@ int launch_attn_prefill(const AttnArgs& a, hipStream_t s) {
 int launch_transpose_v(const bf16_t* src, long src_bs, long src_hs, int src_rs, bf16_t* dst, long dst_bs, long dst_hs,
                        int dst_rs, int n, int hd, int heads, int batch, hipStream_t s) {
     if (dst_rs % 64 || dst_rs < n || (hd != 64 && hd != 128)) return TRACE_ERR_ARG;
-    dim3 grid(dst_rs / 64, heads, batch);
+    dim3 grid((n + 63) / 64, heads, batch);
     if (hd == 64) hipLaunchKernelGGL(transpose_v_kernel<64>, grid, dim3(256), 0, s, src, src_bs, src_hs, src_rs, dst, dst_bs, dst_hs, dst_rs, n);
     else hipLaunchKernelGGL(transpose_v_kernel<128>, grid, dim3(256), 0, s, src, src_bs, src_hs, src_rs, dst, dst_bs, dst_hs, dst_rs, n);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;

@@ -136,164 +136,216 @@ __global__ __launch_bounds__(512, 4) void skinny_gemm_kernel(const bf16_t* __res
 // ---------------------------------------------------------------------------------------------------------
 // Single-query GQA attention over the KV cache, one launch per layer: RoPE of q / the new k, the KV-cache
 // append, the split-context partial attention and the cross-split combine are all in this kernel.
-// grid (nsplit, nkv, B), 256 threads; 16 lanes per cache row (16 B each = one 256-byte row per 16-lane group),
-// every lane pre-loads its K and V rows up front so the two HBM round trips overlap.  Partials go to `ws`
+//
+// Cache layout: K row-major [slot][kvh][pos][128]; V TRANSPOSED [slot][kvh][128][ctx_stride] so that both
+// products run on the matrix cores with every lane streaming contiguous 16-byte pieces:
+//   S^T[pos, head]  = K[pos, :] . q[head, :]      A = 16 cache rows (lane: 2 x 16 B of one row), B = the 4 q heads
+//                                                 of this kv group (columns 4..15 are zero)
+//   O^T[d, head]   += V^T[d, pos] . P^T[pos, head] A = 16 rows of V^T (lane: 8 consecutive positions), B = P
+// A wave iteration covers 32 positions.  The A-row -> position map of the two S tiles is chosen so that the 8 scores
+// a lane ends up holding (2 tiles x 4 accumulator registers) are 8 CONSECUTIVE positions — exactly the k-slots the
+// second MFMA wants for that lane — so P never leaves registers (the swapped-operand flash-attention trick).
+// (The previous VALU formulation spent ~200 VALU ops per cache row per lane and capped at 3.3 TB/s of cache stream.)
+//
+// grid (nsplit, nkv, B), 256 threads = 4 waves, wave w takes 32-position blocks w, w+4, ... of the split's chunk
+// (16 KB of K + V^T per block, re-requested as soon as the registers are free).  Partials go to `ws`
 // ([b][q-head][split][hd + 2] fp32) with write-through (sc1) stores; every wave drains vmcnt, then one lane takes
 // an agent-scope ticket; the last-arriving workgroup of a (b, kv-head) pair does ONE agent-scope acquire and merges
 // the splits (placement-independent: no assumption on dispatch order or XCD), then re-zeroes the ticket.
-__global__ __launch_bounds__(256, 2) void attn_decode_kernel(const bf16_t* __restrict__ qkv, int ldq, bf16_t* __restrict__ kcache,
-                                                             bf16_t* __restrict__ vcache, long slot_stride, long kv_head_stride,
-                                                             const int32_t* __restrict__ slots, const int32_t* __restrict__ pos,
-                                                             float* __restrict__ ws, unsigned int* __restrict__ tickets,
-                                                             bf16_t* __restrict__ O, int ldo, int nq, int nkv, int nsplit,
-                                                             float scale, int fuse_rope, const float* __restrict__ cos_t,
-                                                             const float* __restrict__ sin_t, int dbg) {
-    constexpr int HD = 128, GQ = 4, PF = 4;          // PF = cache rows per 16-lane group per prefetch batch
-    __shared__ float s_acc[4][GQ][HD];
+// Masked positions contribute p = 0 times whatever the cache holds there: the caches are zero-initialised and only
+// ever hold finite values.
+__global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __restrict__ qkv, int ldq, bf16_t* __restrict__ kcache,
+                                                             bf16_t* __restrict__ vtcache, long slot_stride, long kv_head_stride,
+                                                             int ctx_stride, const int32_t* __restrict__ slots,
+                                                             const int32_t* __restrict__ pos, float* __restrict__ ws,
+                                                             unsigned int* __restrict__ tickets, bf16_t* __restrict__ O, int ldo,
+                                                             int nq, int nkv, int nsplit, float scale, int fuse_rope,
+                                                             const float* __restrict__ cos_t, const float* __restrict__ sin_t, int dbg) {
+    constexpr int HD = 128, GQ = 4;
+    __shared__ __attribute__((aligned(16))) float s_acc[4][GQ][HD];
     __shared__ float s_m[4][GQ], s_l[4][GQ];
+    __shared__ __attribute__((aligned(16))) bf16_t s_new[2 * HD];   // roped k | v of the newest position (owner split)
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int j = lane >> 4, c = lane & 15;
+    const int i = lane & 15, g = lane >> 4;          // i: A-row / head column; g: k-group
     const int sp = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
     const int p_new = pos[b];
     const int ctx = p_new + 1;
     int chunk = (ctx + nsplit - 1) / nsplit;
-    chunk = (chunk + 15) & ~15;
+    chunk = (chunk + 31) & ~31;
     const int beg = sp * chunk, end = min(ctx, beg + chunk);
     const int len = max(end - beg, 0);
-    const int nit = (len + 15) >> 4;                  // 16 rows per workgroup iteration (4 waves x 4 groups)
+    const int nit = (len + 31) >> 5;                  // 32-position blocks in this split
     bf16_t* kb = kcache + (size_t)slots[b] * slot_stride + (size_t)kvh * kv_head_stride;
-    bf16_t* vb = vcache + (size_t)slots[b] * slot_stride + (size_t)kvh * kv_head_stride;
+    bf16_t* vb = vtcache + (size_t)slots[b] * slot_stride + (size_t)kvh * kv_head_stride;
+    const bf16_t* row = qkv + (size_t)b * ldq;
+    const bool owner = fuse_rope && len > 0 && end == ctx;       // this split holds the newest position
 
-    uint4 kA[PF], vA[PF], kB[PF], vB[PF];
-    auto load = [&](uint4 (&kr)[PF], uint4 (&vr)[PF], int it0) {
+    const int prow = (i >> 2) * 8 + (i & 3);          // + 4 t: position (within the block) of A-row i of S tile t
+    const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+    u32x4_t kr[2][4], vr[8];
+    auto load_k = [&](int it) {
+        const int P0 = beg + it * 32;
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int i = (it0 + u) * 16 + wid * 4 + j;
-            const bool ok = i < len && !(fuse_rope && beg + i == p_new);
-            kr[u] = ok ? *reinterpret_cast<const uint4*>(kb + (size_t)(beg + i) * HD + c * 8) : make_uint4(0, 0, 0, 0);
-            vr[u] = ok ? *reinterpret_cast<const uint4*>(vb + (size_t)(beg + i) * HD + c * 8) : make_uint4(0, 0, 0, 0);
+        for (int t = 0; t < 2; ++t) {
+            const int p = P0 + prow + 4 * t;
+            const bool ok = p < end && !(fuse_rope && p == p_new);
+            const bf16_t* src = kb + (size_t)p * HD + g * 16;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+                kr[t][s4] = ok ? *reinterpret_cast<const u32x4_t*>(src + (s4 >> 1) * 64 + (s4 & 1) * 8) : zero4;
         }
     };
-    if (nit > 0) load(kA, vA, 0);                     // cache rows start streaming before anything else
+    auto load_v = [&](int it) {
+        const int P0 = beg + it * 32;
+        const bool vok = P0 + g * 8 < end;
+        const bf16_t* vsrc = vb + (size_t)i * ctx_stride + P0 + g * 8;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+            vr[dt] = vok ? *reinterpret_cast<const u32x4_t*>(vsrc + (size_t)dt * 16 * ctx_stride) : zero4;
+    };
+    if (wid < nit) { load_k(wid); load_v(wid); }      // cache blocks start streaming before anything else
 
-    // ---- q (4 heads of this kv group) and, when fused, RoPE + the new k/v row ----
-    float qv[GQ][8];
-    uint4 knew = make_uint4(0, 0, 0, 0), vnew = make_uint4(0, 0, 0, 0);
-    {
-        const bf16_t* row = qkv + (size_t)b * ldq;
-        float cs[8], sn[8];
-        if (fuse_rope) {
-            const float4* cp = reinterpret_cast<const float4*>(cos_t + (size_t)p_new * (HD / 2) + (c & 7) * 8);
-            const float4* sq = reinterpret_cast<const float4*>(sin_t + (size_t)p_new * (HD / 2) + (c & 7) * 8);
+    // rotate-half RoPE of a head's four 8-wide slices held by this lane: d = sp*64 + g*16 + hf*8 + e (its partner
+    // d +- 64 is the same lane's other sp), rounded to bf16 like the stored q / k
+    auto rope_head = [&](const bf16_t* head, u32x4_t (&out)[4]) {
+        u32x4_t x[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) x[s4] = *reinterpret_cast<const u32x4_t*>(head + (s4 >> 1) * 64 + g * 16 + (s4 & 1) * 8);
+        if (!fuse_rope) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) out[s4] = x[s4];
+            return;
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const float4* cp = reinterpret_cast<const float4*>(cos_t + (size_t)p_new * (HD / 2) + g * 16 + hf * 8);
+            const float4* sq = reinterpret_cast<const float4*>(sin_t + (size_t)p_new * (HD / 2) + g * 16 + hf * 8);
             const float4 c0 = cp[0], c1 = cp[1], s0 = sq[0], s1 = sq[1];
-            cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
-            sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
-        }
-        const float sgn = c < 8 ? -1.f : 1.f;      // first half: x*cos - partner*sin ; second half: x*cos + partner*sin
-        auto rot = [&](const bf16_t* head, float* out) {
-            const uint4 u = *reinterpret_cast<const uint4*>(head + c * 8);
-            const float x[8] = {bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y), bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
-            if (!fuse_rope) {
+            const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) out[e] = x[e];
-                return;
-            }
-            const uint4 w = *reinterpret_cast<const uint4*>(head + (c ^ 8) * 8);
-            const float y[8] = {bflo(w.x), bfhi(w.x), bflo(w.y), bfhi(w.y), bflo(w.z), bfhi(w.z), bflo(w.w), bfhi(w.w)};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) out[e] = bf2f(f2bf(x[e] * cs[e] + sgn * y[e] * sn[e]));   // bf16 like the stored q/k
-        };
-#pragma unroll
-        for (int hq = 0; hq < GQ; ++hq) rot(row + (size_t)(kvh * GQ + hq) * HD, qv[hq]);
-        if (fuse_rope) {
-            float kn[8];
-            rot(row + (size_t)(nq + kvh) * HD, kn);
-            knew = make_uint4(pack2bf(kn[0], kn[1]), pack2bf(kn[2], kn[3]), pack2bf(kn[4], kn[5]), pack2bf(kn[6], kn[7]));
-            vnew = *reinterpret_cast<const uint4*>(row + (size_t)(nq + nkv + kvh) * HD + c * 8);
-            if (len > 0 && end == ctx && wid == 0 && j == 0) {      // the split that owns the newest row appends it to the cache
-                *reinterpret_cast<uint4*>(kb + (size_t)p_new * HD + c * 8) = knew;
-                *reinterpret_cast<uint4*>(vb + (size_t)p_new * HD + c * 8) = vnew;
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t a = x[hf][e], bb = x[2 + hf][e];
+                const float x1l = bflo(a), x1h = bfhi(a), x2l = bflo(bb), x2h = bfhi(bb);
+                out[hf][e] = pack2bf(x1l * cs[2 * e] - x2l * sn[2 * e], x1h * cs[2 * e + 1] - x2h * sn[2 * e + 1]);
+                out[2 + hf][e] = pack2bf(x2l * cs[2 * e] + x1l * sn[2 * e], x2h * cs[2 * e + 1] + x1h * sn[2 * e + 1]);
             }
         }
+    };
+    u32x4_t qf[4];                                    // B operand of S: q of head i (i < 4), zero columns otherwise
+    if (i < GQ) rope_head(row + (size_t)(kvh * GQ + i) * HD, qf);
+    else {
 #pragma unroll
-        for (int hq = 0; hq < GQ; ++hq)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qv[hq][e] *= scale;
+        for (int s4 = 0; s4 < 4; ++s4) qf[s4] = zero4;
     }
-    // ---- online softmax per 16-lane group: running max m, sum l, and this lane's 8-wide slice of o, per q-head ----
-    float m[GQ], l[GQ], acc[GQ][8];
+    if (owner) {       // the newest row: append to the caches (K row-major, V down a column of V^T) and park it in LDS
+        if (wid == 0 && i == 0) {
+            u32x4_t kn[4];
+            rope_head(row + (size_t)(nq + kvh) * HD, kn);
 #pragma unroll
-    for (int hq = 0; hq < GQ; ++hq) {
-        m[hq] = -1e30f; l[hq] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[hq][e] = 0.f;
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int d0 = (s4 >> 1) * 64 + g * 16 + (s4 & 1) * 8;
+                *reinterpret_cast<u32x4_t*>(kb + (size_t)p_new * HD + d0) = kn[s4];
+                *reinterpret_cast<u32x4_t*>(&s_new[d0]) = kn[s4];
+            }
+        }
+        if (tid >= 128) {
+            const bf16_t x = row[(size_t)(nq + nkv + kvh) * HD + tid - 128];
+            vb[(size_t)(tid - 128) * ctx_stride + p_new] = x;
+            s_new[HD + tid - 128] = x;
+        }
+        __syncthreads();                              // workgroup-uniform branch
     }
-    auto process = [&](uint4 (&kr)[PF], uint4 (&vr)[PF], int it0) {
+
+    float m = -1e30f, l = 0.f;                        // running max (per head = per column i) and this lane's partial sum
+    f32x4_t acc[8];                                   // O^T tile dt: lane (i, g) reg r  <->  d = dt*16 + g*4 + r, head i
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            if (it0 + u >= nit) break;
-            const int i = (it0 + u) * 16 + wid * 4 + j;
-            const bool fresh = fuse_rope && beg + i == p_new;
-            const uint4 ku = fresh ? knew : kr[u];
-            const uint4 vu = fresh ? vnew : vr[u];
-            const float kv[8] = {bflo(ku.x), bfhi(ku.x), bflo(ku.y), bfhi(ku.y), bflo(ku.z), bfhi(ku.z), bflo(ku.w), bfhi(ku.w)};
-            const float vv[8] = {bflo(vu.x), bfhi(vu.x), bflo(vu.y), bfhi(vu.y), bflo(vu.z), bfhi(vu.z), bflo(vu.w), bfhi(vu.w)};
+    for (int dt = 0; dt < 8; ++dt) acc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // single register set, refilled as soon as the MFMAs that read it have issued: the next block's K streams in
+    // during this block's softmax + PV, its V^T during the next block's QK (3 waves/SIMD cover the rest)
+    for (int it = wid; it < nit; it += 4) {
+        const int P0 = beg + it * 32;
+        if (fuse_rope && p_new >= P0 && p_new < P0 + 32) {          // wave-uniform: splice the newest k / v (parked in LDS)
+            const int o = p_new - P0;
 #pragma unroll
-            for (int hq = 0; hq < GQ; ++hq) {
-                float sc = 0.f;
+            for (int t = 0; t < 2; ++t)
+                if (prow + 4 * t == o) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sc += qv[hq][e] * kv[e];
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        kr[t][s4] = *reinterpret_cast<const u32x4_t*>(&s_new[(s4 >> 1) * 64 + g * 16 + (s4 & 1) * 8]);
+                }
+            if (g == (o >> 3)) {
+                const int wsel = (o & 7) >> 1, hi = o & 1;
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) sc += __shfl_xor(sc, o, 64);
-                if (i < len) {
-                    const float mn = fmaxf(m[hq], sc);
-                    const float a = __expf(m[hq] - mn), p = __expf(sc - mn);
-                    m[hq] = mn;
-                    l[hq] = l[hq] * a + p;
+                for (int dt = 0; dt < 8; ++dt) {
+                    const uint32_t x = s_new[HD + dt * 16 + i];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[hq][e] = acc[hq][e] * a + p * vv[e];
+                    for (int w = 0; w < 4; ++w) {
+                        const uint32_t old = vr[dt][w];
+                        const uint32_t ins = hi ? ((old & 0xffffu) | (x << 16)) : ((old & 0xffff0000u) | x);
+                        vr[dt][w] = (w == wsel) ? ins : old;
+                    }
                 }
             }
         }
-    };
-    for (int it0 = 0; it0 < nit; it0 += 2 * PF) {
-        if (it0 + PF < nit) load(kB, vB, it0 + PF);
-        process(kA, vA, it0);
-        if (it0 + PF < nit) {
-            if (it0 + 2 * PF < nit) load(kA, vA, it0 + 2 * PF);
-            process(kB, vB, it0 + PF);
+        f32x4_t S[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            S[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+                S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kr[t][s4]),
+                                                               __builtin_bit_cast(bf16x8_t, qf[s4]), S[t], 0, 0, 0);
         }
+        if (it + 4 < nit) load_k(it + 4);
+        // lane (head i, group g): S[t][r] is the score of position P0 + g*8 + t*4 + r
+        float sv[8];
+        float mx = -1e30f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = P0 + g * 8 + e < end;
+            sv[e] = ok ? S[e >> 2][e & 3] * scale : -1e30f;
+            mx = fmaxf(mx, sv[e]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float a = __expf(m - mn);
+        m = mn;
+        float p[8], ps = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            p[e] = (P0 + g * 8 + e < end) ? __expf(sv[e] - mn) : 0.f;
+            ps += p[e];
+        }
+        l = l * a + ps;
+        const u32x4_t pf = {pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])};
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            acc[dt] *= a;
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vr[dt]),
+                                                              __builtin_bit_cast(bf16x8_t, pf), acc[dt], 0, 0, 0);
+        }
+        if (it + 4 < nit) load_v(it + 4);
     }
-    // ---- merge the 4 groups of the wave (xor 16, 32), then the 4 waves through LDS ----
+    // ---- the k-groups of a wave share m; sum their l; then merge the 4 waves through LDS ----
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (i < GQ) {
 #pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-#pragma unroll
-        for (int hq = 0; hq < GQ; ++hq) {
-            const float mo = __shfl_xor(m[hq], o, 64), lo = __shfl_xor(l[hq], o, 64);
-            const float M = fmaxf(m[hq], mo);
-            const float fa = __expf(m[hq] - M), fb = __expf(mo - M);
-            l[hq] = l[hq] * fa + lo * fb;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[hq][e] = acc[hq][e] * fa + __shfl_xor(acc[hq][e], o, 64) * fb;
-            m[hq] = M;
-        }
-    }
-    if (j == 0) {
-#pragma unroll
-        for (int hq = 0; hq < GQ; ++hq) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s_acc[wid][hq][c * 8 + e] = acc[hq][e];
-            if (c == 0) { s_m[wid][hq] = m[hq]; s_l[wid][hq] = l[hq]; }
-        }
+        for (int dt = 0; dt < 8; ++dt)
+            *reinterpret_cast<f32x4_t*>(&s_acc[wid][i][dt * 16 + g * 4]) = acc[dt];
+        if (g == 0) { s_m[wid][i] = m; s_l[wid][i] = l; }
     }
     __syncthreads();
     if (dbg == 2) return;
     {
         const size_t base = (((size_t)b * nq + kvh * GQ) * nsplit + sp) * (HD + 2);
         // write-through (sc1) stores: visible at agent scope once vmcnt drains, no L2 write-back fence needed
-        for (int i = tid; i < GQ * HD; i += 256) {
-            const int hq = i >> 7, d = i & 127;
+        for (int x = tid; x < GQ * HD; x += 256) {
+            const int hq = x >> 7, d = x & 127;
             const float M = fmaxf(fmaxf(s_m[0][hq], s_m[1][hq]), fmaxf(s_m[2][hq], s_m[3][hq]));
             float o = 0.f, L = 0.f;
 #pragma unroll
@@ -302,6 +354,10 @@ __global__ __launch_bounds__(256, 2) void attn_decode_kernel(const bf16_t* __res
                 o += f * s_acc[w][hq][d];
                 L += f * s_l[w][hq];
             }
+            if (nsplit == 1) {                        // nothing to merge across workgroups: finish here
+                O[(size_t)b * ldo + (kvh * GQ + hq) * HD + d] = f2bf(o / L);
+                continue;
+            }
             __hip_atomic_store(&ws[base + (size_t)hq * nsplit * (HD + 2) + d], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (d == 0) {
                 __hip_atomic_store(&ws[base + (size_t)hq * nsplit * (HD + 2) + HD], M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -309,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void attn_decode_kernel(const bf16_t* __res
             }
         }
     }
-    if (dbg == 1) return;
+    if (dbg == 1 || nsplit == 1) return;
     // ---- publish + ticket; the last arriver of this (b, kv-head) merges the splits ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -540,13 +596,13 @@ int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_
 }
 
 int g_attn_debug = 0;   // microbenchmark-only phase cut-offs (0 = full kernel)
-int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vcache, long slot_stride, long kv_head_stride,
-                       const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,
+int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vtcache, long slot_stride, long kv_head_stride,
+                       int ctx_stride, const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,
                        int nq, int nkv, int hd, int nsplit, float scale, int fuse_rope, const float* cos_t, const float* sin_t,
                        hipStream_t s) {
-    if (hd != 128 || nq != 4 * nkv || nsplit < 1 || B < 1 || !tickets) return TRACE_ERR_ARG;
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv, B), dim3(256), 0, s, qkv, ldq, kcache, vcache, slot_stride,
-                       kv_head_stride, slots, pos, ws, tickets, O, ldo, nq, nkv, nsplit, scale, fuse_rope, cos_t, sin_t,
+    if (hd != 128 || nq != 4 * nkv || nsplit < 1 || B < 1 || !tickets || ctx_stride % 32) return TRACE_ERR_ARG;
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv, B), dim3(256), 0, s, qkv, ldq, kcache, vtcache, slot_stride,
+                       kv_head_stride, ctx_stride, slots, pos, ws, tickets, O, ldo, nq, nkv, nsplit, scale, fuse_rope, cos_t, sin_t,
                        g_attn_debug);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }

@@ -49,7 +49,7 @@ struct trace_ctx {
     bf16_t *embed, *final_norm, *wheads, *time_tab, *score_tab, *sync_row;
     std::vector<LlmLayer> llm;
     float *slot_cos, *slot_sin, *rope_cos, *rope_sin;
-    // KV cache: [layer][slot][kvh][max_ctx][hd]
+    // KV cache: K [layer][slot][kvh][ctx_pad][hd] row-major; V TRANSPOSED [layer][slot][kvh][hd][ctx_pad] (decode.hip)
     bf16_t *kcache, *vcache;
     size_t kv_head_stride, slot_stride, layer_stride;
     // ViT workspaces
@@ -57,7 +57,7 @@ struct trace_ctx {
     bf16_t *sl_res, *sl_out, *video;     // [T*S, vh], [T*S, H], [T*TPF, H]
     int video_rows = 0;
     // LLM prefill workspaces
-    bf16_t *pX, *pH, *pQKV, *pVT, *pO, *pACT;
+    bf16_t *pX, *pH, *pQKV, *pO, *pACT;
     int32_t *d_kind, *d_row;             // splice index arrays (max_ctx)
     int32_t *h_kind, *h_row;             // pinned host staging
     int spliced_len = 0;
@@ -171,7 +171,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     A(c->slot_cos, (size_t)c->GG * vh / 2); A(c->slot_sin, (size_t)c->GG * vh / 2);
     A(c->rope_cos, (size_t)c->max_ctx * c->HD / 2); A(c->rope_sin, (size_t)c->max_ctx * c->HD / 2);
     // --- KV cache ---
-    c->kv_head_stride = (size_t)c->max_ctx * c->HD;
+    c->kv_head_stride = (size_t)c->ctx_pad * c->HD;
     c->slot_stride = c->kv_head_stride * c->NKV;
     c->layer_stride = c->slot_stride * c->max_B;
     A(c->kcache, c->layer_stride * c->NL); A(c->vcache, c->layer_stride * c->NL);
@@ -190,7 +190,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     }
     // --- prefill workspaces ---
     const size_t Lm = c->max_ctx;
-    A(c->pX, Lm * H); A(c->pH, Lm * H); A(c->pQKV, Lm * c->QKV); A(c->pVT, (size_t)c->NKV * c->HD * c->ctx_pad);
+    A(c->pX, Lm * H); A(c->pH, Lm * H); A(c->pQKV, Lm * c->QKV);
     A(c->pO, Lm * H); A(c->pACT, Lm * I);
     A(c->d_kind, Lm); A(c->d_row, Lm);
     // --- decode ---
@@ -628,10 +628,10 @@ extern "C" int trace_llm_prefill(trace_ctx* c, int slot, const void* embeds, int
     if (embeds) HIPCHK(hipMemcpyAsync(c->pX, embeds, (size_t)L * H * 2, hipMemcpyDeviceToDevice, s));
     const int Lpad = round_up(L, 64);
     AttnArgs a{};
-    a.Q = c->pQKV; a.V = c->pVT; a.O = c->pO;
+    a.Q = c->pQKV; a.O = c->pO;
     a.q_bs = 0; a.q_hs = HD; a.q_rs = QKV;
     a.k_bs = 0; a.k_hs = (long)c->kv_head_stride; a.k_rs = HD;
-    a.v_bs = 0; a.v_hs = (long)HD * Lpad; a.v_rs = Lpad;
+    a.v_bs = 0; a.v_hs = (long)c->kv_head_stride; a.v_rs = c->ctx_pad;      // V^T straight from the cache
     a.o_bs = 0; a.o_hs = HD; a.o_rs = H;
     a.nq_rows = L; a.nkv_rows = L; a.batch = 1; a.heads = c->NQ; a.kv_heads = c->NKV;
     a.scale = 1.0f / sqrtf((float)HD); a.causal = 1;
@@ -641,11 +641,13 @@ extern "C" int trace_llm_prefill(trace_ctx* c, int slot, const void* embeds, int
         bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
         LCHK(launch_rmsnorm(c->pX, H, c->pH, H, W.rms1, L, H, c->c.rms_eps, s));
         TRY(gemm(c->pH, H, W.wqkv, H, c->pQKV, QKV, nullptr, nullptr, 0, L, QKV, H, EPI_NONE, s));
-        LCHK(launch_rope_kv(c->pQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, nullptr, nullptr, slot, 0, L,
+        LCHK(launch_rope_kv(c->pQKV, QKV, kc, nullptr, (long)c->slot_stride, (long)c->kv_head_stride, nullptr, nullptr, slot, 0, L,
                             c->NQ, c->NKV, HD, c->rope_cos, c->rope_sin, s));
-        LCHK(launch_transpose_v(c->pQKV + (size_t)(c->NQ + c->NKV) * HD, 0, HD, QKV, c->pVT, 0, (long)HD * Lpad, Lpad, L, HD,
-                                c->NKV, 1, s));
+        // V goes into the cache transposed ([kvh][hd][ctx_pad]; positions L..Lpad-1 are zero-filled, later overwritten)
+        LCHK(launch_transpose_v(c->pQKV + (size_t)(c->NQ + c->NKV) * HD, 0, HD, QKV, vc + (size_t)slot * c->slot_stride, 0,
+                                (long)c->kv_head_stride, c->ctx_pad, L, HD, c->NKV, 1, s));
         a.K = kc + (size_t)slot * c->slot_stride;
+        a.V = vc + (size_t)slot * c->slot_stride;
         LCHK(launch_attn_prefill(a, s));
         TRY(gemm(c->pO, H, W.wo, H, c->pX, H, nullptr, c->pX, H, L, H, H, EPI_RESIDUAL, s));
         LCHK(launch_rmsnorm(c->pX, H, c->pH, H, W.rms2, L, H, c->c.rms_eps, s));
@@ -682,9 +684,10 @@ static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* l
     return select_only(c, advance, s);
 }
 
-// decode attention context split: ~256-512 workgroups (8 kv heads x B x nsplit) keep every CU busy without paying
-// the per-workgroup latency chain more often than needed
-static int decode_nsplit(int B) { return B <= 1 ? 32 : B <= 2 ? 16 : B <= 8 ? 8 : B <= 16 ? 4 : 2; }
+// decode attention context split: ~256-320 workgroups (8 kv heads x B x nsplit) fill the CUs; more splits only add
+// partial-result traffic and ticket latency (measured, ctx 2100: B=1 16 splits 10.4 us, B=4 8 -> 13 us, B=16 2 -> 26 us,
+// B=32 1 -> 45 us; B=32 with 16 splits: 79 us)
+static int decode_nsplit(int B) { const int n = (40 + B / 2) / B; return n < 1 ? 1 : n > 16 ? 16 : n; }
 
 // one decode step for the current batch: consumes dX (embedding of the last token), leaves the next one in dX
 static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
@@ -697,7 +700,7 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
         //  workgroups cost more than this one 6 us row kernel — 65 us vs 52 + 6 us for the gate|up GEMV)
         LCHK(launch_rmsnorm(c->dX, H, c->dH, H, W.rms1, B, H, c->c.rms_eps, s));
         LCHK(launch_skinny_gemm(c->dH, H, W.wqkv, H, c->dQKV, QKV, nullptr, 0, B, QKV, H, EPI_NONE, s));
-        LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->d_slots, c->d_pos, c->dO,
+        LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots, c->d_pos, c->dO,
                                 H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, decode_nsplit(B), 1.0f / sqrtf((float)HD), 1,
                                 c->rope_cos, c->rope_sin, s));
         LCHK(launch_skinny_gemm(c->dO, H, W.wo, H, c->dX, H, c->dX, H, B, H, H, EPI_RESIDUAL, s));
@@ -890,8 +893,8 @@ extern "C" int trace_op_skinny_gemm(const void* X, const void* W, void* out, con
                             (hipStream_t)stream));
     return TRACE_OK;
 }
-// kcache/vcache [B, nkv, max_ctx, 128]; pos[b] = index of the newest token (ctx = pos+1), already in the cache;
-// q [B, nq*128] ready (rotated).  ws: B*nq*nsplit*130 floats.
+// kcache [B, nkv, max_ctx, 128]; vtcache [B, nkv, 128, max_ctx] (V transposed; max_ctx % 32 == 0); pos[b] = index of the
+// newest token (ctx = pos+1), already in the caches; q [B, nq*128] ready (rotated).  ws: B*nq*nsplit*130 floats.
 extern "C" int trace_op_attn_decode(const void* q, const void* kcache, const void* vcache, const int32_t* pos, void* O, float* ws,
                                     int B, int nq, int nkv, int max_ctx, int nsplit, float scale, void* stream) {
     static int32_t* d_slots = nullptr;
@@ -905,7 +908,7 @@ extern "C" int trace_op_attn_decode(const void* q, const void* kcache, const voi
         HIPCHK(hipMemset(d_tickets, 0, 32 * 64 * 4));
     }
     LCHK(launch_attn_decode((const bf16_t*)q, nq * 128, (bf16_t*)kcache, (bf16_t*)vcache, (long)nkv * max_ctx * 128,
-                            (long)max_ctx * 128, d_slots, pos, (bf16_t*)O, nq * 128, ws, d_tickets, B, nq, nkv, 128, nsplit, scale, 0,
+                            (long)max_ctx * 128, max_ctx, d_slots, pos, (bf16_t*)O, nq * 128, ws, d_tickets, B, nq, nkv, 128, nsplit, scale, 0,
                             nullptr, nullptr, (hipStream_t)stream));
     return TRACE_OK;
 }

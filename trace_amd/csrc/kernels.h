@@ -79,8 +79,8 @@ int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_
 // fuse_rope = 1: `qkv` rows are the raw [q | k | v] projections of the new token: q and the new k are rotated here
 // (RoPE at pos[b]) and k/v appended to the cache at row pos[b].  fuse_rope = 0: `qkv` holds ready q rows (ld ldq)
 // and the cache already contains row pos[b].  tickets: zeroed uint32 [B*nkv].  O [B, nq*hd].
-int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vcache, long slot_stride, long kv_head_stride,
-                       const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,
+int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vtcache, long slot_stride, long kv_head_stride,
+                       int ctx_stride, const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,
                        int nq, int nkv, int hd, int nsplit, float scale, int fuse_rope, const float* cos_t, const float* sin_t,
                        hipStream_t s);
 // heads: logits over [text V+1 | time Tv | score Sv] rows of Wh [NV_pad, H]; only tiles intersecting an active

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(bf16_t* __restrict__ qkv, 
         bf16_t* x = qkv + (size_t)r * ld + (size_t)hh * hd;
         const uint4 u1 = *reinterpret_cast<const uint4*>(x + c * 8);
         const uint4 u2 = *reinterpret_cast<const uint4*>(x + half + c * 8);
-        if (hh >= nq + nkv) {   // V: plain copy into the cache
+        if (hh >= nq + nkv) {   // V: plain copy into a row-major cache (the engine's V^T cache is written by transpose_v / attn_decode)
+            if (!vcache) continue;
             bf16_t* dst = vcache + (size_t)slot * slot_stride + (size_t)(hh - nq - nkv) * kv_head_stride + (size_t)pos * hd;
             *reinterpret_cast<uint4*>(dst + c * 8) = u1;
             *reinterpret_cast<uint4*>(dst + half + c * 8) = u2;

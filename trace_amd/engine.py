@@ -288,9 +288,13 @@ class ops:
         return out
 
     @staticmethod
-    def attn_decode(q, kcache, vcache, pos, nsplit, scale):
-        """q [B, nq*128]; caches [B, nkv, max_ctx, 128]; pos int32 [B] (device)"""
+    def attn_decode(q, kcache, vcache, pos, nsplit, scale, vtcache=None):
+        """q [B, nq*128]; caches [B, nkv, max_ctx, 128]; pos int32 [B] (device).  The kernel reads V transposed
+        ([B, nkv, 128, max_ctx], the engine's cache layout): built here unless `vtcache` is passed."""
         lib = _lib.load()
+        if vtcache is None:
+            vtcache = vcache.transpose(2, 3).contiguous()
+        vcache = vtcache
         Bn = q.shape[0]
         nkv, max_ctx = kcache.shape[1], kcache.shape[2]
         nq = q.shape[1] // 128

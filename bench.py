@@ -160,7 +160,7 @@ def main():
             "stages_ms": {"vit_slotpool_per_video": t_enc, "prefill_per_video": t_pre, f"decode_{n_new - 1}_steps_batch{B}": t_dec,
                           "decode_ms_per_step": t_dec / (n_new - 1), "weights_load_s": t_load},
             "mfma_util": {"vit": vit_flops / (t_enc * 1e-3) / 2.5e15, "prefill": pre_flops / (t_pre * 1e-3) / 2.5e15},
-            "roofline": {"bound": "hbm", "kernel": "skinny_gemm_kernel<EPI_SWIGLU> (decode gate|up GEMV, 1 launch/layer/step)",
+            "roofline": {"bound": "hbm", "kernel": "skinny_lds_kernel<EPI_PARTIAL,NB,NT=2> (decode gate|up GEMV, 1 launch/layer/step)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
                          "traffic": traffic, "algorithmic_bytes_per_launch": k_bytes, "avg_launch_ms": k_ms, "samples": k_n},
         }

@@ -140,7 +140,7 @@ def test_attention_prefill_causal_gqa(L, kvh):
 
 
 @pytest.mark.parametrize("Bn,N,K", [(1, 128, 256), (1, 4096, 4096), (3, 6144, 4096), (16, 256, 14336), (2, 512, 128),
-                                    (17, 256, 4096), (32, 512, 14336), (25, 6144, 4096)])
+                                    (17, 256, 4096), (32, 512, 14336), (25, 6144, 4096), (20, 16384, 256)])
 def test_skinny_gemm(Bn, N, K):
     X, W, R = rnd(Bn, K), rnd(N, K, scale=0.05), rnd(Bn, N)
     lin = X.float() @ W.float().t()
@@ -151,6 +151,26 @@ def test_skinny_gemm(Bn, N, K):
         Wp = torch.stack([Wg.reshape(-1, 16, K), Wu.reshape(-1, 16, K)], dim=1).reshape(N, K).contiguous()
         g, u = X.float() @ Wg.float().t(), X.float() @ Wu.float().t()
         check("skinny swiglu", ops.skinny_gemm(X, Wp, epilogue=E.EPI_SWIGLU), torch.nn.functional.silu(g) * u, 3e-2, 1e-2)
+        if K % 64 == 0:
+            sw = ops.skinny_gemm(X, ops.tile_pack(Wp), epilogue=E.EPI_SWIGLU, tiled=True)
+            assert torch.equal(sw, ops.skinny_gemm(X, Wp, epilogue=E.EPI_SWIGLU)), "tile layout changes the result"
+            pg = ops.skinny_gemm(X, ops.tile_pack(Wp), epilogue=E.EPI_PARTIAL, tiled=True)     # the engine's path: partial rows + combine
+            check("skinny partial + swiglu combine", ops.swiglu_combine(pg, Bn), torch.nn.functional.silu(g) * u, 3e-2, 1e-2)
+    # the decode weight layout is a pure permutation: bit-identical results
+    Wt = ops.tile_pack(W)
+    assert torch.equal(ops.skinny_gemm(X, Wt, tiled=True), ops.skinny_gemm(X, W))
+    # fp32 k-chunk partial rows + the fused residual add / RMSNorm consumer (the o-proj / down-proj path of a decode step)
+    if N <= 4096:
+        part = ops.skinny_gemm(X, Wt, epilogue=E.EPI_PARTIAL, tiled=True)
+        tot = part.sum(0)[:Bn]
+        check("skinny partial", tot, lin, 2e-3, 1e-3)
+        w = rnd(N, seed=9)
+        x, y = ops.add_rmsnorm(part, R, w, 1e-5)
+        xr = (tot.to(torch.bfloat16).float() + R.float()).to(torch.bfloat16)
+        assert (x.float() - xr.float()).abs().max().item() <= 2 ** -6 * xr.float().abs().max().item()
+        xf = x.float()
+        yr = xf * torch.rsqrt((xf * xf).mean(-1, keepdim=True) + 1e-5) * w.float()
+        check("add_rmsnorm", y, yr, 2e-2, 1e-2)
 
 
 @pytest.mark.parametrize("Bn,ctxs", [(1, [80]), (3, [1, 200, 2047]), (2, [16, 17])])

@@ -53,7 +53,11 @@ SIGNATURES = {
     "trace_op_layernorm": (I, [P, P, P, P, I, I, F, P]),
     "trace_op_rmsnorm": (I, [P, P, P, I, I, F, P]),
     "trace_op_attention": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
-    "trace_op_skinny_gemm": (I, [P, P, P, P, I, I, I, I, P]),
+    "trace_op_skinny_gemm": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "trace_op_skinny_ks": (I, [I, I, I, I]),
+    "trace_op_tile_pack": (I, [P, P, I, I, P]),
+    "trace_op_swiglu_combine": (I, [P, I, I, P, I, P]),
+    "trace_op_add_rmsnorm": (I, [P, I, P, P, P, P, I, I, F, P]),
     "trace_op_attn_decode": (I, [P, P, P, P, P, P, I, I, I, I, I, F, P]),
 }
 

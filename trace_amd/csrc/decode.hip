@@ -12,6 +12,10 @@
 // head_logits / select_next:  active-head GEMV, masked arg-max (trace_mistral.py:244-252 + HF greedy), the
 //   head-switch state machine (trace_mistral.py:86-88,336-344) and the next-token embedding
 //   (trace_arch.py:345-375) — all on device, so a decode step never returns to the host.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -30,7 +34,7 @@ template <int EPI, int NB>
 __global__ __launch_bounds__(512, 4) void skinny_gemm_kernel(const bf16_t* __restrict__ X, int ldx,
                                                                             const bf16_t* __restrict__ W, int ldw,
                                                                             bf16_t* __restrict__ out, int ldo,
-                                                                            const bf16_t* __restrict__ R, int ldr, int B, int N, int K) {
+                                                                            const bf16_t* __restrict__ R, int ldr, int B, int N, int K, int dbg) {
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;      // 16-row weight tiles per workgroup
     constexpr int UN = NB == 1 ? 2 : 1;                  // 64-wide k units per load batch (keeps <= 128 VGPRs: 2 workgroups/CU)
     __shared__ float red[8][NT * NB][256];
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(512, 4) void skinny_gemm_kernel(const bf16_t* __res
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         xon[nb] = r + 16 * nb < B;
-        xp[nb] = X + (size_t)(xon[nb] ? r + 16 * nb : 0) * ldx + g * 16;
+        xp[nb] = X + (size_t)((xon[nb] && !dbg) ? r + 16 * nb : 0) * ldx + g * 16;
     }
 
     f32x4_t acc[NT][NB];
@@ -134,6 +138,293 @@ __global__ __launch_bounds__(512, 4) void skinny_gemm_kernel(const bf16_t* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// skinny_lds: the same product with the ACTIVATIONS STATIONARY IN LDS.  In skinny_gemm every workgroup re-reads all
+// of X from L2 (B x K bf16 per 16 weight rows): at B = 32 that L2 stream is as large as the weight stream itself and
+// costs 30-60% (measured: gate|up 72 us vs 55 us with the X loads neutered, down 45 vs 29, qkv 26 vs 16).  Here one
+// workgroup per CU parks a K-chunk of X (up to 2048 k = 128 KB for 32 rows) in LDS once, in MFMA-fragment order
+// (every later read is a lane-linear ds_read_b128), and streams several 16-row weight tiles against it:
+//   grid = KS k-chunks x row-groups (<= #CUs workgroups), workgroup = T tasks x WPT waves; a task is one weight tile
+//   (a gate|up tile pair) over the chunk, its k-units split over WPT waves (LDS-reduced) when T is small.
+// K-chunk partials of a tile ([KS][NT*NB][64 lanes][4] fp32, written through) are merged by whichever wave takes
+// the last agent-scope ticket of the tile, always in chunk order -> results do not depend on arrival order.  That
+// merge costs ~5 us of dependent round trips (store drain -> ticket -> acquire -> loads), so the two GEMVs whose
+// consumer is a row kernel anyway (o-proj, down-proj -> residual add + RMSNorm) use EPI_PARTIAL instead: plain fp32
+// partial rows [ks][32][N] and add_rmsnorm_kernel below sums them on load.
+// Weights: `tiled` = the decode copy [N/16][K/64][64 lanes][16] (one 2 KB block per 16 rows x 64 k, lane-linear, so a
+// wave's stream is ONE contiguous run: measured +24% over 16 interleaved 8 KB-strided row streams, which thrash DRAM
+// pages); row-major [N][K] is kept for small callers (STC squeeze-excite).
+template <int EPI, int NB, int NT>
+__global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W, int ldw,
+                                                         bf16_t* __restrict__ out, int ldo, const bf16_t* __restrict__ R, int ldr,
+                                                         int B, int K, int chunk_units, int KS, int T, int WPT, int ntiles,
+                                                         float* __restrict__ ws, unsigned int* __restrict__ tickets, int tiled,
+                                                         int dbg) {
+    // NT = 16-row weight tiles per task (2: a gate|up pair, or two neighbouring tiles of a wide PARTIAL product)
+    constexpr int UN = (NT == 2) ? 2 : 4;                // 64-wide k units per load batch: 8 KB of weights per batch per wave
+    constexpr int NF = NT * NB;                          // accumulator fragments per task
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem);                                      // [unit][half][nb][lane]
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem + (size_t)chunk_units * 2 * NB * 1024); // [task][wsub][NF][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nwaves = blockDim.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int ks = blockIdx.x % KS, rg = blockIdx.x / KS;
+    const int U = K >> 6;
+    const int u_beg = ks * chunk_units, nu = min(U - u_beg, chunk_units);
+    const int task = wid / WPT, wsub = wid - task * WPT;
+    const int tile = rg * T + task;
+    const bool active = task < T && tile < ntiles;
+    const int ua = (wsub * nu) / WPT, ub = ((wsub + 1) * nu) / WPT;                     // this wave's units of the chunk
+    const int n0 = tile * 16 * NT;
+
+    const bf16_t* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (tiled) wp[t] = W + ((size_t)(active ? tile * NT + t : 0) * U + u_beg) * 1024 + lane * 16;
+        else wp[t] = W + (size_t)(active ? n0 + t * 16 + r : 0) * ldw + (size_t)u_beg * 64 + g * 16;
+    }
+    const int ustride = tiled ? 1024 : 64;
+    Frag wa[UN][NT][2], wb[UN][NT][2];
+    auto loadw = [&](Frag (&wf)[UN][NT][2], int u) {
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const bool ok = u + j < ub;
+            const int ko = (u + j) * ustride;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                wf[j][t][0].u = ok ? ldg_nt(wp[t] + ko) : make_uint4(0, 0, 0, 0);
+                wf[j][t][1].u = ok ? ldg_nt(wp[t] + ko + 8) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    const bool work = active && ua < ub;
+    if (work) loadw(wa, ua);                             // the weight stream starts before the activations are parked
+
+    // ---- park X[:, chunk] in LDS in fragment order: combo c = (unit*2 + half)*NB + nb, lane (r, g) holds
+    //      X[16 nb + r][(u_beg + unit)*64 + g*16 + half*8 .. +8]  (zeros for rows >= B) ----
+    {
+        const int combos = nu * 2 * NB;
+        for (int c0 = wid; c0 < combos; c0 += nwaves * 4) {
+            u32x4_t v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = c0 + q * nwaves;
+                const int nb = c % NB, uh = c / NB, h = uh & 1, u = uh >> 1;
+                const int m = 16 * nb + r;
+                v[q] = u32x4_t{0u, 0u, 0u, 0u};
+                if (c < combos && m < B)
+                    v[q] = *reinterpret_cast<const u32x4_t*>(X + (size_t)m * ldx + (size_t)(u_beg + u) * 64 + g * 16 + h * 8);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = c0 + q * nwaves;
+                if (c < combos) xs[c * 64 + lane] = v[q];
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x4_t acc[NT][NB];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](Frag (&wf)[UN][NT][2], int u) {
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            if (u + j < ub) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const bf16x8_t x0 = __builtin_bit_cast(bf16x8_t, xs[(((u + j) * 2 + 0) * NB + nb) * 64 + lane]);
+                    const bf16x8_t x1 = __builtin_bit_cast(bf16x8_t, xs[(((u + j) * 2 + 1) * NB + nb) * 64 + lane]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][t][0].v, x0, acc[t][nb], 0, 0, 0);
+                        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][t][1].v, x1, acc[t][nb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    if (work) {
+        for (int u = ua; u < ub; u += 2 * UN) {
+            if (u + UN < ub) loadw(wb, u + UN);
+            mma(wa, u);
+            if (u + UN < ub) {
+                if (u + 2 * UN < ub) loadw(wa, u + 2 * UN);
+                mma(wb, u + UN);
+            }
+        }
+    }
+    // ---- the WPT waves of a task: fixed-order sum through LDS (workgroup-uniform branch) ----
+    if (WPT > 1) {
+        if (active) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) red[((task * WPT + wsub) * NF + t * NB + nb) * 64 + lane] = acc[t][nb];
+        }
+        __syncthreads();
+        if (active && wsub == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    f32x4_t sacc = red[((task * WPT) * NF + t * NB + nb) * 64 + lane];
+                    for (int w = 1; w < WPT; ++w) sacc += red[((task * WPT + w) * NF + t * NB + nb) * 64 + lane];
+                    acc[t][nb] = sacc;
+                }
+        }
+    }
+    if (!active || wsub != 0 || dbg == 3) return;
+    if (EPI == EPI_PARTIAL) {                           // fp32 partial rows [ks][32][N = ldo]; the consumer sums the chunks
+        float* pr = ws + (size_t)ks * 32 * ldo;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int m = 16 * nb + r;
+            if (m < B) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4_t*>(pr + (size_t)m * ldo + n0 + t * 16 + g * 4) = acc[t][nb];
+            }
+        }
+        return;
+    }
+    // ---- K-chunk partials: publish, ticket, the last wave of the tile merges in chunk order ----
+    if (KS > 1) {
+        float* wt = ws + (size_t)tile * KS * NF * 256;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)       // write-through (sc1) stores: at agent scope once vmcnt drains
+                    __hip_atomic_store(&wt[((size_t)(ks * NF + t * NB + nb) * 4 + e) * 64 + lane], acc[t][nb][e], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (dbg == 4) return;
+        unsigned tk = 0;
+        if (lane == 0) tk = __hip_atomic_fetch_add(&tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (tk != (unsigned)(KS - 1)) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[t][nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int k2 = 0; k2 < KS; ++k2) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t][nb][e] += wt[((size_t)(k2 * NF + t * NB + nb) * 4 + e) * 64 + lane];
+        }
+        if (lane == 0) __hip_atomic_store(&tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- epilogue straight from the accumulators: lane (r, g) holds out[m = 16 nb + r][n0 + t*16 + g*4 + 0..3] ----
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int m = 16 * nb + r;
+        if (m >= B) continue;
+        float o[4];
+        if (EPI == EPI_SWIGLU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gt = acc[0][nb][e], up = acc[NT - 1][nb][e];
+                o[e] = gt / (1.f + __expf(-gt)) * up;
+            }
+            *reinterpret_cast<uint2*>(out + (size_t)m * ldo + (n0 >> 1) + g * 4) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[0][nb][e];
+            if (EPI == EPI_RESIDUAL) {
+                const uint2 rr = *reinterpret_cast<const uint2*>(R + (size_t)m * ldr + n0 + g * 4);
+                o[0] = bf2f(f2bf(o[0])) + bflo(rr.x); o[1] = bf2f(f2bf(o[1])) + bfhi(rr.x);
+                o[2] = bf2f(f2bf(o[2])) + bflo(rr.y); o[3] = bf2f(f2bf(o[3])) + bfhi(rr.y);
+            }
+            *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n0 + g * 4) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+        }
+    }
+}
+
+// SwiGLU over EPI_PARTIAL rows of the gate|up product (16-row interleaved: columns [32p, 32p+16) gate, [32p+16, 32p+32)
+// up of output columns [16p, 16p+16)): out[b][j] = bf16(silu(sum_ks gate) * sum_ks up).  4 outputs per thread.
+__global__ __launch_bounds__(256) void swiglu_combine_kernel(const float* __restrict__ part, int KS, int N2, bf16_t* __restrict__ out,
+                                                             int ldo, int B) {
+    const int I4 = N2 >> 3;                              // float4 groups per output row
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * I4) return;
+    const int b = idx / I4, j4 = idx - b * I4;
+    const int p = j4 >> 2, i = (j4 & 3) * 4;
+    const float* base = part + (size_t)b * N2 + p * 32 + i;
+    f32x4_t gt = *reinterpret_cast<const f32x4_t*>(base), up = *reinterpret_cast<const f32x4_t*>(base + 16);
+    for (int k2 = 1; k2 < KS; ++k2) {
+        gt += *reinterpret_cast<const f32x4_t*>(base + (size_t)k2 * 32 * N2);
+        up += *reinterpret_cast<const f32x4_t*>(base + (size_t)k2 * 32 * N2 + 16);
+    }
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = gt[e] / (1.f + __expf(-gt[e])) * up[e];
+    *reinterpret_cast<uint2*>(out + (size_t)b * ldo + j4 * 4) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+}
+
+// Row-major W [N][K] -> the decode copy [N/16][K/64][64 lanes][16]: lane (r, g) of block (tile, unit) holds
+// W[tile*16 + r][unit*64 + g*16 .. +16] (its two MFMA fragments back to back).  One thread per 16-byte piece.
+__global__ __launch_bounds__(256) void tile_pack_kernel(const bf16_t* __restrict__ src, int ldw, bf16_t* __restrict__ dst, int N, int K) {
+    const int U = K >> 6;
+    const long total = (long)N * (K >> 3);
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long)gridDim.x * 256) {
+        const int n = (int)(p / (K >> 3)), k8 = (int)(p - (long)n * (K >> 3));
+        const int tile = n >> 4, r = n & 15, u = k8 >> 3, g = (k8 & 7) >> 1, h = k8 & 1;
+        *reinterpret_cast<u32x4_t*>(dst + (((size_t)tile * U + u) * 64 + g * 16 + r) * 16 + h * 8) =
+            *reinterpret_cast<const u32x4_t*>(src + (size_t)n * ldw + (size_t)k8 * 8);
+    }
+}
+
+// Decode residual add + RMSNorm fed by EPI_PARTIAL: x = bf16(sum_ks part[ks][b][:]) + R[b][:] (the GEMV epilogue's
+// rounding), stored as the new residual stream, then y = RMSNorm(x) * w.  One workgroup per sequence.
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(const float* __restrict__ part, int KS, const bf16_t* __restrict__ R, int ldr,
+                                                          bf16_t* __restrict__ xout, int ldx, const bf16_t* __restrict__ w,
+                                                          bf16_t* __restrict__ y, int ldy, int N, float eps) {
+    constexpr int MAXC = 4;                            // 256 threads x 4 chunks x 4 elements = 4096
+    __shared__ float s_red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nch = N >> 2;
+    float v[MAXC][4];
+    uint2 wv[MAXC];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = tid + i * 256;
+        if (c < nch) {
+            wv[i] = *reinterpret_cast<const uint2*>(w + c * 4);
+            f32x4_t a = *reinterpret_cast<const f32x4_t*>(part + (size_t)b * N + c * 4);
+            for (int k2 = 1; k2 < KS; ++k2) a += *reinterpret_cast<const f32x4_t*>(part + ((size_t)k2 * 32 + b) * N + c * 4);
+            const uint2 rr = *reinterpret_cast<const uint2*>(R + (size_t)b * ldr + c * 4);
+            const float x0 = bf2f(f2bf(a[0])) + bflo(rr.x), x1 = bf2f(f2bf(a[1])) + bfhi(rr.x);
+            const float x2 = bf2f(f2bf(a[2])) + bflo(rr.y), x3 = bf2f(f2bf(a[3])) + bfhi(rr.y);
+            const uint2 xo = make_uint2(pack2bf(x0, x1), pack2bf(x2, x3));
+            *reinterpret_cast<uint2*>(xout + (size_t)b * ldx + c * 4) = xo;
+            v[i][0] = bflo(xo.x); v[i][1] = bfhi(xo.x); v[i][2] = bflo(xo.y); v[i][3] = bfhi(xo.y);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss += v[i][e] * v[i][e];
+        }
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) s_red[tid >> 6] = ss;
+    __syncthreads();
+    const float rstd = rsqrtf((s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (float)N + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = tid + i * 256;
+        if (c < nch) {
+            const float o0 = v[i][0] * rstd * bflo(wv[i].x), o1 = v[i][1] * rstd * bfhi(wv[i].x);
+            const float o2 = v[i][2] * rstd * bflo(wv[i].y), o3 = v[i][3] * rstd * bfhi(wv[i].y);
+            *reinterpret_cast<uint2*>(y + (size_t)b * ldy + c * 4) = make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Single-query GQA attention over the KV cache, one launch per layer: RoPE of q / the new k, the KV-cache
 // append, the split-context partial attention and the cross-split combine are all in this kernel.
 //
@@ -160,7 +451,8 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
                                                              const int32_t* __restrict__ pos, float* __restrict__ ws,
                                                              unsigned int* __restrict__ tickets, bf16_t* __restrict__ O, int ldo,
                                                              int nq, int nkv, int nsplit, float scale, int fuse_rope,
-                                                             const float* __restrict__ cos_t, const float* __restrict__ sin_t, int dbg) {
+                                                             const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                             const float* __restrict__ qpart, int qks, int dbg) {
     constexpr int HD = 128, GQ = 4;
     __shared__ __attribute__((aligned(16))) float s_acc[4][GQ][HD];
     __shared__ float s_m[4][GQ], s_l[4][GQ];
@@ -178,7 +470,25 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
     const int nit = (len + 31) >> 5;                  // 32-position blocks in this split
     bf16_t* kb = kcache + (size_t)slots[b] * slot_stride + (size_t)kvh * kv_head_stride;
     bf16_t* vb = vtcache + (size_t)slots[b] * slot_stride + (size_t)kvh * kv_head_stride;
+    // the qkv row of this sequence: bf16 [ldq], or (qpart) the qkv GEMV's fp32 k-chunk partial rows [qks][32][ldq], summed
+    // and rounded to bf16 here (what the GEMV epilogue would have stored)
     const bf16_t* row = qkv + (size_t)b * ldq;
+    auto slice8 = [&](int n) -> u32x4_t {
+        if (!qpart) return *reinterpret_cast<const u32x4_t*>(row + n);
+        const float* pp = qpart + (size_t)b * ldq + n;
+        f32x4_t a = *reinterpret_cast<const f32x4_t*>(pp), c = *reinterpret_cast<const f32x4_t*>(pp + 4);
+        for (int k2 = 1; k2 < qks; ++k2) {
+            a += *reinterpret_cast<const f32x4_t*>(pp + (size_t)k2 * 32 * ldq);
+            c += *reinterpret_cast<const f32x4_t*>(pp + (size_t)k2 * 32 * ldq + 4);
+        }
+        return u32x4_t{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(c[0], c[1]), pack2bf(c[2], c[3])};
+    };
+    auto elem = [&](int n) -> bf16_t {
+        if (!qpart) return row[n];
+        float a = qpart[(size_t)b * ldq + n];
+        for (int k2 = 1; k2 < qks; ++k2) a += qpart[((size_t)k2 * 32 + b) * ldq + n];
+        return f2bf(a);
+    };
     const bool owner = fuse_rope && len > 0 && end == ctx;       // this split holds the newest position
 
     const int prow = (i >> 2) * 8 + (i & 3);          // + 4 t: position (within the block) of A-row i of S tile t
@@ -208,10 +518,10 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
 
     // rotate-half RoPE of a head's four 8-wide slices held by this lane: d = sp*64 + g*16 + hf*8 + e (its partner
     // d +- 64 is the same lane's other sp), rounded to bf16 like the stored q / k
-    auto rope_head = [&](const bf16_t* head, u32x4_t (&out)[4]) {
+    auto rope_head = [&](int col, u32x4_t (&out)[4]) {
         u32x4_t x[4];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) x[s4] = *reinterpret_cast<const u32x4_t*>(head + (s4 >> 1) * 64 + g * 16 + (s4 & 1) * 8);
+        for (int s4 = 0; s4 < 4; ++s4) x[s4] = slice8(col + (s4 >> 1) * 64 + g * 16 + (s4 & 1) * 8);
         if (!fuse_rope) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) out[s4] = x[s4];
@@ -234,7 +544,7 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
         }
     };
     u32x4_t qf[4];                                    // B operand of S: q of head i (i < 4), zero columns otherwise
-    if (i < GQ) rope_head(row + (size_t)(kvh * GQ + i) * HD, qf);
+    if (i < GQ) rope_head((kvh * GQ + i) * HD, qf);
     else {
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) qf[s4] = zero4;
@@ -242,7 +552,7 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
     if (owner) {       // the newest row: append to the caches (K row-major, V down a column of V^T) and park it in LDS
         if (wid == 0 && i == 0) {
             u32x4_t kn[4];
-            rope_head(row + (size_t)(nq + kvh) * HD, kn);
+            rope_head((nq + kvh) * HD, kn);
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const int d0 = (s4 >> 1) * 64 + g * 16 + (s4 & 1) * 8;
@@ -251,7 +561,7 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
             }
         }
         if (tid >= 128) {
-            const bf16_t x = row[(size_t)(nq + nkv + kvh) * HD + tid - 128];
+            const bf16_t x = elem((nq + nkv + kvh) * HD + tid - 128);
             vb[(size_t)(tid - 128) * ctx_stride + p_new] = x;
             s_new[HD + tid - 128] = x;
         }
@@ -572,26 +882,130 @@ __global__ __launch_bounds__(256) void select_next_kernel(const float* __restric
 }
 }  // namespace
 
-int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R, int ldr,
-                       int B, int N, int K, int epi, hipStream_t s) {
-    if (B < 1 || B > 32 || K % 64 || (ldx % 8) || (ldw % 8)) return TRACE_ERR_ARG;
-#define SK(EPI_, NB_, GRID_) hipLaunchKernelGGL((skinny_gemm_kernel<EPI_, NB_>), dim3(GRID_), dim3(512), 0, s, X, ldx, W, ldw, out, ldo, R, ldr, B, N, K)
+int g_skinny_debug = 0; // microbenchmark-only: 1 = skinny_gemm with every lane reading activation row 0 (no X traffic; wrong
+                        // results), 2 = force the L2-activation kernel (skinny_gemm) for every call
+static int skinny_l2(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R, int ldr,
+                     int B, int N, int K, int epi, hipStream_t s) {
+#define SK(EPI_, NB_, GRID_) hipLaunchKernelGGL((skinny_gemm_kernel<EPI_, NB_>), dim3(GRID_), dim3(512), 0, s, X, ldx, W, ldw, out, ldo, R, ldr, B, N, K, g_skinny_debug == 1)
     switch (epi) {
-        case EPI_NONE:
-            if (N % 16) return TRACE_ERR_ARG;
-            if (B <= 16) SK(EPI_NONE, 1, N / 16); else SK(EPI_NONE, 2, N / 16);
-            break;
-        case EPI_RESIDUAL:
-            if (N % 16 || !R) return TRACE_ERR_ARG;
-            if (B <= 16) SK(EPI_RESIDUAL, 1, N / 16); else SK(EPI_RESIDUAL, 2, N / 16);
-            break;
-        case EPI_SWIGLU:
-            if (N % 32) return TRACE_ERR_ARG;
-            if (B <= 16) SK(EPI_SWIGLU, 1, N / 32); else SK(EPI_SWIGLU, 2, N / 32);
-            break;
-        default: return TRACE_ERR_ARG;
+        case EPI_NONE: if (B <= 16) SK(EPI_NONE, 1, N / 16); else SK(EPI_NONE, 2, N / 16); break;
+        case EPI_RESIDUAL: if (B <= 16) SK(EPI_RESIDUAL, 1, N / 16); else SK(EPI_RESIDUAL, 2, N / 16); break;
+        default: if (B <= 16) SK(EPI_SWIGLU, 1, N / 32); else SK(EPI_SWIGLU, 2, N / 32); break;
     }
 #undef SK
+    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+}
+
+// Partition for skinny_lds (see the kernel header): KS k-chunks x row-groups of T tiles, WPT waves per tile.
+struct SkinnyPlan { int KS, chunk_units, T, WPT, ntiles, grid, threads; };
+static int skinny_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+static int skinny_nt(int N, int epi) { return epi == EPI_SWIGLU || (epi == EPI_PARTIAL && N >= 16384 && N % 32 == 0) ? 2 : 1; }
+static SkinnyPlan skinny_plan(int N, int K, int epi, int B) {
+    SkinnyPlan p{};
+    const int NT = skinny_nt(N, epi), NB = B > 16 ? 2 : 1;
+    const int U = K / 64;
+    static const int cap1 = getenv("TRACE_SK_CAP") ? atoi(getenv("TRACE_SK_CAP")) : 64;    // tuning knob (microbenchmarks)
+    const int cap = NB == 2 ? 32 : cap1;                  // units of X that fit 128 KB of LDS
+    const int ks_min = (U + cap - 1) / cap;
+    const int ks_max = epi == EPI_PARTIAL ? std::min(U, ks_min + 4) : ks_min;    // extra chunks are free only without the ticket merge
+    p.ntiles = N / (16 * NT);
+    const int ncu = skinny_num_cus();
+    long best = -1;
+    for (int ks = ks_min; ks <= ks_max; ++ks) {
+        const int chunk = (U + ks - 1) / ks;
+        for (int T = 1; T <= 8; ++T) {
+            const int grid = ks * ((p.ntiles + T - 1) / T);
+            const long rounds = (grid + ncu - 1) / ncu;
+            const long cost = rounds * T * chunk * 64 + rounds * 8 + ks;   // per-CU weight stream; ties -> fewer rounds, fewer chunks
+            if (best < 0 || cost < best) { best = cost; p.KS = ks; p.chunk_units = chunk; p.T = T; p.grid = grid; }
+        }
+    }
+    p.WPT = 1;
+    const int wmax = NT * NB == 4 ? 4 : 8;                // bounds the LDS reduction scratch (T*WPT*NT*NB KB)
+    while (p.WPT * 2 * p.T <= 8 && p.WPT * 2 <= wmax && p.WPT * 2 <= p.chunk_units) p.WPT *= 2;
+    p.threads = p.T * p.WPT * 64;
+    return p;
+}
+static size_t skinny_plan_ws(const SkinnyPlan& p, int N, int epi, int B) {
+    if (epi == EPI_PARTIAL) return (size_t)p.KS * 32 * N;
+    const int NT = skinny_nt(N, epi), NB = B > 16 ? 2 : 1;
+    return p.KS > 1 ? (size_t)p.ntiles * p.KS * NT * NB * 256 : 0;
+}
+size_t skinny_ws_floats(int N, int K, int epi) {
+    return std::max(skinny_plan_ws(skinny_plan(N, K, epi, 1), N, epi, 1), skinny_plan_ws(skinny_plan(N, K, epi, 32), N, epi, 32));
+}
+int skinny_ks(int N, int K, int epi, int B) { return skinny_plan(N, K, epi, B).KS; }
+
+template <int EPI, int NB, int NT>
+static int skinny_lds_launch(const SkinnyPlan& p, const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo,
+                             const bf16_t* R, int ldr, int B, int K, float* ws, unsigned int* tickets, int tiled, hipStream_t s) {
+    const size_t lds = (size_t)p.chunk_units * 2 * NB * 1024 + (p.WPT > 1 ? (size_t)p.T * p.WPT * NT * NB * 1024 : 0);
+    static size_t granted = 0;
+    if (lds > granted) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_lds_kernel<EPI, NB, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) return TRACE_ERR_HIP;
+        granted = lds;
+    }
+    hipLaunchKernelGGL((skinny_lds_kernel<EPI, NB, NT>), dim3(p.grid), dim3(p.threads), lds, s, X, ldx, W, ldw, out, ldo, R, ldr, B, K,
+                       p.chunk_units, p.KS, p.T, p.WPT, p.ntiles, ws, tickets, tiled, g_skinny_debug);
+    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+}
+
+// EPI_PARTIAL: `out` is unused, ldo = N, the fp32 partial rows [KS = skinny_ks()][32][N] land in ws.
+int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R, int ldr,
+                       int B, int N, int K, int epi, int tiled, float* ws, size_t ws_floats, unsigned int* tickets, int ntickets,
+                       hipStream_t s) {
+    if (B < 1 || B > 32 || K % 64 || (ldx % 8) || (ldw % 8) || (ldo % 4)) return TRACE_ERR_ARG;
+    if (epi != EPI_NONE && epi != EPI_RESIDUAL && epi != EPI_SWIGLU && epi != EPI_PARTIAL) return TRACE_ERR_ARG;
+    if (N % (epi == EPI_SWIGLU ? 32 : 16) || (epi == EPI_RESIDUAL && (!R || ldr % 4))) return TRACE_ERR_ARG;
+    if (g_skinny_debug == 1 || g_skinny_debug == 2) {
+        if (tiled || epi == EPI_PARTIAL) return TRACE_ERR_ARG;
+        return skinny_l2(X, ldx, W, ldw, out, ldo, R, ldr, B, N, K, epi, s);
+    }
+    const SkinnyPlan p = skinny_plan(N, K, epi, B);
+    const size_t need = skinny_plan_ws(p, N, epi, B);
+    if (need && (!ws || ws_floats < need)) return TRACE_ERR_ARG;
+    if (epi != EPI_PARTIAL && p.KS > 1 && (!tickets || ntickets < p.ntiles)) return TRACE_ERR_ARG;
+    if (epi == EPI_PARTIAL) ldo = N;
+#define SL(EPI_, NT_) (B <= 16 ? skinny_lds_launch<EPI_, 1, NT_>(p, X, ldx, W, ldw, out, ldo, R, ldr, B, K, ws, tickets, tiled, s) \
+                               : skinny_lds_launch<EPI_, 2, NT_>(p, X, ldx, W, ldw, out, ldo, R, ldr, B, K, ws, tickets, tiled, s))
+    switch (epi) {
+        case EPI_NONE: return SL(EPI_NONE, 1);
+        case EPI_RESIDUAL: return SL(EPI_RESIDUAL, 1);
+        case EPI_PARTIAL: return skinny_nt(N, epi) == 2 ? SL(EPI_PARTIAL, 2) : SL(EPI_PARTIAL, 1);
+        default: return SL(EPI_SWIGLU, 2);
+    }
+#undef SL
+}
+
+int launch_swiglu_combine(const float* part, int KS, int N2, bf16_t* out, int ldo, int B, hipStream_t s) {
+    if (B < 1 || B > 32 || KS < 1 || N2 % 32 || ldo % 4) return TRACE_ERR_ARG;
+    const int total = B * (N2 / 8);
+    hipLaunchKernelGGL(swiglu_combine_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, KS, N2, out, ldo, B);
+    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+}
+
+int launch_tile_pack(const bf16_t* src, int ldw, bf16_t* dst, int N, int K, hipStream_t s) {
+    if (N % 16 || K % 64 || ldw % 8) return TRACE_ERR_ARG;
+    const long total = (long)N * (K / 8);
+    const int grid = (int)std::min<long>((total + 255) / 256, 65536);
+    hipLaunchKernelGGL(tile_pack_kernel, dim3(grid), dim3(256), 0, s, src, ldw, dst, N, K);
+    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+}
+
+int launch_add_rmsnorm(const float* part, int KS, const bf16_t* R, int ldr, bf16_t* xout, int ldx, const bf16_t* w, bf16_t* y,
+                       int ldy, int B, int N, float eps, hipStream_t s) {
+    if (B < 1 || B > 32 || KS < 1 || N % 4 || N > 4096 || (ldr % 4) || (ldx % 4) || (ldy % 4)) return TRACE_ERR_ARG;
+    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(B), dim3(256), 0, s, part, KS, R, ldr, xout, ldx, w, y, ldy, N, eps);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 
@@ -599,11 +1013,11 @@ int g_attn_debug = 0;   // microbenchmark-only phase cut-offs (0 = full kernel)
 int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vtcache, long slot_stride, long kv_head_stride,
                        int ctx_stride, const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,
                        int nq, int nkv, int hd, int nsplit, float scale, int fuse_rope, const float* cos_t, const float* sin_t,
-                       hipStream_t s) {
+                       const float* qpart, int qks, hipStream_t s) {
     if (hd != 128 || nq != 4 * nkv || nsplit < 1 || B < 1 || !tickets || ctx_stride % 32) return TRACE_ERR_ARG;
     hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv, B), dim3(256), 0, s, qkv, ldq, kcache, vtcache, slot_stride,
                        kv_head_stride, ctx_stride, slots, pos, ws, tickets, O, ldo, nq, nkv, nsplit, scale, fuse_rope, cos_t, sin_t,
-                       g_attn_debug);
+                       qpart, qks, g_attn_debug);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 

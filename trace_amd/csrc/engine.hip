@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -19,10 +20,14 @@
 static thread_local std::string g_err;
 static int fail(int code, const std::string& m) { g_err = m; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(TRACE_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+#define LCHK(x) do { int r_ = (x); if (r_ != TRACE_OK) return fail(r_, std::string("launch failed: ") + #x); } while (0)
 #define TRY(x) do { int r_ = (x); if (r_ != TRACE_OK) { if (g_err.empty()) g_err = std::string("failed: ") + #x; return r_; } } while (0)
 
 struct VitLayer { bf16_t *ln1w, *ln1b, *wqkv, *bqkv, *wo, *bo, *ln2w, *ln2b, *w1, *b1, *w2, *b2; };
-struct LlmLayer { bf16_t *rms1, *wqkv, *wo, *rms2, *wgu, *wd; };
+struct LlmLayer {
+    bf16_t *rms1, *wqkv, *wo, *rms2, *wgu, *wd;
+    bf16_t *wqkv_d, *wo_d, *wgu_d, *wd_d;      // decode copies in the GEMV tile layout (decode.hip: launch_tile_pack)
+};
 struct StcBlock { bf16_t *w1, *n1w, *n1b, *wdw, *n2w, *n2b, *fc1w, *fc1b, *fc2w, *fc2b, *w3, *n3w, *n3b, *wd, *ndw, *ndb; int cin, rd; };
 
 struct trace_ctx {
@@ -64,6 +69,7 @@ struct trace_ctx {
     // decode state
     bf16_t *dX, *dH, *dQKV, *dO, *dACT, *xlast;   // [16, *]
     float* attn_ws; unsigned int* tickets;
+    float* sk_ws = nullptr; unsigned int* sk_tickets = nullptr; size_t sk_ws_floats = 0; int sk_ntickets = 0;   // decode GEMV K-chunk partials
     float* part_val; int32_t* part_idx;
     int32_t *d_slots, *d_pos, *d_heads, *d_done, *d_out_ids, *d_out_len, *d_step, *d_forced, *d_params;
     int B = 0, max_new = 0, eos = -1, has_forced = 0, ntiles = 0, nsplit = 32;
@@ -95,6 +101,7 @@ static int dalloc(trace_ctx* c, T** p, size_t n_elems) {
     return TRACE_OK;
 }
 
+#define SKWS(c) (c)->sk_ws, (c)->sk_ws_floats, (c)->sk_tickets, (c)->sk_ntickets
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 extern "C" const char* trace_last_error(void) { return g_err.c_str(); }
@@ -167,6 +174,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     c->llm.resize(c->NL);
     for (auto& l : c->llm) {
         A(l.rms1, H); A(l.wqkv, (size_t)c->QKV * H); A(l.wo, H * H); A(l.rms2, H); A(l.wgu, 2 * I * H); A(l.wd, H * I);
+        A(l.wqkv_d, (size_t)c->QKV * H); A(l.wo_d, H * H); A(l.wgu_d, 2 * I * H); A(l.wd_d, H * I);
     }
     A(c->slot_cos, (size_t)c->GG * vh / 2); A(c->slot_sin, (size_t)c->GG * vh / 2);
     A(c->rope_cos, (size_t)c->max_ctx * c->HD / 2); A(c->rope_sin, (size_t)c->max_ctx * c->HD / 2);
@@ -197,6 +205,17 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     A(c->dX, 32 * H); A(c->dH, 32 * H); A(c->dQKV, 32 * (size_t)c->QKV); A(c->dO, 32 * H); A(c->dACT, 32 * I);
     A(c->xlast, 64 * H);
     A(c->attn_ws, (size_t)32 * c->NQ * c->nsplit * (c->HD + 2)); A(c->tickets, 32 * c->NKV);
+    {
+        size_t f = skinny_ws_floats(c->QKV, H, EPI_NONE);
+        f = std::max(f, skinny_ws_floats(c->QKV, H, EPI_PARTIAL));
+        f = std::max(f, skinny_ws_floats(H, H, EPI_PARTIAL));
+        f = std::max(f, skinny_ws_floats(2 * I, H, EPI_SWIGLU));
+        f = std::max(f, skinny_ws_floats(2 * I, H, EPI_PARTIAL));
+        f = std::max(f, skinny_ws_floats(H, I, EPI_PARTIAL));
+        c->sk_ws_floats = std::max<size_t>(f, 64);
+        c->sk_ntickets = (int)std::max<size_t>(std::max<size_t>((size_t)c->QKV, (size_t)H), (size_t)(2 * I)) / 16;
+        A(c->sk_ws, c->sk_ws_floats); A(c->sk_tickets, c->sk_ntickets);
+    }
     c->ntiles = c->NVpad / 16;
     A(c->part_val, (size_t)32 * c->ntiles); A(c->part_idx, (size_t)32 * c->ntiles);
     A(c->d_slots, 32); A(c->d_pos, 32); A(c->d_heads, 32); A(c->d_done, 32); A(c->d_out_len, 32); A(c->d_step, 4); A(c->d_params, 4);
@@ -418,6 +437,14 @@ extern "C" int trace_ctx_finalize(trace_ctx* c) {
         HIPCHK(hipMemcpy(c->rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
     }
+    // decode copies of the LLM matrices in the GEMV tile layout (288 GB of HBM: +14.5 GB buys ~25% on the weight stream)
+    for (auto& l : c->llm) {
+        LCHK(launch_tile_pack(l.wqkv, c->H, l.wqkv_d, c->QKV, c->H, 0));
+        LCHK(launch_tile_pack(l.wo, c->H, l.wo_d, c->H, c->H, 0));
+        LCHK(launch_tile_pack(l.wgu, c->H, l.wgu_d, 2 * c->I, c->H, 0));
+        LCHK(launch_tile_pack(l.wd, c->I, l.wd_d, c->H, c->I, 0));
+    }
+    HIPCHK(hipDeviceSynchronize());
     c->finalized = true;
     return TRACE_OK;
 }
@@ -430,7 +457,6 @@ static int gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* C, i
     if (rc != TRACE_OK) return fail(rc, "gemm launch failed (M=" + std::to_string(M) + " N=" + std::to_string(N) + " K=" + std::to_string(K) + ")");
     return TRACE_OK;
 }
-#define LCHK(x) do { int r_ = (x); if (r_ != TRACE_OK) return fail(r_, std::string("launch failed: ") + #x); } while (0)
 
 extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dtype, int T, void* feats_out, void* stream) {
     if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
@@ -503,9 +529,9 @@ static int stc_block(trace_ctx* c, const StcBlock& k, const bf16_t* x, bf16_t* o
     LCHK(launch_dwconv3x3(y, k.wdw, z, N, hh, ww, H, s));
     LCHK(launch_layernorm(z, H, z, H, k.n2w, k.n2b, rows, H, 1e-6f, s, 1));
     LCHK(launch_avgpool(z, c->stc_pool, N, HW, H, s));
-    LCHK(launch_skinny_gemm(c->stc_pool, H, k.fc1w, H, c->stc_g1, k.rd, nullptr, 0, N, k.rd, H, EPI_NONE, s));
+    LCHK(launch_skinny_gemm(c->stc_pool, H, k.fc1w, H, c->stc_g1, k.rd, nullptr, 0, N, k.rd, H, EPI_NONE, 0, SKWS(c), s));
     LCHK(launch_bias_act(c->stc_g1, k.fc1b, N, k.rd, ACT_SILU, s));
-    LCHK(launch_skinny_gemm(c->stc_g1, k.rd, k.fc2w, k.rd, c->stc_g2, H, nullptr, 0, N, H, k.rd, EPI_NONE, s));
+    LCHK(launch_skinny_gemm(c->stc_g1, k.rd, k.fc2w, k.rd, c->stc_g2, H, nullptr, 0, N, H, k.rd, EPI_NONE, 0, SKWS(c), s));
     LCHK(launch_bias_act(c->stc_g2, k.fc2b, N, H, ACT_SIGMOID, s));
     LCHK(launch_scale_rows(z, c->stc_g2, N, HW, H, s));
     TRY(gemm(z, H, k.w3, H, y, H, nullptr, nullptr, 0, rows, H, H, EPI_NONE, s));
@@ -692,31 +718,38 @@ static int decode_nsplit(int B) { const int n = (40 + B / 2) / B; return n < 1 ?
 // one decode step for the current batch: consumes dX (embedding of the last token), leaves the next one in dX
 static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
     const int H = c->H, I = c->I, HD = c->HD, QKV = c->QKV, B = c->B;
+    // Every GEMV leaves fp32 k-chunk partial rows in sk_ws and its consumer sums them on load (an in-kernel merge costs
+    // 5-8 us of dependent round trips per GEMV): qkv -> attention (RoPE + cache append + attention) -> o -> [sum + residual
+    // -> new residual, RMSNorm] -> gate|up -> [sum, SwiGLU] -> down -> [sum + residual, next layer's / the final RMSNorm].
+    const int ks_q = skinny_ks(QKV, H, EPI_PARTIAL, B), ks_o = skinny_ks(H, H, EPI_PARTIAL, B);
+    const int ks_g = skinny_ks(2 * I, H, EPI_PARTIAL, B), ks_d = skinny_ks(H, I, EPI_PARTIAL, B);
+    LCHK(launch_rmsnorm(c->dX, H, c->dH, H, c->llm[0].rms1, B, H, c->c.rms_eps, s));
     for (int l = 0; l < c->NL; ++l) {
         const LlmLayer& W = c->llm[l];
         bf16_t* kc = c->kcache + (size_t)l * c->layer_stride;
         bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
-        // (fusing the RMSNorm into the GEMV was tried: re-scaling the same activations in every one of its ~900
-        //  workgroups cost more than this one 6 us row kernel — 65 us vs 52 + 6 us for the gate|up GEMV)
-        LCHK(launch_rmsnorm(c->dX, H, c->dH, H, W.rms1, B, H, c->c.rms_eps, s));
-        LCHK(launch_skinny_gemm(c->dH, H, W.wqkv, H, c->dQKV, QKV, nullptr, 0, B, QKV, H, EPI_NONE, s));
+        // (fusing the RMSNorm into the GEMV itself was tried: re-scaling the same activations in every workgroup cost
+        //  more than a row kernel — 65 us vs 52 + 6 us for the gate|up GEMV)
+        LCHK(launch_skinny_gemm(c->dH, H, W.wqkv_d, H, nullptr, QKV, nullptr, 0, B, QKV, H, EPI_PARTIAL, 1, SKWS(c), s));
         LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots, c->d_pos, c->dO,
                                 H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, decode_nsplit(B), 1.0f / sqrtf((float)HD), 1,
-                                c->rope_cos, c->rope_sin, s));
-        LCHK(launch_skinny_gemm(c->dO, H, W.wo, H, c->dX, H, c->dX, H, B, H, H, EPI_RESIDUAL, s));
+                                c->rope_cos, c->rope_sin, c->sk_ws, ks_q, s));
+        LCHK(launch_skinny_gemm(c->dO, H, W.wo_d, H, nullptr, H, nullptr, 0, B, H, H, EPI_PARTIAL, 1, SKWS(c), s));
+        LCHK(launch_add_rmsnorm(c->sk_ws, ks_o, c->dX, H, c->dX, H, W.rms2, c->dH, H, B, H, c->c.rms_eps, s));
         // roofline probe: HIP events around ONE launch of the dominant kernel (layer 0 gate|up GEMV) per step
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (l == 0 && c->profile == 2) {
             // (event-record nodes captured into a hipGraph do not yield usable timestamps on ROCm 7.2: eager launches only)
             if (s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) { e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2; }
         }
-        LCHK(launch_rmsnorm(c->dX, H, c->dH, H, W.rms2, B, H, c->c.rms_eps, s));
         if (e0) hipEventRecord(e0, s);
-        LCHK(launch_skinny_gemm(c->dH, H, W.wgu, H, c->dACT, I, nullptr, 0, B, 2 * I, H, EPI_SWIGLU, s));
+        LCHK(launch_skinny_gemm(c->dH, H, W.wgu_d, H, nullptr, 2 * I, nullptr, 0, B, 2 * I, H, EPI_PARTIAL, 1, SKWS(c), s));
         if (e1) hipEventRecord(e1, s);
-        LCHK(launch_skinny_gemm(c->dACT, I, W.wd, I, c->dX, H, c->dX, H, B, H, I, EPI_RESIDUAL, s));
+        LCHK(launch_swiglu_combine(c->sk_ws, ks_g, 2 * I, c->dACT, I, B, s));
+        LCHK(launch_skinny_gemm(c->dACT, I, W.wd_d, I, nullptr, H, nullptr, 0, B, H, I, EPI_PARTIAL, 1, SKWS(c), s));
+        const bf16_t* nw = l + 1 < c->NL ? c->llm[l + 1].rms1 : c->final_norm;
+        LCHK(launch_add_rmsnorm(c->sk_ws, ks_d, c->dX, H, c->dX, H, nw, c->dH, H, B, H, c->c.rms_eps, s));
     }
-    LCHK(launch_rmsnorm(c->dX, H, c->dH, H, c->final_norm, B, H, c->c.rms_eps, s));
     return head_and_select(c, c->dH, 1, logits_out, s);
 }
 
@@ -852,8 +885,10 @@ extern "C" int trace_op_gemm(const void* A, int lda, const void* W, int ldw, voi
 }
 extern int g_gemm_variant;
 extern int g_attn_debug;
+extern int g_skinny_debug;
 extern "C" int trace_op_set_gemm_variant(int variant) {
-    if (variant >= 100 && variant < 104) { g_attn_debug = variant - 100; return TRACE_OK; }   // microbench: attention phase cut-offs
+    if (variant >= 100 && variant < 104) { g_attn_debug = variant - 100; return TRACE_OK; }
+    if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }   // microbench: attention phase cut-offs
     if (variant < 0 || variant > 3) return fail(TRACE_ERR_ARG, "variant must be 0..3");
     g_gemm_variant = variant;
     return TRACE_OK;
@@ -886,10 +921,43 @@ extern "C" int trace_op_attention(const void* Q, const void* K, const void* V, v
     else return fail(TRACE_ERR_ARG, "head_dim must be 64 or 128");
     return TRACE_OK;
 }
+// Decode GEMV test hooks.  w_tiled: W is in the decode tile layout (trace_op_tile_pack) instead of row-major [N][K].
+// epilogue 4 (EPI_PARTIAL): `out` receives the fp32 partial rows [trace_op_skinny_ks(...)][32][N] instead of bf16.
+static float* g_sk_ws = nullptr;
+static unsigned int* g_sk_tk = nullptr;
+static size_t g_sk_ws_floats = 0;
+static int g_sk_ntk = 0;
 extern "C" int trace_op_skinny_gemm(const void* X, const void* W, void* out, const void* R, int B, int N, int K, int epilogue,
-                                    void* stream) {
+                                    int w_tiled, void* stream) {
     const int No = epilogue == EPI_SWIGLU ? N / 2 : N;
+    const size_t need = skinny_ws_floats(N, K, epilogue);
+    if (need > g_sk_ws_floats || N / 16 > g_sk_ntk) {             // grow-only scratch (never freed)
+        HIPCHK(hipDeviceSynchronize());
+        if (g_sk_ws) hipFree(g_sk_ws);
+        if (g_sk_tk) hipFree(g_sk_tk);
+        g_sk_ws_floats = std::max(need, g_sk_ws_floats) + 64; g_sk_ntk = std::max(N / 16, g_sk_ntk);
+        HIPCHK(hipMalloc((void**)&g_sk_ws, g_sk_ws_floats * 4));
+        HIPCHK(hipMalloc((void**)&g_sk_tk, (size_t)g_sk_ntk * 4));
+        HIPCHK(hipMemset(g_sk_tk, 0, (size_t)g_sk_ntk * 4));
+    }
     LCHK(launch_skinny_gemm((const bf16_t*)X, K, (const bf16_t*)W, K, (bf16_t*)out, No, (const bf16_t*)R, No, B, N, K, epilogue,
+                            w_tiled, g_sk_ws, g_sk_ws_floats, g_sk_tk, g_sk_ntk, (hipStream_t)stream));
+    if (epilogue == EPI_PARTIAL && out)
+        HIPCHK(hipMemcpyAsync(out, g_sk_ws, (size_t)skinny_ks(N, K, epilogue, B) * 32 * N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return TRACE_OK;
+}
+extern "C" int trace_op_skinny_ks(int N, int K, int epilogue, int B) { return skinny_ks(N, K, epilogue, B); }
+extern "C" int trace_op_tile_pack(const void* W, void* Wt, int N, int K, void* stream) {
+    LCHK(launch_tile_pack((const bf16_t*)W, K, (bf16_t*)Wt, N, K, (hipStream_t)stream));
+    return TRACE_OK;
+}
+extern "C" int trace_op_swiglu_combine(const float* part, int KS, int N2, void* out, int B, void* stream) {
+    LCHK(launch_swiglu_combine(part, KS, N2, (bf16_t*)out, N2 / 2, B, (hipStream_t)stream));
+    return TRACE_OK;
+}
+extern "C" int trace_op_add_rmsnorm(const float* part, int KS, const void* R, void* xout, const void* w, void* y, int B, int N,
+                                    float eps, void* stream) {
+    LCHK(launch_add_rmsnorm(part, KS, (const bf16_t*)R, N, (bf16_t*)xout, N, (const bf16_t*)w, (bf16_t*)y, N, B, N, eps,
                             (hipStream_t)stream));
     return TRACE_OK;
 }
@@ -909,6 +977,6 @@ extern "C" int trace_op_attn_decode(const void* q, const void* kcache, const voi
     }
     LCHK(launch_attn_decode((const bf16_t*)q, nq * 128, (bf16_t*)kcache, (bf16_t*)vcache, (long)nkv * max_ctx * 128,
                             (long)max_ctx * 128, max_ctx, d_slots, pos, (bf16_t*)O, nq * 128, ws, d_tickets, B, nq, nkv, 128, nsplit, scale, 0,
-                            nullptr, nullptr, (hipStream_t)stream));
+                            nullptr, nullptr, nullptr, 0, (hipStream_t)stream));
     return TRACE_OK;
 }

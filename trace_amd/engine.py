@@ -11,7 +11,7 @@ from . import _lib
 from .config import TraceConfig
 from .model.encoders import TimeTower, ScoreTower
 
-EPI_NONE, EPI_RESIDUAL, EPI_QUICKGELU, EPI_SWIGLU = 0, 1, 2, 3
+EPI_NONE, EPI_RESIDUAL, EPI_QUICKGELU, EPI_SWIGLU, EPI_PARTIAL = 0, 1, 2, 3, 4
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -278,14 +278,48 @@ class ops:
         return o
 
     @staticmethod
-    def skinny_gemm(X, W, R=None, epilogue=EPI_NONE):
+    def tile_pack(W):
+        """row-major [N, K] -> the decode GEMV tile layout (same shape/bytes, permuted)"""
+        lib = _lib.load()
+        out = torch.empty_like(W)
+        _lib.check(lib.trace_op_tile_pack(_ptr(W), _ptr(out), W.shape[0], W.shape[1], _stream()))
+        return out
+
+    @staticmethod
+    def skinny_gemm(X, W, R=None, epilogue=EPI_NONE, tiled=False, want_partial=True):
+        """decode GEMV; `tiled`: W was passed through tile_pack.  EPI_PARTIAL returns the fp32 partial rows [KS, 32, N]."""
         lib = _lib.load()
         Bn, K = X.shape
         N = W.shape[0]
-        No = N // 2 if epilogue == EPI_SWIGLU else N
-        out = torch.empty((Bn, No), dtype=torch.bfloat16, device=X.device)
-        _lib.check(lib.trace_op_skinny_gemm(_ptr(X), _ptr(W), _ptr(out), _ptr(R), Bn, N, K, epilogue, _stream()))
+        if epilogue == EPI_PARTIAL:
+            ks = lib.trace_op_skinny_ks(N, K, epilogue, Bn)
+            out = torch.zeros((ks, 32, N), dtype=torch.float32, device=X.device) if want_partial else None
+        else:
+            No = N // 2 if epilogue == EPI_SWIGLU else N
+            out = torch.empty((Bn, No), dtype=torch.bfloat16, device=X.device)
+        _lib.check(lib.trace_op_skinny_gemm(_ptr(X), _ptr(W), _ptr(out), _ptr(R), Bn, N, K, epilogue, int(tiled), _stream()))
         return out
+
+    @staticmethod
+    def skinny_ks(N, K, epilogue, B):
+        return _lib.load().trace_op_skinny_ks(N, K, epilogue, B)
+
+    @staticmethod
+    def swiglu_combine(part, Bn):
+        lib = _lib.load()
+        N2 = part.shape[2]
+        out = torch.empty((Bn, N2 // 2), dtype=torch.bfloat16, device=part.device)
+        _lib.check(lib.trace_op_swiglu_combine(_ptr(part), part.shape[0], N2, _ptr(out), Bn, _stream()))
+        return out
+
+    @staticmethod
+    def add_rmsnorm(part, R, w, eps):
+        """(x, y): x = bf16(sum_ks part[ks, b]) + R[b]; y = RMSNorm(x) * w"""
+        lib = _lib.load()
+        Bn, N = R.shape
+        x, y = torch.empty_like(R), torch.empty_like(R)
+        _lib.check(lib.trace_op_add_rmsnorm(_ptr(part), part.shape[0], _ptr(R), _ptr(x), _ptr(w), _ptr(y), Bn, N, eps, _stream()))
+        return x, y
 
     @staticmethod
     def attn_decode(q, kcache, vcache, pos, nsplit, scale, vtcache=None):

@@ -1,14 +1,14 @@
-// Decode-step kernels (1 new token for each of B <= 16 sequences).  This is the HBM-bound heart of the path:
-// every step streams all 7.2 B bf16 weights once (reference: TraceMistralForCausalLM.forward with
-// input_ids [B,1] + past_key_values, trace/model/language_model/trace_mistral.py:114-264).
+// Decode-step kernels (1 new token for each of B <= 32 sequences).  This is the HBM-bound heart of the path:
+// every step streams all 7.2 B bf16 weights once plus the KV cache of every sequence (reference:
+// TraceMistralForCausalLM.forward with input_ids [B,1] + past_key_values, trace/model/language_model/trace_mistral.py:114-264).
 //
-// skinny_gemm:  out[b,n] = sum_k X[b,k] W[n,k].  One workgroup = 16 weight rows (32 for the fused
-//   gate|up pair), 8 waves split K; each lane streams 32 contiguous bytes of its weight row per step with
-//   non-temporal 16-byte loads (a 16-lane row group covers full 128-byte lines), feeds them to the 16x16x32
-//   bf16 MFMA as the A operand against the (L2-resident) activations as B, so B = 1..16 cost the same weight
-//   stream.  The k-slot permutation trick (A and B fragments only have to agree on which k each slot means)
-//   is what lets each lane read contiguous memory.  Partial tiles are combined through LDS.
-// attn_decode:  single-query GQA attention over the KV cache, split over the context, + combine.
+// skinny_lds:   out[b,n] = sum_k X[b,k] W[n,k] on the 16x16x32 bf16 MFMA with the weights as the A operand, streamed
+//   once from a tile-contiguous decode copy with non-temporal 16-byte loads, and the activations as B, parked in
+//   LDS.  The k-slot permutation trick (A and B fragments only have to agree on which k each slot means) lets each
+//   lane read 32 contiguous bytes.  The four GEMVs of a layer leave fp32 k-chunk partial rows; their consumers
+//   (attn_decode, add_rmsnorm, swiglu_combine) sum them on load.
+// attn_decode:  single-query GQA attention over the KV cache on the matrix cores (V cache stored transposed), split
+//   over the context, + RoPE, cache append and the cross-split merge.
 // head_logits / select_next:  active-head GEMV, masked arg-max (trace_mistral.py:244-252 + HF greedy), the
 //   head-switch state machine (trace_mistral.py:86-88,336-344) and the next-token embedding
 //   (trace_arch.py:345-375) — all on device, so a decode step never returns to the host.
@@ -29,130 +29,22 @@ __device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
 union Frag { uint4 u; bf16x8_t v; };
 
 // ---------------------------------------------------------------------------------------------------------
-// NB = number of 16-row activation groups (1: B <= 16, 2: B <= 32): the weight fragment is reused for both.
-template <int EPI, int NB>
-__global__ __launch_bounds__(512, 4) void skinny_gemm_kernel(const bf16_t* __restrict__ X, int ldx,
-                                                                            const bf16_t* __restrict__ W, int ldw,
-                                                                            bf16_t* __restrict__ out, int ldo,
-                                                                            const bf16_t* __restrict__ R, int ldr, int B, int N, int K, int dbg) {
-    constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;      // 16-row weight tiles per workgroup
-    constexpr int UN = NB == 1 ? 2 : 1;                  // 64-wide k units per load batch (keeps <= 128 VGPRs: 2 workgroups/CU)
-    __shared__ float red[8][NT * NB][256];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16 * NT;
-    const int U = K >> 6;
-    const int u0 = (wid * U) >> 3, u1 = ((wid + 1) * U) >> 3;
-
-    const bf16_t* wp[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) wp[t] = W + (size_t)(n0 + t * 16 + r) * ldw + g * 16;
-    bool xon[NB];
-    const bf16_t* xp[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        xon[nb] = r + 16 * nb < B;
-        xp[nb] = X + (size_t)((xon[nb] && !dbg) ? r + 16 * nb : 0) * ldx + g * 16;
-    }
-
-    f32x4_t acc[NT][NB];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    Frag wa[UN][NT][2], wb[UN][NT][2], xa[UN][NB][2], xb[UN][NB][2];
-    auto load = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][NB][2], int u) {
-#pragma unroll
-        for (int j = 0; j < UN; ++j) {
-            const bool ok = u + j < u1;
-            const int ko = (u + j) * 64;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                wf[j][t][0].u = ok ? ldg_nt(wp[t] + ko) : make_uint4(0, 0, 0, 0);
-                wf[j][t][1].u = ok ? ldg_nt(wp[t] + ko + 8) : make_uint4(0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                xf[j][nb][0].u = (ok && xon[nb]) ? *reinterpret_cast<const uint4*>(xp[nb] + ko) : make_uint4(0, 0, 0, 0);
-                xf[j][nb][1].u = (ok && xon[nb]) ? *reinterpret_cast<const uint4*>(xp[nb] + ko + 8) : make_uint4(0, 0, 0, 0);
-            }
-        }
-    };
-    auto mma = [&](Frag (&wf)[UN][NT][2], Frag (&xf)[UN][NB][2]) {
-#pragma unroll
-        for (int j = 0; j < UN; ++j)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][t][0].v, xf[j][nb][0].v, acc[t][nb], 0, 0, 0);
-                    acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][t][1].v, xf[j][nb][1].v, acc[t][nb], 0, 0, 0);
-                }
-    };
-    if (u0 < u1) {
-        load(wa, xa, u0);
-        for (int u = u0; u < u1; u += 2 * UN) {
-            if (u + UN < u1) load(wb, xb, u + UN);
-            mma(wa, xa);
-            if (u + UN < u1) {
-                if (u + 2 * UN < u1) load(wa, xa, u + 2 * UN);
-                mma(wb, xb);
-            }
-        }
-    }
-    // acc[t][nb][i] = partial out[m = 16*nb + r][n = n0 + t*16 + g*4 + i]
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) red[wid][t * NB + nb][i * 64 + lane] = acc[t][nb][i];
-    __syncthreads();
-    if (tid < 256) {
-        const int i = tid >> 6, l = tid & 63;
-        const int nl = (l >> 4) * 4 + i;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int m = (l & 15) + 16 * nb;
-            float v[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                float s = 0.f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) s += red[w][t * NB + nb][tid];
-                v[t] = s;
-            }
-            if (m < B) {
-                if (EPI == EPI_SWIGLU) {
-                    const float gt = v[0], up = v[NT - 1];
-                    out[(size_t)m * ldo + (n0 >> 1) + nl] = f2bf(gt / (1.f + __expf(-gt)) * up);
-                } else {
-                    float o = v[0];
-                    if (EPI == EPI_RESIDUAL) o = bf2f(f2bf(o)) + bf2f(R[(size_t)m * ldr + n0 + nl]);
-                    out[(size_t)m * ldo + n0 + nl] = f2bf(o);
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// skinny_lds: the same product with the ACTIVATIONS STATIONARY IN LDS.  In skinny_gemm every workgroup re-reads all
-// of X from L2 (B x K bf16 per 16 weight rows): at B = 32 that L2 stream is as large as the weight stream itself and
-// costs 30-60% (measured: gate|up 72 us vs 55 us with the X loads neutered, down 45 vs 29, qkv 26 vs 16).  Here one
-// workgroup per CU parks a K-chunk of X (up to 2048 k = 128 KB for 32 rows) in LDS once, in MFMA-fragment order
-// (every later read is a lane-linear ds_read_b128), and streams several 16-row weight tiles against it:
-//   grid = KS k-chunks x row-groups (<= #CUs workgroups), workgroup = T tasks x WPT waves; a task is one weight tile
-//   (a gate|up tile pair) over the chunk, its k-units split over WPT waves (LDS-reduced) when T is small.
-// K-chunk partials of a tile ([KS][NT*NB][64 lanes][4] fp32, written through) are merged by whichever wave takes
-// the last agent-scope ticket of the tile, always in chunk order -> results do not depend on arrival order.  That
-// merge costs ~5 us of dependent round trips (store drain -> ticket -> acquire -> loads), so the two GEMVs whose
-// consumer is a row kernel anyway (o-proj, down-proj -> residual add + RMSNorm) use EPI_PARTIAL instead: plain fp32
-// partial rows [ks][32][N] and add_rmsnorm_kernel below sums them on load.
-// Weights: `tiled` = the decode copy [N/16][K/64][64 lanes][16] (one 2 KB block per 16 rows x 64 k, lane-linear, so a
-// wave's stream is ONE contiguous run: measured +24% over 16 interleaved 8 KB-strided row streams, which thrash DRAM
-// pages); row-major [N][K] is kept for small callers (STC squeeze-excite).
+// skinny_lds: decode GEMV with the ACTIVATIONS STATIONARY IN LDS.
+// History: the first version gave every workgroup 16 weight rows and all of K, and read X (B x K bf16, L2-resident)
+// straight into MFMA fragments.  At B = 32 that L2 stream is as large as the weight stream itself and cost 30-60 %
+// (gate|up 72 us vs 55 us with the X loads neutered, down 45 vs 29, qkv 26 vs 16); its 16 interleaved 8 KB-strided
+// row streams per wave also thrashed DRAM pages (the same bytes read as one contiguous run: 51.7 -> 41.7 us).
+// Now one workgroup per CU parks a K-chunk of X (<= 128 KB: 4096 k for 16 rows, 2048 k for 32) in LDS once, in
+// MFMA-fragment order (every later read is a lane-linear ds_read_b128), and streams several weight tiles against it:
+//   grid = KS k-chunks x row-groups (<= #CUs workgroups), workgroup = T tasks x WPT waves; a task is NT 16-row weight
+//   tiles over the chunk, its k-units split over WPT waves (LDS-reduced, fixed order) when T is small.
+// Weights: `tiled` = the decode copy [N/16][K/64][64 lanes][16] (one 2 KB block per 16 rows x 64 k, lane-linear, so
+// a wave's stream is ONE contiguous run); row-major [N][K] is kept for small callers (STC squeeze-excite).
+// Epilogues: EPI_PARTIAL (the decode step's path) stores plain fp32 partial rows [ks][32][N] and the CONSUMER kernel
+// sums the chunks on load.  EPI_NONE / RESIDUAL / SWIGLU finish in-kernel: with KS > 1 the chunk partials of a tile
+// ([KS][NT*NB][64 lanes][4] fp32, written through) are merged by whichever wave takes the tile's last agent-scope
+// ticket, always in chunk order, so results do not depend on arrival order — but that merge costs 5-8 us of dependent
+// round trips (store drain -> ticket -> acquire -> loads) per launch, which is why the decode step does not use it.
 template <int EPI, int NB, int NT>
 __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W, int ldw,
                                                          bf16_t* __restrict__ out, int ldo, const bf16_t* __restrict__ R, int ldr,
@@ -882,20 +774,7 @@ __global__ __launch_bounds__(256) void select_next_kernel(const float* __restric
 }
 }  // namespace
 
-int g_skinny_debug = 0; // microbenchmark-only: 1 = skinny_gemm with every lane reading activation row 0 (no X traffic; wrong
-                        // results), 2 = force the L2-activation kernel (skinny_gemm) for every call
-static int skinny_l2(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R, int ldr,
-                     int B, int N, int K, int epi, hipStream_t s) {
-#define SK(EPI_, NB_, GRID_) hipLaunchKernelGGL((skinny_gemm_kernel<EPI_, NB_>), dim3(GRID_), dim3(512), 0, s, X, ldx, W, ldw, out, ldo, R, ldr, B, N, K, g_skinny_debug == 1)
-    switch (epi) {
-        case EPI_NONE: if (B <= 16) SK(EPI_NONE, 1, N / 16); else SK(EPI_NONE, 2, N / 16); break;
-        case EPI_RESIDUAL: if (B <= 16) SK(EPI_RESIDUAL, 1, N / 16); else SK(EPI_RESIDUAL, 2, N / 16); break;
-        default: if (B <= 16) SK(EPI_SWIGLU, 1, N / 32); else SK(EPI_SWIGLU, 2, N / 32); break;
-    }
-#undef SK
-    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
-}
-
+int g_skinny_debug = 0;   // microbenchmark-only: 3 = stop before the epilogue, 4 = stop after the partial stores (ticket path)
 // Partition for skinny_lds (see the kernel header): KS k-chunks x row-groups of T tiles, WPT waves per tile.
 struct SkinnyPlan { int KS, chunk_units, T, WPT, ntiles, grid, threads; };
 static int skinny_num_cus() {
@@ -967,10 +846,6 @@ int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_
     if (B < 1 || B > 32 || K % 64 || (ldx % 8) || (ldw % 8) || (ldo % 4)) return TRACE_ERR_ARG;
     if (epi != EPI_NONE && epi != EPI_RESIDUAL && epi != EPI_SWIGLU && epi != EPI_PARTIAL) return TRACE_ERR_ARG;
     if (N % (epi == EPI_SWIGLU ? 32 : 16) || (epi == EPI_RESIDUAL && (!R || ldr % 4))) return TRACE_ERR_ARG;
-    if (g_skinny_debug == 1 || g_skinny_debug == 2) {
-        if (tiled || epi == EPI_PARTIAL) return TRACE_ERR_ARG;
-        return skinny_l2(X, ldx, W, ldw, out, ldo, R, ldr, B, N, K, epi, s);
-    }
     const SkinnyPlan p = skinny_plan(N, K, epi, B);
     const size_t need = skinny_plan_ws(p, N, epi, B);
     if (need && (!ws || ws_floats < need)) return TRACE_ERR_ARG;

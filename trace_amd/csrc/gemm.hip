@@ -27,7 +27,10 @@ __device__ __forceinline__ int swz(int row, int kc) { return row * 128 + ((kc ^ 
 // vmcnt + raw s_barrier — gave nothing: the loop is not load-latency bound; (2) a persistent one-workgroup-per-CU
 // version that prefetches the next output tile's first K-tile under a two-half epilogue was 5-15 % SLOWER on the
 // K = 1024 ViT shapes than letting the dispatcher place fresh workgroups (static tile assignment + two extra
-// epilogue barriers cost more than the hidden prologue).  Per-tile fixed cost is ~13 us vs ~1.6 us per K-tile.
+// epilogue barriers cost more than the hidden prologue); (3) de-phasing the first wave of workgroups (groups of CUs
+// sleeping 3-10 us before their first tile so that the tiles' HBM write bursts do not coincide) moved the ViT shapes by
+// -4..+1 % — the epilogues are not synchronised enough for write bandwidth to be what the fixed cost pays for.
+// Per-tile fixed cost is ~13 us vs ~1.6 us per K-tile.
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     constexpr int NW = WM * WN, NTHR = NW * 64;

@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" = one pass of the hot path over one batch of `--videos-per-step` (default 32) videos per GPU, inputs already
+A "step" = one pass of the hot path over one batch of `--videos-per-step` (default 64) videos per GPU, inputs already
 resident in HBM: CLIP-ViT-L/14-336 over 128 frames -> SpatialSlotPool -> splice -> Mistral-7B prefill (L = 1968) -> 256 greedy
 decode steps with head switching, then ONE RCCL all-gather of the packed token ids (N > 1).  Prints one JSON line
 (rank 0) with the whole-job videos/sec, the decode tokens/sec, the roofline of the dominant kernel (the fused gate|up
@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--videos-per-step", type=int, default=int(os.environ.get("TRACE_BENCH_BATCH", "32")))
+    ap.add_argument("--videos-per-step", type=int, default=int(os.environ.get("TRACE_BENCH_BATCH", "64")))
     ap.add_argument("--frames", type=int, default=128)
     ap.add_argument("--max-new", type=int, default=256)
     ap.add_argument("--graph", action="store_true",

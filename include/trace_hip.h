@@ -115,14 +115,14 @@ int trace_op_layernorm(const void* x, void* y, const void* w, const void* b, int
 int trace_op_rmsnorm(const void* x, void* y, const void* w, int rows, int D, float eps, void* stream);
 int trace_op_attention(const void* Q, const void* K, const void* V, void* O, void* vt_scratch, int batch, int heads,
                        int kv_heads, int nq, int nkv, int head_dim, int causal, float scale, void* stream);
-/* Decode GEMV out[b,n] = sum_k X[b,k] W[n,k], B <= 32.  w_tiled: W in the decode tile layout written by
+/* Decode GEMV out[b,n] = sum_k X[b,k] W[n,k], B <= 64.  w_tiled: W in the decode tile layout written by
    trace_op_tile_pack ([N/16][K/64][64][16]) instead of row-major.  epilogue 0 none, 1 +R, 3 SwiGLU (16-row interleaved
-   gate|up), 4 partial: `out` = fp32 k-chunk partial rows [trace_op_skinny_ks()][32][N] for trace_op_add_rmsnorm. */
+   gate|up), 4 partial: `out` = fp32 k-chunk partial rows [trace_op_skinny_ks()][64][N] for trace_op_add_rmsnorm. */
 int trace_op_skinny_gemm(const void* X, const void* W, void* out, const void* R, int B, int N, int K, int epilogue,
                          int w_tiled, void* stream);
 int trace_op_skinny_ks(int N, int K, int epilogue, int B);
 int trace_op_tile_pack(const void* W, void* Wt, int N, int K, void* stream);
-/* out[b][j] = bf16(silu(sum_ks gate) * sum_ks up) from partial rows [KS][32][N2] of the 16-row interleaved gate|up GEMV */
+/* out[b][j] = bf16(silu(sum_ks gate) * sum_ks up) from partial rows [KS][64][N2] of the 16-row interleaved gate|up GEMV */
 int trace_op_swiglu_combine(const float* part, int KS, int N2, void* out, int B, void* stream);
 /* x = bf16(sum_ks part[ks][b][:]) + R[b][:] -> xout;  y = RMSNorm(x) * w   (decode residual add + norm, N <= 4096) */
 int trace_op_add_rmsnorm(const float* part, int KS, const void* R, void* xout, const void* w, void* y, int B, int N,

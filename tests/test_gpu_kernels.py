@@ -140,7 +140,8 @@ def test_attention_prefill_causal_gqa(L, kvh):
 
 
 @pytest.mark.parametrize("Bn,N,K", [(1, 128, 256), (1, 4096, 4096), (3, 6144, 4096), (16, 256, 14336), (2, 512, 128),
-                                    (17, 256, 4096), (32, 512, 14336), (25, 6144, 4096), (20, 16384, 256)])
+                                    (17, 256, 4096), (32, 512, 14336), (25, 6144, 4096), (20, 16384, 256), (40, 512, 4096), (64, 4096, 14336),
+                                    (50, 16384, 512)])
 def test_skinny_gemm(Bn, N, K):
     X, W, R = rnd(Bn, K), rnd(N, K, scale=0.05), rnd(Bn, N)
     lin = X.float() @ W.float().t()

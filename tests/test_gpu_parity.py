@@ -189,19 +189,20 @@ def test_errors_are_python_exceptions(setup):
         eng.time_ids([[1.0], [2.0, 3.0]])       # unequal time-token length (trace_arch.py:285)
 
 
-def test_batch_20_equals_single(setup):
-    """B > 16 exercises the two-group (NB = 2) decode GEMV / head kernels: 20 sequences (two distinct videos,
-    alternating) must reproduce the B = 1 streams."""
+@pytest.mark.parametrize("nb", [20, 40])
+def test_big_batch_equals_single(setup, nb):
+    """B > 16 / B > 32 exercise the two- and four-group decode GEMV (NB = 2, 4) and the second head pass: nb sequences
+    (two distinct videos, alternating) must reproduce the B = 1 streams."""
     cfg, eng, ora, E, frames = setup
     f2 = synth.synth_frames(cfg, 1).to(torch.bfloat16)
     ts, ids = E["timestamps"].tolist(), E["input_ids"].tolist()
     n = 16
     a, _ = eng.generate([frames], [ts], [ids], [1], n)
     b, _ = eng.generate([f2], [ts], [ids], [1], n)
-    big = TraceEngine(cfg, max_batch=20, max_ctx=192, max_frames=4, max_new_tokens=32)
+    big = TraceEngine(cfg, max_batch=nb, max_ctx=192, max_frames=4, max_new_tokens=32)
     big.load_weights(synth.state_dict(cfg).items())
-    vids = [frames if i % 2 == 0 else f2 for i in range(20)]
-    out, _ = big.generate(vids, [ts] * 20, [ids] * 20, [1] * 20, n)
-    for i in range(20):
+    vids = [frames if i % 2 == 0 else f2 for i in range(nb)]
+    out, _ = big.generate(vids, [ts] * nb, [ids] * nb, [1] * nb, n)
+    for i in range(nb):
         assert out[i] == (a[0] if i % 2 == 0 else b[0]), i
     big.close()

@@ -36,11 +36,11 @@ union Frag { uint4 u; bf16x8_t v; };
 // row streams per wave also thrashed DRAM pages (the same bytes read as one contiguous run: 51.7 -> 41.7 us).
 // Now one workgroup per CU parks a K-chunk of X (<= 128 KB: 4096 k for 16 rows, 2048 k for 32) in LDS once, in
 // MFMA-fragment order (every later read is a lane-linear ds_read_b128), and streams several weight tiles against it:
-//   grid = KS k-chunks x row-groups (<= #CUs workgroups), workgroup = T tasks x WPT waves; a task is NT 16-row weight
-//   tiles over the chunk, its k-units split over WPT waves (LDS-reduced, fixed order) when T is small.
+//   grid = KS k-chunks x row-groups (<= #CUs workgroups), workgroup = T <= 16 tasks on <= 8 waves; a task is NT 16-row
+//   weight tiles over the chunk; when T <= 4 its k-units are split over WPT waves (LDS-reduced, fixed order).
 // Weights: `tiled` = the decode copy [N/16][K/64][64 lanes][16] (one 2 KB block per 16 rows x 64 k, lane-linear, so
 // a wave's stream is ONE contiguous run); row-major [N][K] is kept for small callers (STC squeeze-excite).
-// Epilogues: EPI_PARTIAL (the decode step's path) stores plain fp32 partial rows [ks][32][N] and the CONSUMER kernel
+// Epilogues: EPI_PARTIAL (the decode step's path) stores plain fp32 partial rows [ks][SK_ROWS][N] and the CONSUMER kernel
 // sums the chunks on load.  EPI_NONE / RESIDUAL / SWIGLU finish in-kernel: with KS > 1 the chunk partials of a tile
 // ([KS][NT*NB][64 lanes][4] fp32, written through) are merged by whichever wave takes the tile's last agent-scope
 // ticket, always in chunk order, so results do not depend on arrival order — but that merge costs 5-8 us of dependent
@@ -62,19 +62,10 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restric
     const int ks = blockIdx.x % KS, rg = blockIdx.x / KS;
     const int U = K >> 6;
     const int u_beg = ks * chunk_units, nu = min(U - u_beg, chunk_units);
-    const int task = wid / WPT, wsub = wid - task * WPT;
-    const int tile = rg * T + task;
-    const bool active = task < T && tile < ntiles;
+    const int team = wid / WPT, wsub = wid - team * WPT, nteams = nwaves / WPT;
     const int ua = (wsub * nu) / WPT, ub = ((wsub + 1) * nu) / WPT;                     // this wave's units of the chunk
-    const int n0 = tile * 16 * NT;
-
-    const bf16_t* wp[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (tiled) wp[t] = W + ((size_t)(active ? tile * NT + t : 0) * U + u_beg) * 1024 + lane * 16;
-        else wp[t] = W + (size_t)(active ? n0 + t * 16 + r : 0) * ldw + (size_t)u_beg * 64 + g * 16;
-    }
     const int ustride = tiled ? 1024 : 64;
+    const bf16_t* wp[NT];
     Frag wa[UN][NT][2], wb[UN][NT][2];
     auto loadw = [&](Frag (&wf)[UN][NT][2], int u) {
 #pragma unroll
@@ -88,12 +79,25 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restric
             }
         }
     };
+    f32x4_t acc[NT][NB];
+    // a team takes tasks team, team + nteams, ... of the workgroup's T (WPT > 1: nteams == T, one pass for every wave,
+    // so the barriers below stay workgroup-uniform)
+    bool parked = false;
+    for (int task = team; task < T; task += nteams) {
+    const int tile = rg * T + task;
+    const bool active = tile < ntiles;
+    const int n0 = tile * 16 * NT;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (tiled) wp[t] = W + ((size_t)(active ? tile * NT + t : 0) * U + u_beg) * 1024 + lane * 16;
+        else wp[t] = W + (size_t)(active ? n0 + t * 16 + r : 0) * ldw + (size_t)u_beg * 64 + g * 16;
+    }
     const bool work = active && ua < ub;
     if (work) loadw(wa, ua);                             // the weight stream starts before the activations are parked
 
     // ---- park X[:, chunk] in LDS in fragment order: combo c = (unit*2 + half)*NB + nb, lane (r, g) holds
     //      X[16 nb + r][(u_beg + unit)*64 + g*16 + half*8 .. +8]  (zeros for rows >= B) ----
-    {
+    if (!parked) {
         const int combos = nu * 2 * NB;
         for (int c0 = wid; c0 < combos; c0 += nwaves * 4) {
             u32x4_t v[4];
@@ -112,10 +116,10 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restric
                 if (c < combos) xs[c * 64 + lane] = v[q];
             }
         }
+        __syncthreads();
+        parked = true;
     }
-    __syncthreads();
 
-    f32x4_t acc[NT][NB];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restric
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) red[((task * WPT + wsub) * NF + t * NB + nb) * 64 + lane] = acc[t][nb];
+                for (int nb = 0; nb < NB; ++nb) red[((team * WPT + wsub) * NF + t * NB + nb) * 64 + lane] = acc[t][nb];
         }
         __syncthreads();
         if (active && wsub == 0) {
@@ -161,15 +165,15 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restric
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    f32x4_t sacc = red[((task * WPT) * NF + t * NB + nb) * 64 + lane];
-                    for (int w = 1; w < WPT; ++w) sacc += red[((task * WPT + w) * NF + t * NB + nb) * 64 + lane];
+                    f32x4_t sacc = red[((team * WPT) * NF + t * NB + nb) * 64 + lane];
+                    for (int w = 1; w < WPT; ++w) sacc += red[((team * WPT + w) * NF + t * NB + nb) * 64 + lane];
                     acc[t][nb] = sacc;
                 }
         }
     }
-    if (!active || wsub != 0 || dbg == 3) return;
-    if (EPI == EPI_PARTIAL) {                           // fp32 partial rows [ks][32][N = ldo]; the consumer sums the chunks
-        float* pr = ws + (size_t)ks * 32 * ldo;
+    if (!active || wsub != 0 || dbg == 3) continue;
+    if (EPI == EPI_PARTIAL) {                           // fp32 partial rows [ks][SK_ROWS][N = ldo]; the consumer sums the chunks
+        float* pr = ws + (size_t)ks * SK_ROWS * ldo;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int m = 16 * nb + r;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restric
                 for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4_t*>(pr + (size_t)m * ldo + n0 + t * 16 + g * 4) = acc[t][nb];
             }
         }
-        return;
+        continue;
     }
     // ---- K-chunk partials: publish, ticket, the last wave of the tile merges in chunk order ----
     if (KS > 1) {
@@ -192,11 +196,11 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restric
                     __hip_atomic_store(&wt[((size_t)(ks * NF + t * NB + nb) * 4 + e) * 64 + lane], acc[t][nb][e], __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (dbg == 4) return;
+        if (dbg == 4) continue;
         unsigned tk = 0;
         if (lane == 0) tk = __hip_atomic_fetch_add(&tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tk = __builtin_amdgcn_readfirstlane(tk);
-        if (tk != (unsigned)(KS - 1)) return;
+        if (tk != (unsigned)(KS - 1)) continue;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -236,6 +240,7 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restric
             *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n0 + g * 4) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
         }
     }
+    }   // task loop
 }
 
 // SwiGLU over EPI_PARTIAL rows of the gate|up product (16-row interleaved: columns [32p, 32p+16) gate, [32p+16, 32p+32)
@@ -250,8 +255,8 @@ __global__ __launch_bounds__(256) void swiglu_combine_kernel(const float* __rest
     const float* base = part + (size_t)b * N2 + p * 32 + i;
     f32x4_t gt = *reinterpret_cast<const f32x4_t*>(base), up = *reinterpret_cast<const f32x4_t*>(base + 16);
     for (int k2 = 1; k2 < KS; ++k2) {
-        gt += *reinterpret_cast<const f32x4_t*>(base + (size_t)k2 * 32 * N2);
-        up += *reinterpret_cast<const f32x4_t*>(base + (size_t)k2 * 32 * N2 + 16);
+        gt += *reinterpret_cast<const f32x4_t*>(base + (size_t)k2 * SK_ROWS * N2);
+        up += *reinterpret_cast<const f32x4_t*>(base + (size_t)k2 * SK_ROWS * N2 + 16);
     }
     float o[4];
 #pragma unroll
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const float* __restric
         if (c < nch) {
             wv[i] = *reinterpret_cast<const uint2*>(w + c * 4);
             f32x4_t a = *reinterpret_cast<const f32x4_t*>(part + (size_t)b * N + c * 4);
-            for (int k2 = 1; k2 < KS; ++k2) a += *reinterpret_cast<const f32x4_t*>(part + ((size_t)k2 * 32 + b) * N + c * 4);
+            for (int k2 = 1; k2 < KS; ++k2) a += *reinterpret_cast<const f32x4_t*>(part + ((size_t)k2 * SK_ROWS + b) * N + c * 4);
             const uint2 rr = *reinterpret_cast<const uint2*>(R + (size_t)b * ldr + c * 4);
             const float x0 = bf2f(f2bf(a[0])) + bflo(rr.x), x1 = bf2f(f2bf(a[1])) + bfhi(rr.x);
             const float x2 = bf2f(f2bf(a[2])) + bflo(rr.y), x3 = bf2f(f2bf(a[3])) + bfhi(rr.y);
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
     const int nit = (len + 31) >> 5;                  // 32-position blocks in this split
     bf16_t* kb = kcache + (size_t)slots[b] * slot_stride + (size_t)kvh * kv_head_stride;
     bf16_t* vb = vtcache + (size_t)slots[b] * slot_stride + (size_t)kvh * kv_head_stride;
-    // the qkv row of this sequence: bf16 [ldq], or (qpart) the qkv GEMV's fp32 k-chunk partial rows [qks][32][ldq], summed
+    // the qkv row of this sequence: bf16 [ldq], or (qpart) the qkv GEMV's fp32 k-chunk partial rows [qks][SK_ROWS][ldq], summed
     // and rounded to bf16 here (what the GEMV epilogue would have stored)
     const bf16_t* row = qkv + (size_t)b * ldq;
     auto slice8 = [&](int n) -> u32x4_t {
@@ -370,15 +375,15 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
         const float* pp = qpart + (size_t)b * ldq + n;
         f32x4_t a = *reinterpret_cast<const f32x4_t*>(pp), c = *reinterpret_cast<const f32x4_t*>(pp + 4);
         for (int k2 = 1; k2 < qks; ++k2) {
-            a += *reinterpret_cast<const f32x4_t*>(pp + (size_t)k2 * 32 * ldq);
-            c += *reinterpret_cast<const f32x4_t*>(pp + (size_t)k2 * 32 * ldq + 4);
+            a += *reinterpret_cast<const f32x4_t*>(pp + (size_t)k2 * SK_ROWS * ldq);
+            c += *reinterpret_cast<const f32x4_t*>(pp + (size_t)k2 * SK_ROWS * ldq + 4);
         }
         return u32x4_t{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(c[0], c[1]), pack2bf(c[2], c[3])};
     };
     auto elem = [&](int n) -> bf16_t {
         if (!qpart) return row[n];
         float a = qpart[(size_t)b * ldq + n];
-        for (int k2 = 1; k2 < qks; ++k2) a += qpart[((size_t)k2 * 32 + b) * ldq + n];
+        for (int k2 = 1; k2 < qks; ++k2) a += qpart[((size_t)k2 * SK_ROWS + b) * ldq + n];
         return f2bf(a);
     };
     const bool owner = fuse_rope && len > 0 && end == ctx;       // this split holds the newest position
@@ -708,7 +713,8 @@ __global__ __launch_bounds__(512) void head_logits_kernel(const bf16_t* __restri
     }
 }
 
-// one workgroup; sequences handled one after another by all 256 threads
+// one workgroup per sequence.  `step` is shared: every workgroup reads it first, then checks in; the last one to
+// check in advances it (so no workgroup can observe the next step's value).
 __global__ __launch_bounds__(256) void select_next_kernel(const float* __restrict__ part_val, const int32_t* __restrict__ part_idx,
                                                           StepState st, const bf16_t* __restrict__ embed,
                                                           const bf16_t* __restrict__ time_tab, const bf16_t* __restrict__ score_tab,
@@ -718,59 +724,64 @@ __global__ __launch_bounds__(256) void select_next_kernel(const float* __restric
     __shared__ int si[4];
     __shared__ int s_feed;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int step = *st.step;
+    const int b = blockIdx.x;
+    const int step = __hip_atomic_load(st.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int max_new = st.params[0], eos = st.params[1], record_feed = st.params[2];
-    for (int b = 0; b < B; ++b) {
-        float v = -INFINITY;
-        int idx = 0x7fffffff;
-        for (int t = tid; t < ntiles; t += 256) {
-            const float ov = part_val[(size_t)b * ntiles + t];
-            const int oi = part_idx[(size_t)b * ntiles + t];
-            if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    __syncthreads();
+    if (tid == 0) {
+        const int arrived = __hip_atomic_fetch_add(st.step + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == B - 1) {
+            __hip_atomic_store(st.step + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st.step, step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(v, o, 64);
-            const int oi = __shfl_xor(idx, o, 64);
-            if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-        }
-        if (lane == 0) { sv[wid] = v; si[wid] = idx; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < 4; ++w)
-                if (sv[w] > v || (sv[w] == v && si[w] < idx)) { v = sv[w]; idx = si[w]; }
-            int tok = idx;
-            if (advance) st.pos[b] += 1;
-            int feed = tok;
-            if (step < max_new) {
-                const int f = st.forced[(size_t)b * max_new + step];
-                if (f >= 0) feed = f;
-            }
-            if (record_feed) tok = feed;          // host-driven sampling: the emitted token is the one fed back
-            const bool was_done = st.done[b] != 0;
-            if (!was_done && step < max_new) {
-                st.out_ids[(size_t)b * max_new + step] = tok;
-                st.out_len[b] = step + 1;
-                if (eos >= 0 && tok == eos) st.done[b] = 1;
-            }
-            // head switch (trace_mistral.py:86-88): V -> time(1), V+1 -> score(2), V+Tv+1 -> text(0)
-            int hd = st.heads[b];
-            if (feed == V) hd = 1; else if (feed == V + 1) hd = 2; else if (feed == V + Tv + 1) hd = 0;
-            st.heads[b] = hd;
-            s_feed = feed;
-        }
-        __syncthreads();
-        const int feed = s_feed;
-        const bf16_t* src;
-        if (feed == V) src = sync_row;
-        else if (feed > V && feed < V + 1 + Tv) src = time_tab + (size_t)(feed - V - 1) * H;
-        else if (feed >= V + 1 + Tv) src = score_tab + (size_t)(feed - V - 1 - Tv) * H;
-        else src = embed + (size_t)(feed % V) * H;
-        for (int c = tid; c < (H >> 3); c += 256)
-            *reinterpret_cast<uint4*>(xnext + (size_t)b * ldx + c * 8) = *reinterpret_cast<const uint4*>(src + c * 8);
-        __syncthreads();
     }
-    if (tid == 0) *st.step = step + 1;
+    float v = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int t = tid; t < ntiles; t += 256) {
+        const float ov = part_val[(size_t)b * ntiles + t];
+        const int oi = part_idx[(size_t)b * ntiles + t];
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    if (lane == 0) { sv[wid] = v; si[wid] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > v || (sv[w] == v && si[w] < idx)) { v = sv[w]; idx = si[w]; }
+        int tok = idx;
+        if (advance) st.pos[b] += 1;
+        int feed = tok;
+        if (step < max_new) {
+            const int f = st.forced[(size_t)b * max_new + step];
+            if (f >= 0) feed = f;
+        }
+        if (record_feed) tok = feed;          // host-driven sampling: the emitted token is the one fed back
+        const bool was_done = st.done[b] != 0;
+        if (!was_done && step < max_new) {
+            st.out_ids[(size_t)b * max_new + step] = tok;
+            st.out_len[b] = step + 1;
+            if (eos >= 0 && tok == eos) st.done[b] = 1;
+        }
+        // head switch (trace_mistral.py:86-88): V -> time(1), V+1 -> score(2), V+Tv+1 -> text(0)
+        int hd = st.heads[b];
+        if (feed == V) hd = 1; else if (feed == V + 1) hd = 2; else if (feed == V + Tv + 1) hd = 0;
+        st.heads[b] = hd;
+        s_feed = feed;
+    }
+    __syncthreads();
+    const int feed = s_feed;
+    const bf16_t* src;
+    if (feed == V) src = sync_row;
+    else if (feed > V && feed < V + 1 + Tv) src = time_tab + (size_t)(feed - V - 1) * H;
+    else if (feed >= V + 1 + Tv) src = score_tab + (size_t)(feed - V - 1 - Tv) * H;
+    else src = embed + (size_t)(feed % V) * H;
+    for (int c = tid; c < (H >> 3); c += 256)
+        *reinterpret_cast<uint4*>(xnext + (size_t)b * ldx + c * 8) = *reinterpret_cast<const uint4*>(src + c * 8);
 }
 }  // namespace
 
@@ -788,12 +799,13 @@ static int skinny_num_cus() {
     return n;
 }
 static int skinny_nt(int N, int epi) { return epi == EPI_SWIGLU || (epi == EPI_PARTIAL && N >= 16384 && N % 32 == 0) ? 2 : 1; }
+static int skinny_nb(int B) { return B > 32 ? 4 : B > 16 ? 2 : 1; }       // 16-row activation groups
 static SkinnyPlan skinny_plan(int N, int K, int epi, int B) {
     SkinnyPlan p{};
-    const int NT = skinny_nt(N, epi), NB = B > 16 ? 2 : 1;
+    const int NT = skinny_nt(N, epi), NB = skinny_nb(B);
     const int U = K / 64;
     static const int cap1 = getenv("TRACE_SK_CAP") ? atoi(getenv("TRACE_SK_CAP")) : 64;    // tuning knob (microbenchmarks)
-    const int cap = NB == 2 ? 32 : cap1;                  // units of X that fit 128 KB of LDS
+    const int cap = NB == 1 ? cap1 : 64 / NB;             // units of X that fit 128 KB of LDS
     const int ks_min = (U + cap - 1) / cap;
     const int ks_max = epi == EPI_PARTIAL ? std::min(U, ks_min + 4) : ks_min;    // extra chunks are free only without the ticket merge
     p.ntiles = N / (16 * NT);
@@ -801,7 +813,7 @@ static SkinnyPlan skinny_plan(int N, int K, int epi, int B) {
     long best = -1;
     for (int ks = ks_min; ks <= ks_max; ++ks) {
         const int chunk = (U + ks - 1) / ks;
-        for (int T = 1; T <= 8; ++T) {
+        for (int T = 1; T <= 16; ++T) {
             const int grid = ks * ((p.ntiles + T - 1) / T);
             const long rounds = (grid + ncu - 1) / ncu;
             const long cost = rounds * T * chunk * 64 + rounds * 8 + ks;   // per-CU weight stream; ties -> fewer rounds, fewer chunks
@@ -809,18 +821,20 @@ static SkinnyPlan skinny_plan(int N, int K, int epi, int B) {
         }
     }
     p.WPT = 1;
-    const int wmax = NT * NB == 4 ? 4 : 8;                // bounds the LDS reduction scratch (T*WPT*NT*NB KB)
-    while (p.WPT * 2 * p.T <= 8 && p.WPT * 2 <= wmax && p.WPT * 2 <= p.chunk_units) p.WPT *= 2;
-    p.threads = p.T * p.WPT * 64;
+    // T*WPT <= 8 waves; the LDS reduction scratch (T*WPT*NT*NB KB) must fit beside the 128 KB of parked activations
+    while (p.WPT * 2 * p.T <= 8 && p.WPT * 2 * p.T * NT * NB <= 28 && p.WPT * 2 <= p.chunk_units) p.WPT *= 2;
+    p.threads = std::min(p.T, 8) * p.WPT * 64;          // T > 8: every wave takes two tasks in turn
     return p;
 }
 static size_t skinny_plan_ws(const SkinnyPlan& p, int N, int epi, int B) {
-    if (epi == EPI_PARTIAL) return (size_t)p.KS * 32 * N;
-    const int NT = skinny_nt(N, epi), NB = B > 16 ? 2 : 1;
+    if (epi == EPI_PARTIAL) return (size_t)p.KS * SK_ROWS * N;
+    const int NT = skinny_nt(N, epi), NB = skinny_nb(B);
     return p.KS > 1 ? (size_t)p.ntiles * p.KS * NT * NB * 256 : 0;
 }
 size_t skinny_ws_floats(int N, int K, int epi) {
-    return std::max(skinny_plan_ws(skinny_plan(N, K, epi, 1), N, epi, 1), skinny_plan_ws(skinny_plan(N, K, epi, 32), N, epi, 32));
+    size_t f = 0;
+    for (int B : {1, 32, 64}) f = std::max(f, skinny_plan_ws(skinny_plan(N, K, epi, B), N, epi, B));
+    return f;
 }
 int skinny_ks(int N, int K, int epi, int B) { return skinny_plan(N, K, epi, B).KS; }
 
@@ -843,7 +857,7 @@ static int skinny_lds_launch(const SkinnyPlan& p, const bf16_t* X, int ldx, cons
 int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R, int ldr,
                        int B, int N, int K, int epi, int tiled, float* ws, size_t ws_floats, unsigned int* tickets, int ntickets,
                        hipStream_t s) {
-    if (B < 1 || B > 32 || K % 64 || (ldx % 8) || (ldw % 8) || (ldo % 4)) return TRACE_ERR_ARG;
+    if (B < 1 || B > SK_ROWS || K % 64 || (ldx % 8) || (ldw % 8) || (ldo % 4)) return TRACE_ERR_ARG;
     if (epi != EPI_NONE && epi != EPI_RESIDUAL && epi != EPI_SWIGLU && epi != EPI_PARTIAL) return TRACE_ERR_ARG;
     if (N % (epi == EPI_SWIGLU ? 32 : 16) || (epi == EPI_RESIDUAL && (!R || ldr % 4))) return TRACE_ERR_ARG;
     const SkinnyPlan p = skinny_plan(N, K, epi, B);
@@ -852,7 +866,8 @@ int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_
     if (epi != EPI_PARTIAL && p.KS > 1 && (!tickets || ntickets < p.ntiles)) return TRACE_ERR_ARG;
     if (epi == EPI_PARTIAL) ldo = N;
 #define SL(EPI_, NT_) (B <= 16 ? skinny_lds_launch<EPI_, 1, NT_>(p, X, ldx, W, ldw, out, ldo, R, ldr, B, K, ws, tickets, tiled, s) \
-                               : skinny_lds_launch<EPI_, 2, NT_>(p, X, ldx, W, ldw, out, ldo, R, ldr, B, K, ws, tickets, tiled, s))
+                     : B <= 32 ? skinny_lds_launch<EPI_, 2, NT_>(p, X, ldx, W, ldw, out, ldo, R, ldr, B, K, ws, tickets, tiled, s) \
+                               : skinny_lds_launch<EPI_, 4, NT_>(p, X, ldx, W, ldw, out, ldo, R, ldr, B, K, ws, tickets, tiled, s))
     switch (epi) {
         case EPI_NONE: return SL(EPI_NONE, 1);
         case EPI_RESIDUAL: return SL(EPI_RESIDUAL, 1);
@@ -863,7 +878,7 @@ int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_
 }
 
 int launch_swiglu_combine(const float* part, int KS, int N2, bf16_t* out, int ldo, int B, hipStream_t s) {
-    if (B < 1 || B > 32 || KS < 1 || N2 % 32 || ldo % 4) return TRACE_ERR_ARG;
+    if (B < 1 || B > SK_ROWS || KS < 1 || N2 % 32 || ldo % 4) return TRACE_ERR_ARG;
     const int total = B * (N2 / 8);
     hipLaunchKernelGGL(swiglu_combine_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, KS, N2, out, ldo, B);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
@@ -879,7 +894,7 @@ int launch_tile_pack(const bf16_t* src, int ldw, bf16_t* dst, int N, int K, hipS
 
 int launch_add_rmsnorm(const float* part, int KS, const bf16_t* R, int ldr, bf16_t* xout, int ldx, const bf16_t* w, bf16_t* y,
                        int ldy, int B, int N, float eps, hipStream_t s) {
-    if (B < 1 || B > 32 || KS < 1 || N % 4 || N > 4096 || (ldr % 4) || (ldx % 4) || (ldy % 4)) return TRACE_ERR_ARG;
+    if (B < 1 || B > SK_ROWS || KS < 1 || N % 4 || N > 4096 || (ldr % 4) || (ldx % 4) || (ldy % 4)) return TRACE_ERR_ARG;
     hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(B), dim3(256), 0, s, part, KS, R, ldr, xout, ldx, w, y, ldy, N, eps);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
@@ -898,19 +913,21 @@ int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vtcac
 
 int launch_head_logits(const bf16_t* X, int ldx, const bf16_t* Wh, int H, const int32_t* heads, int V, int Tv, int Sv,
                        float* part_val, int32_t* part_idx, float* logits_out, int B, hipStream_t s) {
-    if (B < 1 || B > 32 || H % 64) return TRACE_ERR_ARG;
-    const int ntiles = (V + 1 + Tv + Sv + 15) / 16;
-    hipLaunchKernelGGL(head_logits_kernel, dim3(ntiles), dim3(512), 0, s, X, ldx, Wh, H, heads, V, Tv, Sv, part_val, part_idx,
-                       logits_out, B, ntiles);
+    if (B < 1 || B > SK_ROWS || H % 64) return TRACE_ERR_ARG;
+    const int ntiles = (V + 1 + Tv + Sv + 15) / 16, NV = V + 1 + Tv + Sv;
+    for (int b0 = 0; b0 < B; b0 += 32)        // the kernel holds 32 rows; a larger batch takes a second pass over the active tiles
+        hipLaunchKernelGGL(head_logits_kernel, dim3(ntiles), dim3(512), 0, s, X + (size_t)b0 * ldx, ldx, Wh, H, heads + b0, V, Tv, Sv,
+                           part_val + (size_t)b0 * ntiles, part_idx + (size_t)b0 * ntiles,
+                           logits_out ? logits_out + (size_t)b0 * NV : nullptr, std::min(32, B - b0), ntiles);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 
 int launch_select_next(const float* part_val, const int32_t* part_idx, const StepState& st, const bf16_t* embed,
                        const bf16_t* time_tab, const bf16_t* score_tab, const bf16_t* sync_row, bf16_t* xnext, int ldx, int B,
                        int H, int V, int Tv, int Sv, int advance, hipStream_t s) {
-    if (B < 1 || B > 32 || H % 8) return TRACE_ERR_ARG;
+    if (B < 1 || B > SK_ROWS || H % 8) return TRACE_ERR_ARG;
     const int ntiles = (V + 1 + Tv + Sv + 15) / 16;
-    hipLaunchKernelGGL(select_next_kernel, dim3(1), dim3(256), 0, s, part_val, part_idx, st, embed, time_tab, score_tab,
+    hipLaunchKernelGGL(select_next_kernel, dim3(B), dim3(256), 0, s, part_val, part_idx, st, embed, time_tab, score_tab,
                        sync_row, xnext, ldx, B, H, V, Tv, Sv, ntiles, advance);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }

@@ -202,9 +202,9 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     A(c->pO, Lm * H); A(c->pACT, Lm * I);
     A(c->d_kind, Lm); A(c->d_row, Lm);
     // --- decode ---
-    A(c->dX, 32 * H); A(c->dH, 32 * H); A(c->dQKV, 32 * (size_t)c->QKV); A(c->dO, 32 * H); A(c->dACT, 32 * I);
+    A(c->dX, SK_ROWS * H); A(c->dH, SK_ROWS * H); A(c->dQKV, SK_ROWS * (size_t)c->QKV); A(c->dO, SK_ROWS * H); A(c->dACT, SK_ROWS * I);
     A(c->xlast, 64 * H);
-    A(c->attn_ws, (size_t)32 * c->NQ * c->nsplit * (c->HD + 2)); A(c->tickets, 32 * c->NKV);
+    A(c->attn_ws, (size_t)SK_ROWS * c->NQ * c->nsplit * (c->HD + 2)); A(c->tickets, SK_ROWS * c->NKV);
     {
         size_t f = skinny_ws_floats(c->QKV, H, EPI_NONE);
         f = std::max(f, skinny_ws_floats(c->QKV, H, EPI_PARTIAL));
@@ -217,9 +217,9 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
         A(c->sk_ws, c->sk_ws_floats); A(c->sk_tickets, c->sk_ntickets);
     }
     c->ntiles = c->NVpad / 16;
-    A(c->part_val, (size_t)32 * c->ntiles); A(c->part_idx, (size_t)32 * c->ntiles);
-    A(c->d_slots, 32); A(c->d_pos, 32); A(c->d_heads, 32); A(c->d_done, 32); A(c->d_out_len, 32); A(c->d_step, 4); A(c->d_params, 4);
-    A(c->d_out_ids, (size_t)32 * cfg->max_new_tokens); A(c->d_forced, (size_t)32 * cfg->max_new_tokens);
+    A(c->part_val, (size_t)SK_ROWS * c->ntiles); A(c->part_idx, (size_t)SK_ROWS * c->ntiles);
+    A(c->d_slots, SK_ROWS); A(c->d_pos, SK_ROWS); A(c->d_heads, SK_ROWS); A(c->d_done, SK_ROWS); A(c->d_out_len, SK_ROWS); A(c->d_step, 4); A(c->d_params, 4);
+    A(c->d_out_ids, (size_t)SK_ROWS * cfg->max_new_tokens); A(c->d_forced, (size_t)SK_ROWS * cfg->max_new_tokens);
 #undef A
     if (rc == TRACE_OK && hipHostMalloc((void**)&c->h_kind, Lm * 8) != hipSuccess) rc = fail(TRACE_ERR_HIP, "hipHostMalloc");
     if (rc != TRACE_OK) { trace_ctx_destroy(c); return rc; }
@@ -756,10 +756,10 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
 extern "C" int trace_decode_begin(trace_ctx* c, const int32_t* slots, int B, const int32_t* heads, int max_new, int eos,
                                   const int32_t* forced, float* logits_out, void* stream) {
     if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
-    if (!slots || !heads || B < 1 || B > c->max_B || B > 32) return fail(TRACE_ERR_ARG, "bad batch (at most 32 sequences decode together)");
+    if (!slots || !heads || B < 1 || B > c->max_B || B > SK_ROWS) return fail(TRACE_ERR_ARG, "bad batch (at most 64 sequences decode together)");
     if (max_new < 1 || max_new > c->c.max_new_tokens) return fail(TRACE_ERR_ARG, "max_new exceeds capacity");
     hipStream_t s = (hipStream_t)stream;
-    int32_t pos[32], zero[32] = {0};
+    int32_t pos[SK_ROWS], zero[SK_ROWS] = {0};
     for (int b = 0; b < B; ++b) {
         if (slots[b] < 0 || slots[b] >= c->max_B || c->slot_len[slots[b]] <= 0) return fail(TRACE_ERR_STATE, "slot not prefilled");
         if (heads[b] < 0 || heads[b] > 2) return fail(TRACE_ERR_ARG, "head must be 0, 1 or 2");
@@ -922,7 +922,7 @@ extern "C" int trace_op_attention(const void* Q, const void* K, const void* V, v
     return TRACE_OK;
 }
 // Decode GEMV test hooks.  w_tiled: W is in the decode tile layout (trace_op_tile_pack) instead of row-major [N][K].
-// epilogue 4 (EPI_PARTIAL): `out` receives the fp32 partial rows [trace_op_skinny_ks(...)][32][N] instead of bf16.
+// epilogue 4 (EPI_PARTIAL): `out` receives the fp32 partial rows [trace_op_skinny_ks(...)][64][N] instead of bf16.
 static float* g_sk_ws = nullptr;
 static unsigned int* g_sk_tk = nullptr;
 static size_t g_sk_ws_floats = 0;
@@ -943,7 +943,7 @@ extern "C" int trace_op_skinny_gemm(const void* X, const void* W, void* out, con
     LCHK(launch_skinny_gemm((const bf16_t*)X, K, (const bf16_t*)W, K, (bf16_t*)out, No, (const bf16_t*)R, No, B, N, K, epilogue,
                             w_tiled, g_sk_ws, g_sk_ws_floats, g_sk_tk, g_sk_ntk, (hipStream_t)stream));
     if (epilogue == EPI_PARTIAL && out)
-        HIPCHK(hipMemcpyAsync(out, g_sk_ws, (size_t)skinny_ks(N, K, epilogue, B) * 32 * N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        HIPCHK(hipMemcpyAsync(out, g_sk_ws, (size_t)skinny_ks(N, K, epilogue, B) * SK_ROWS * N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return TRACE_OK;
 }
 extern "C" int trace_op_skinny_ks(int N, int K, int epilogue, int B) { return skinny_ks(N, K, epilogue, B); }
@@ -968,12 +968,12 @@ extern "C" int trace_op_attn_decode(const void* q, const void* kcache, const voi
     static int32_t* d_slots = nullptr;
     static unsigned int* d_tickets = nullptr;
     if (!d_slots) {
-        int32_t h[32];
-        for (int i = 0; i < 32; ++i) h[i] = i;
-        HIPCHK(hipMalloc((void**)&d_slots, 128));
-        HIPCHK(hipMemcpy(d_slots, h, 128, hipMemcpyHostToDevice));
-        HIPCHK(hipMalloc((void**)&d_tickets, 32 * 64 * 4));
-        HIPCHK(hipMemset(d_tickets, 0, 32 * 64 * 4));
+        int32_t h[SK_ROWS];
+        for (int i = 0; i < SK_ROWS; ++i) h[i] = i;
+        HIPCHK(hipMalloc((void**)&d_slots, SK_ROWS * 4));
+        HIPCHK(hipMemcpy(d_slots, h, SK_ROWS * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&d_tickets, SK_ROWS * 64 * 4));
+        HIPCHK(hipMemset(d_tickets, 0, SK_ROWS * 64 * 4));
     }
     LCHK(launch_attn_decode((const bf16_t*)q, nq * 128, (bf16_t*)kcache, (bf16_t*)vcache, (long)nkv * max_ctx * 128,
                             (long)max_ctx * 128, max_ctx, d_slots, pos, (bf16_t*)O, nq * 128, ws, d_tickets, B, nq, nkv, 128, nsplit, scale, 0,

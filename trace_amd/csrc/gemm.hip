@@ -30,6 +30,9 @@ __device__ __forceinline__ int swz(int row, int kc) { return row * 128 + ((kc ^ 
 // epilogue barriers cost more than the hidden prologue); (3) de-phasing the first wave of workgroups (groups of CUs
 // sleeping 3-10 us before their first tile so that the tiles' HBM write bursts do not coincide) moved the ViT shapes by
 // -4..+1 % — the epilogues are not synchronised enough for write bandwidth to be what the fixed cost pays for.
+// (4) two co-resident workgroups per CU (256x128 tiles, 4 waves, 32-wide K-tiles in 64-byte swizzled rows, 70 KB of LDS
+// each) so that one tile's prologue/epilogue overlaps the other's main loop: correct, but 730 vs 761 (qkv), 788 vs 808
+// (fc1), 832 vs 986 (fc2) TFLOP/s — the halved work per barrier costs what the overlap buys.
 // Per-tile fixed cost is ~13 us vs ~1.6 us per K-tile.
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include "common.h"
 
+constexpr int SK_ROWS = 64;   // row stride of the decode GEMV's fp32 partial buffers [ks][SK_ROWS][N] = max decode batch
 enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_QUICKGELU = 2, EPI_SWIGLU = 3, EPI_PARTIAL = 4 };   // PARTIAL: decode GEMV only
 
 struct GemmArgs {
@@ -72,17 +73,17 @@ int launch_rope_kv(bf16_t* qkv, int ld, bf16_t* kcache, bf16_t* vcache, long slo
                    const float* cos_t, const float* sin_t, hipStream_t s);
 
 // ---- decode (decode.hip) ----
-// out[b, n] = sum_k X[b,k] W[n,k]  (B <= 32) (+ residual / SwiGLU on interleaved W)
+// out[b, n] = sum_k X[b,k] W[n,k]  (B <= 64) (+ residual / SwiGLU on interleaved W)
 // tiled: W is the decode copy made by launch_tile_pack ([N/16][K/64][64][16]); else row-major [N][ldw].
 // ws / tickets: workspace of skinny_ws_floats(N, K, epi) floats and >= N/16 zero-initialised tickets.
-// EPI_PARTIAL: no bf16 output; fp32 partial rows [skinny_ks(N, K, epi, B)][32][N] in ws, summed by launch_add_rmsnorm.
+// EPI_PARTIAL: no bf16 output; fp32 partial rows [skinny_ks(N, K, epi, B)][SK_ROWS][N] in ws, summed by launch_add_rmsnorm.
 int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R,
                        int ldr, int B, int N, int K, int epi, int tiled, float* ws, size_t ws_floats, unsigned int* tickets,
                        int ntickets, hipStream_t s);
 size_t skinny_ws_floats(int N, int K, int epi);
 int skinny_ks(int N, int K, int epi, int B);
 int launch_tile_pack(const bf16_t* src, int ldw, bf16_t* dst, int N, int K, hipStream_t s);
-// out[b][j] = bf16(silu(sum_ks gate) * sum_ks up) over EPI_PARTIAL rows [KS][32][N2] of the 16-row interleaved gate|up product
+// out[b][j] = bf16(silu(sum_ks gate) * sum_ks up) over EPI_PARTIAL rows [KS][SK_ROWS][N2] of the 16-row interleaved gate|up product
 int launch_swiglu_combine(const float* part, int KS, int N2, bf16_t* out, int ldo, int B, hipStream_t s);
 // x = bf16(sum_ks part[ks][b]) + R[b] -> xout (may alias R); y = RMSNorm(x) * w.  N <= 4096.
 int launch_add_rmsnorm(const float* part, int KS, const bf16_t* R, int ldr, bf16_t* xout, int ldx, const bf16_t* w, bf16_t* y,
@@ -94,7 +95,7 @@ int launch_add_rmsnorm(const float* part, int KS, const bf16_t* R, int ldr, bf16
 int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vtcache, long slot_stride, long kv_head_stride,
                        int ctx_stride, const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,
                        int nq, int nkv, int hd, int nsplit, float scale, int fuse_rope, const float* cos_t, const float* sin_t,
-                       const float* qpart, int qks, hipStream_t s);   // qpart: fp32 partial rows [qks][32][ldq] instead of bf16 qkv
+                       const float* qpart, int qks, hipStream_t s);   // qpart: fp32 partial rows [qks][SK_ROWS][ldq] instead of bf16 qkv
 // heads: logits over [text V+1 | time Tv | score Sv] rows of Wh [NV_pad, H]; only tiles intersecting an active
 // head's range are computed.  part: [B, ntiles] (max,idx).  logits_out optional [B, NV] fp32 (masked -inf).
 int launch_head_logits(const bf16_t* X, int ldx, const bf16_t* Wh, int H, const int32_t* heads, int V, int Tv, int Sv,

@@ -287,13 +287,13 @@ class ops:
 
     @staticmethod
     def skinny_gemm(X, W, R=None, epilogue=EPI_NONE, tiled=False, want_partial=True):
-        """decode GEMV; `tiled`: W was passed through tile_pack.  EPI_PARTIAL returns the fp32 partial rows [KS, 32, N]."""
+        """decode GEMV; `tiled`: W was passed through tile_pack.  EPI_PARTIAL returns the fp32 partial rows [KS, 64, N]."""
         lib = _lib.load()
         Bn, K = X.shape
         N = W.shape[0]
         if epilogue == EPI_PARTIAL:
             ks = lib.trace_op_skinny_ks(N, K, epilogue, Bn)
-            out = torch.zeros((ks, 32, N), dtype=torch.float32, device=X.device) if want_partial else None
+            out = torch.zeros((ks, 64, N), dtype=torch.float32, device=X.device) if want_partial else None
         else:
             No = N // 2 if epilogue == EPI_SWIGLU else N
             out = torch.empty((Bn, No), dtype=torch.bfloat16, device=X.device)

@@ -111,6 +111,8 @@ int trace_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int l
                   int ldr, int M, int N, int K, int epilogue, void* stream);
 /* GEMM tile selection for tests/microbenchmarks: 0 auto, 2 = 128^2 tiles, 3 = 256^2 tiles. */
 int trace_op_set_gemm_variant(int variant);
+/* profiling: device buffer of 8 x uint64 per workgroup receiving phase time stamps of every later GEMM launch (NULL = off) */
+int trace_op_set_gemm_trace(void* buf);
 int trace_op_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, float eps, void* stream);
 int trace_op_rmsnorm(const void* x, void* y, const void* w, int rows, int D, float eps, void* stream);
 int trace_op_attention(const void* Q, const void* K, const void* V, void* O, void* vt_scratch, int batch, int heads,

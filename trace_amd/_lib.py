@@ -54,6 +54,7 @@ SIGNATURES = {
     "trace_op_rmsnorm": (I, [P, P, P, I, I, F, P]),
     "trace_op_attention": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "trace_op_skinny_gemm": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "trace_op_set_gemm_trace": (I, [P]),
     "trace_op_skinny_ks": (I, [I, I, I, I]),
     "trace_op_tile_pack": (I, [P, P, I, I, P]),
     "trace_op_swiglu_combine": (I, [P, I, I, P, I, P]),

@@ -450,9 +450,11 @@ extern "C" int trace_ctx_finalize(trace_ctx* c) {
 }
 
 // ------------------------------------------------------------------------------------------------ ViT
+static unsigned long long* g_gemm_trace = nullptr;      // tools/gemm_trace.py
+extern "C" int trace_op_set_gemm_trace(void* buf) { g_gemm_trace = (unsigned long long*)buf; return TRACE_OK; }
 static int gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* C, int ldc, const bf16_t* bias, const bf16_t* R,
                 int ldr, int M, int N, int K, int epi, hipStream_t s) {
-    GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K};
+    GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, g_gemm_trace};
     const int rc = launch_gemm_bf16(g, epi, s);
     if (rc != TRACE_OK) return fail(rc, "gemm launch failed (M=" + std::to_string(M) + " N=" + std::to_string(N) + " K=" + std::to_string(K) + ")");
     return TRACE_OK;

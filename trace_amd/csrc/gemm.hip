@@ -59,6 +59,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
         tn = in_g / gsz;
     }
     const int m0 = tm * BM, n0 = tn * BN;
+    // phase stamps (100 MHz s_memrealtime) of wave 0, only when a trace buffer is passed
+    unsigned long long* tr = p.trace ? p.trace + (size_t)blockIdx.x * 8 : nullptr;
+    if (tr && threadIdx.x == 0) { tr[0] = __builtin_amdgcn_s_memrealtime(); tr[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); tr[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); }
 
     const bf16_t* asrc[A_IT];
     const bf16_t* wsrc[W_IT];
@@ -125,6 +128,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     issue_a(0); issue_w(0);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                                   // tile kt landed (vmcnt(0) + barrier); everyone is done with tile kt-1
+        if (tr && kt == 0 && threadIdx.x == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
         if (!SPREAD && kt + 1 < nk) { issue_a(kt + 1); issue_w(kt + 1); }
         const bool more = SPREAD && kt + 1 < nk;
         const char* sa = a_stage(kt & 1);
@@ -162,7 +166,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
             }
         }
     }
+    // the lane's 4 bias values per column tile, fetched ONCE (8 bytes per tile) before the barrier: inside the loops
+    // below the compiler cannot hoist them past the LDS stores, and 128 dependent 2-byte loads per lane were most of a
+    // 10 us epilogue (tools/gemm_trace.py)
+    float bv[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        uint2 b2 = make_uint2(0u, 0u);
+        if (!GLU && p.bias) b2 = *reinterpret_cast<const uint2*>(p.bias + n0 + wn * (BN / WN) + j * 16 + g * 4);
+        bv[j][0] = bflo(b2.x); bv[j][1] = bfhi(b2.x); bv[j][2] = bflo(b2.y); bv[j][3] = bfhi(b2.y);
+    }
     __syncthreads();
+    if (tr && threadIdx.x == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
     // ---- epilogue: fp32 bias/activation -> bf16 -> LDS rows -> 16-byte stores ----
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -174,8 +189,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float x = acc[i][j][q];
-                    if (p.bias) x += bf2f(p.bias[n0 + nl + q]);
+                    float x = acc[i][j][q] + bv[j][q];
                     if (EPI == EPI_QUICKGELU) x = x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x));   // x*sigmoid(1.702x)
                     v[q] = x;
                 }
@@ -196,16 +210,32 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
         }
     }
     __syncthreads();
+    if (tr && threadIdx.x == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
     constexpr int OUTW = GLU ? BN / 2 : BN;
     constexpr int CPR = OUTW / 8;
     const int on0 = GLU ? n0 / 2 : n0;
-    for (int c = tid; c < BM * CPR; c += NTHR) {
+    constexpr int OIT = BM * CPR / NTHR;
+    static_assert(BM * CPR % NTHR == 0, "output pieces must divide over the workgroup");
+    // residual pieces first, all in flight together (the accumulators are dead: registers are free) — one dependent HBM
+    // round trip per piece made this loop 12 us on the residual GEMMs
+    uint4 rres[EPI == EPI_RESIDUAL ? OIT : 1];
+    if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+        for (int it = 0; it < OIT; ++it) {
+            const int c = it * NTHR + tid, row = c / CPR, ch = c - row * CPR;
+            const int m = min(m0 + row, p.M - 1);
+            rres[it] = *reinterpret_cast<const uint4*>(p.R + (size_t)m * p.ldr + on0 + ch * 8);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < OIT; ++it) {
+        const int c = it * NTHR + tid;
         const int row = c / CPR, ch = c - row * CPR;
         const int m = m0 + row;
         if (m >= p.M) continue;
         uint4 v = *reinterpret_cast<const uint4*>(smem + row * OSTRIDE + ch * 16);
         if (EPI == EPI_RESIDUAL) {
-            const uint4 rr = *reinterpret_cast<const uint4*>(p.R + (size_t)m * p.ldr + on0 + ch * 8);
+            const uint4 rr = rres[it];
             v.x = pack2bf(bflo(v.x) + bflo(rr.x), bfhi(v.x) + bfhi(rr.x));
             v.y = pack2bf(bflo(v.y) + bflo(rr.y), bfhi(v.y) + bfhi(rr.y));
             v.z = pack2bf(bflo(v.z) + bflo(rr.z), bfhi(v.z) + bfhi(rr.z));
@@ -215,6 +245,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
         __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(p.C + (size_t)m * p.ldc + on0 + ch * 8));
     }
+    if (tr && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tr[4] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 

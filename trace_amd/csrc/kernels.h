@@ -15,6 +15,7 @@ struct GemmArgs {
     const bf16_t* bias;             // [N] or null
     const bf16_t* R; int ldr;       // residual [M,N] for EPI_RESIDUAL (may alias C)
     int M, N, K;
+    unsigned long long* trace;      // profiling only (tools/gemm_trace.py): 8 x u64 per workgroup, or null
 };
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s);
 

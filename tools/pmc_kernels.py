@@ -1,4 +1,4 @@
-"""Small fixed workload for rocprofv3 --pmc passes: ViT attention, ViT fc1 GEMM, decode gate|up GEMV (batch 32)."""
+"""Small fixed workload for rocprofv3 --pmc passes: ViT attention, ViT fc1 GEMM, decode gate|up GEMV (batch 64)."""
 import math, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trace_amd import engine as E
@@ -14,9 +14,9 @@ if what in ("all", "gemm"):
     A, W, b = rnd(73856, 1024), rnd(4096, 1024, scale=0.02), rnd(4096)
     for _ in range(3):
         ops.gemm(A, W, bias=b, epilogue=E.EPI_QUICKGELU)
-if what in ("all", "gemv"):      # the decode step's dominant kernel: gate|up GEMV, batch 32, tile-layout weights, fp32 partial rows
+if what in ("all", "gemv"):      # the decode step's dominant kernel: gate|up GEMV, batch 64 (the bench default), tile-layout weights, fp32 partial rows
     Ws = [ops.tile_pack(rnd(28672, 4096, scale=0.02)) for _ in range(3)]
-    X = rnd(32, 4096)
+    X = rnd(64, 4096)
     for i in range(6):
         ops.skinny_gemm(X, Ws[i % 3], epilogue=E.EPI_PARTIAL, tiled=True, want_partial=False)
 torch.cuda.synchronize()

@@ -24,9 +24,9 @@ total = fetch_kb * 1024 * 2 + write_kb * 1024
 json.dump({
     "skinny_gateup_bytes_per_launch": total,
     "detail": {
-        "kernel": "skinny_lds_kernel<EPI_PARTIAL, NB=2, NT=2> (decode gate|up GEMV), B=32, 6 launches over 3 rotating weight copies",
+        "kernel": "skinny_lds_kernel<EPI_PARTIAL, NB=4, NT=2> (decode gate|up GEMV), B=64, 6 launches over 3 rotating weight copies",
         "FETCH_SIZE_KB_mean": fetch_kb, "WRITE_SIZE_KB_mean": write_kb, "launches": [n1, n2],
-        "correction": "FETCH_SIZE x 1024 x 2 (gfx950 half-count of 16 B/lane streaming reads) + WRITE_SIZE x 1024 (uncalibrated; the fp32 partial rows, 2 x 32 x 28672 x 4 B = 7.3 MB)",
+        "correction": "FETCH_SIZE x 1024 x 2 (gfx950 half-count of 16 B/lane streaming reads) + WRITE_SIZE x 1024 (uncalibrated; matches the fp32 partial rows exactly: 4 chunks x 64 x 28672 x 4 B = 29.4 MB)",
         "algorithmic_bytes": alg, "ratio_traffic_over_algorithmic": total / alg,
         "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python tools/pmc_kernels.py gemv",
                      "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python tools/pmc_kernels.py gemv"],

@@ -33,7 +33,15 @@ __device__ __forceinline__ int swz(int row, int kc) { return row * 128 + ((kc ^ 
 // (4) two co-resident workgroups per CU (256x128 tiles, 4 waves, 32-wide K-tiles in 64-byte swizzled rows, 70 KB of LDS
 // each) so that one tile's prologue/epilogue overlaps the other's main loop: correct, but 730 vs 761 (qkv), 788 vs 808
 // (fc1), 832 vs 986 (fc2) TFLOP/s — the halved work per barrier costs what the overlap buys.
-// Per-tile fixed cost is ~13 us vs ~1.6 us per K-tile.
+// (5) an 8-wave ping-pong main loop (waves w / w+4 of a SIMD alternating a fragment-read + LDS-DMA phase with a 32-MFMA
+// phase across raw s_barriers, set B one phase behind): bit-correct, same speed (885 vs 876, 897 vs 931 TFLOP/s).
+// Knock-out runs on that loop (fc1, 690 us) explain why: MFMAs alone 250 us (= the 2.5 PFLOP/s rate), LDS-DMA alone
+// 243 us (the CU's address path retires one 1 KB piece per ~31 cycles = 32 B/clk, so 64 KB per K-tile costs as much as
+// its 64 MFMAs per wave), fragment reads alone 83 us, everything outside the K loop 205-232 us — and MFMA + DMA run
+// almost additively (458 us together), in either loop structure, also with the DMA confined to the read phases.  A
+// 256x256 tile cannot lower DMA bytes per flop (the accumulators already fill half the register file), so the next
+// step is hiding the per-tile 8 us (epilogue 4 + stores 2 + prologue 1.6) rather than re-shaping the K loop.
+// Per-tile cost after the epilogue fixes (tools/gemm_trace.py): ~8 us fixed + ~1.7 us per K-tile.
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     constexpr int NW = WM * WN, NTHR = NW * 64;
@@ -166,6 +174,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
             }
         }
     }
+    constexpr int OUTW = GLU ? BN / 2 : BN;
+    constexpr int CPR = OUTW / 8;
+    const int on0 = GLU ? n0 / 2 : n0;
+    constexpr int OIT = BM * CPR / NTHR;
+    static_assert(BM * CPR % NTHR == 0, "output pieces must divide over the workgroup");
+    // residual pieces requested up front, all in flight under the epilogue math — one dependent HBM round trip per piece
+    // in the store loop made it 12 us on the residual GEMMs (now 2.9)
+    uint4 rres[EPI == EPI_RESIDUAL ? OIT : 1];
+    if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+        for (int it = 0; it < OIT; ++it) {
+            const int c = it * NTHR + tid, row = c / CPR, ch = c - row * CPR;
+            const int m = min(m0 + row, p.M - 1);
+            rres[it] = *reinterpret_cast<const uint4*>(p.R + (size_t)m * p.ldr + on0 + ch * 8);
+        }
+    }
     // the lane's 4 bias values per column tile, fetched ONCE (8 bytes per tile) before the barrier: inside the loops
     // below the compiler cannot hoist them past the LDS stores, and 128 dependent 2-byte loads per lane were most of a
     // 10 us epilogue (tools/gemm_trace.py)
@@ -211,22 +235,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     }
     __syncthreads();
     if (tr && threadIdx.x == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
-    constexpr int OUTW = GLU ? BN / 2 : BN;
-    constexpr int CPR = OUTW / 8;
-    const int on0 = GLU ? n0 / 2 : n0;
-    constexpr int OIT = BM * CPR / NTHR;
-    static_assert(BM * CPR % NTHR == 0, "output pieces must divide over the workgroup");
-    // residual pieces first, all in flight together (the accumulators are dead: registers are free) — one dependent HBM
-    // round trip per piece made this loop 12 us on the residual GEMMs
-    uint4 rres[EPI == EPI_RESIDUAL ? OIT : 1];
-    if (EPI == EPI_RESIDUAL) {
-#pragma unroll
-        for (int it = 0; it < OIT; ++it) {
-            const int c = it * NTHR + tid, row = c / CPR, ch = c - row * CPR;
-            const int m = min(m0 + row, p.M - 1);
-            rres[it] = *reinterpret_cast<const uint4*>(p.R + (size_t)m * p.ldr + on0 + ch * 8);
-        }
-    }
 #pragma unroll
     for (int it = 0; it < OIT; ++it) {
         const int c = it * NTHR + tid;

@@ -92,7 +92,7 @@ def test_gemm_residual_in_place():
     check("residual in place", Rc, ref, 3e-2, 1e-2)
 
 
-@pytest.mark.parametrize("rows,D", [(5, 128), (577, 1024), (33, 4096)])
+@pytest.mark.parametrize("rows,D", [(5, 128), (577, 1024), (33, 4096), (4618, 1024)])
 def test_norms(rows, D):
     x, w, b = rnd(rows, D, scale=2.0), 1 + rnd(D, scale=0.1), rnd(D, scale=0.1)
     ref = torch.nn.functional.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5)

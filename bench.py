@@ -31,34 +31,35 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s 
 
 def cpu_baseline(cfg, n_new: int, threads: int) -> dict:
     """Oracle (CPU restatement of the reference path, validated against the reference fixtures) timed on a bounded
-    sample of the same workload and extrapolated linearly: ViT on 1 of the 128 frames (all 23 layers), slot pool on
-    that frame, 1 of the 32 decoder layers at the full prefill length, and 4 single-token decode steps on that layer."""
+    sample of the same workload and extrapolated linearly: ViT on 4 of the 128 frames (all 23 layers), slot pool on
+    those frames, 2 of the 32 decoder layers at the full prefill length, and 8 single-token decode steps on those layers."""
     import dataclasses
     from oracle import trace_oracle as O
     torch.set_num_threads(threads)
-    c1 = dataclasses.replace(cfg, num_hidden_layers=1, vocab_size=64, num_frames=1)
+    SF, SL, SD = 4, 2, 8                      # sample: frames, decoder layers, decode steps
+    c1 = dataclasses.replace(cfg, num_hidden_layers=SL, vocab_size=64, num_frames=SF)
     sd = {}
     for name, shape, kind in synth.weight_specs(c1):
         sd[name] = synth.synth_tensor(name, shape, kind, torch.float32)
     ora = O.Oracle(c1, sd, emulate_bf16=False)
     T_full, L_full = cfg.num_frames, cfg.num_frames * cfg.tokens_per_frame + 176
-    frames = synth.synth_frames(c1, 0, num_frames=1)
+    frames = synth.synth_frames(c1, 0, num_frames=SF)
     with torch.no_grad():
         t0 = time.perf_counter(); feats = ora.vit_forward(frames); t_vit = time.perf_counter() - t0
         t0 = time.perf_counter(); ora.slot_pool(feats); t_slot = time.perf_counter() - t0
         emb = torch.randn(L_full, cfg.hidden_size) * 0.02
         t0 = time.perf_counter(); _, kv = ora.llm_forward(emb); t_pre = time.perf_counter() - t0
         t0 = time.perf_counter()
-        for _ in range(4):
+        for _ in range(SD):
             _, kv = ora.llm_forward(torch.randn(1, cfg.hidden_size) * 0.02, kv)
-        t_dec = (time.perf_counter() - t0) / 4
+        t_dec = (time.perf_counter() - t0) / SD
     NLf = cfg.num_hidden_layers
-    per_video = (t_vit + t_slot) * T_full + t_pre * NLf + t_dec * NLf * (n_new - 1)
+    per_video = (t_vit + t_slot) * T_full / SF + t_pre * NLf / SL + t_dec * NLf / SL * (n_new - 1)
     return {"value": 1.0 / per_video, "unit": "videos/s", "cores": threads, "kind": "port",
-            "sample": (f"oracle fp32: ViT+slot-pool on 1/{T_full} frames ({t_vit + t_slot:.2f}s), 1/{NLf} decoder layers at L={L_full} "
-                       f"({t_pre:.2f}s), 4 decode steps on that layer ({t_dec * 1e3:.1f} ms each); extrapolated linearly "
+            "sample": (f"oracle fp32: ViT+slot-pool on {SF}/{T_full} frames ({t_vit + t_slot:.2f}s), {SL}/{NLf} decoder layers at L={L_full} "
+                       f"({t_pre:.2f}s), {SD} decode steps on those layers ({t_dec * 1e3:.1f} ms each); extrapolated linearly "
                        f"(heads/embedding excluded) -> {per_video:.0f} s/video"),
-            "decode_tok_s": 1.0 / (t_dec * NLf)}
+            "decode_tok_s": 1.0 / (t_dec * NLf / SL)}
 
 
 def dvc_schedule(cfg, n_new, seed):

@@ -206,3 +206,42 @@ def test_big_batch_equals_single(setup, nb):
     for i in range(nb):
         assert out[i] == (a[0] if i % 2 == 0 else b[0]), i
     big.close()
+
+
+def test_ragged_batch_and_context_limits(setup):
+    """Ragged batch: videos with different frame counts (2 vs 4 -> 28 vs 56 visual rows) and different prompt lengths decode
+    together exactly as they do alone, and match the bf16-emulating oracle on the 13-way heads.  Context edge: a prompt
+    whose prefill + max_new lands exactly on max_ctx is accepted; one token more is rejected with a Python exception."""
+    cfg, eng, ora, E, frames = setup
+    from trace_amd._lib import TraceHipError
+    ids_a = E["input_ids"].tolist()
+    ids_b = synth.synth_prompt_ids(cfg, n_text=37, video_pos=5, seed=11).tolist()
+    fa, fb = frames, synth.synth_frames(cfg, 3).to(torch.bfloat16)[:2]
+    ts_a, ts_b = E["timestamps"].tolist(), [[0.5], [7.25]]
+    n = 12
+    a, _ = eng.generate([fa], [ts_a], [ids_a], [1], n)
+    b, _ = eng.generate([fb], [ts_b], [ids_b], [1], n)
+    ab, heads = eng.generate([fa, fb], [ts_a, ts_b], [ids_a, ids_b], [1, 1], n)
+    assert ab[0] == a[0] and ab[1] == b[0]
+    o_ids, o_lg = ora.generate(torch.tensor(ids_b), fb.float(), ts_b, head=1, max_new_tokens=n, return_logits=True)
+    srt = torch.sort(torch.where(torch.isfinite(o_lg), o_lg, torch.full_like(o_lg, -1e30)), dim=-1, descending=True).values
+    for i, (x, y) in enumerate(zip(b[0], o_ids)):
+        if (srt[i, 0] - srt[i, 1]) <= 0.05:
+            break                                   # a near-tie: the two greedy streams may legitimately part here
+        assert x == y, f"ragged video, step {i}: {x} != oracle {y}"
+    assert i >= 3
+    # context limit on an engine whose cache is exactly prompt + 8 tokens long
+    L = int(E["prefill_len"])
+    small = TraceEngine(cfg, max_batch=1, max_ctx=L + 8, max_frames=4, max_new_tokens=16)
+    small.load_weights(synth.state_dict(cfg).items())
+    small.encode_video(fa, ts_a)
+    assert small.splice(ids_a) == L
+    small.prefill(0, L)
+    small.decode_begin([0], [1], 8, eos=-1)                        # exactly fills the cache
+    small.decode_steps(7, use_graph=False)
+    out, _ = small.decode_read()
+    assert out[0] == a[0][:8]
+    small.prefill(0, L)
+    with pytest.raises(TraceHipError, match="exceeds max_ctx"):
+        small.decode_begin([0], [1], 9, eos=-1)
+    small.close()

@@ -51,6 +51,15 @@ int trace_ctx_load_tensor(trace_ctx* ctx, const char* name, const void* data, in
 int trace_ctx_finalize(trace_ctx* ctx);
 int64_t trace_ctx_device_bytes(trace_ctx* ctx);
 
+/* Frame preprocessing of process_video (trace/mm_utils.py:456-462; expand2square :259-270; HF CLIPImageProcessor.preprocess of
+ * transformers 4.40.1: resize shortest edge -> v_image with Pillow BICUBIC, centre crop, x/255, (x - mean)/std), on the device:
+ * frames_u8 [T,H,W,3] uint8 RGB (device) -> out [T,3,v_image,v_image] (out_dtype 0 = bf16, 1 = fp32; device).
+ * pad_to_square = the drivers' aspect_ratio == 'pad' (background int(mean*255)).  image_mean / image_std: 3 host floats.
+ * The resize reproduces Pillow's 8-bit two-pass fixed-point resampler bit for bit; fp32 output equals the reference's
+ * FloatTensor exactly. */
+int trace_preprocess_frames(trace_ctx* ctx, const void* frames_u8, int T, int H, int W, int pad_to_square,
+                            const float* image_mean, const float* image_std, void* out, int out_dtype, void* stream);
+
 /* CLIPVisionTower.forward + feature_select (trace/model/multimodal_encoder/clip_encoder.py:31-53):
  * frames [T,3,S,S] (dtype 0 = bf16, 1 = fp32, device) -> features [T, patches, v_hidden] bf16 = hidden state
  * after encoder layer v_layers_used, CLS dropped.  feats_out may be NULL (kept internally for trace_slot_pool). */

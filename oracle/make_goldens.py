@@ -293,9 +293,39 @@ def int_goldens():
     print("host_functions.json written:", list(G.keys()))
 
 
+def preprocess_goldens():
+    """Frame preprocessing of process_video (mm_utils.py:456-462): the reference's own expand2square + the HF
+    CLIPImageProcessor it delegates to (PIL backend), on small synthetic frames, 'pad' and plain modes.  The processor is
+    built at 56 px so the fixture stays small; the arithmetic (Pillow 8-bit bicubic resample, centre crop, x/255,
+    (x-mean)/std) does not depend on the size."""
+    import numpy as np
+    from PIL import Image
+    from transformers import CLIPImageProcessor
+    from Trace.trace import mm_utils as ref_mm
+    proc = CLIPImageProcessor(size={"shortest_edge": 56}, crop_size={"height": 56, "width": 56})
+    rng = np.random.RandomState(5)
+    G = {"image_mean": np.array(proc.image_mean, dtype=np.float32), "image_std": np.array(proc.image_std, dtype=np.float32)}
+    for tag, (T, H, W) in {"land": (3, 90, 160), "port": (2, 150, 70), "square": (2, 64, 64), "up": (2, 20, 33)}.items():
+        frames = rng.randint(0, 256, size=(T, H, W, 3), dtype=np.uint8)
+        # smooth half of them so the resampler sees structure, not only noise
+        frames[0] = (np.add.outer(np.arange(H) * 255 // max(H - 1, 1), np.arange(W) * 255 // max(W - 1, 1)) // 2)[..., None].astype(np.uint8)
+        G[f"{tag}_frames"] = frames
+        images = [Image.fromarray(f) for f in frames]
+        padded = [ref_mm.expand2square(im, tuple(int(x * 255) for x in proc.image_mean)) for im in images]
+        G[f"{tag}_pad"] = proc.preprocess(padded, return_tensors="pt")["pixel_values"].numpy().astype(np.float32)
+        G[f"{tag}_plain"] = proc.preprocess(images, return_tensors="pt")["pixel_values"].numpy().astype(np.float32)
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "preprocess.npz")
+    np.savez_compressed(out, **G)
+    print("wrote", out, {k: v.shape for k, v in G.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     tmp = install_shim()
+    if "--preprocess-only" in sys.argv:
+        preprocess_goldens()
+        sys.exit(0)
     int_goldens()
     fp_goldens(tmp)
+    preprocess_goldens()

@@ -124,6 +124,114 @@ def parse_output_ids(cfg, ids: Sequence[int]) -> Dict[str, list]:
 # ----------------------------------------------------------------------------------------------
 # floating-point pieces
 # ----------------------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------
+# frame preprocessing (process_video's image branch, trace/mm_utils.py:259-270,456-462 -> HF CLIPImageProcessor.preprocess,
+# transformers==4.40.1 image_processing_clip.py: resize(shortest_edge, BICUBIC) -> center_crop -> rescale(1/255) -> normalize;
+# the resize itself is Pillow's ImagingResample (src/libImaging/Resample.c, 8-bit path), restated here integer for integer)
+# ----------------------------------------------------------------------------------------------
+def _bicubic(x: float) -> float:
+    a = -0.5                                   # Resample.c bicubic_filter
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pillow_coeffs(in_size: int, out_size: int):
+    """Resample.c precompute_coeffs + normalize_coeffs_8bpc: per output index (first source index, tap count) and the taps as
+    22-bit fixed point."""
+    import numpy as np
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        for x in range(xmax):
+            k = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + k * (1 << 22)) if k < 0 else int(0.5 + k * (1 << 22))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def pillow_resize(img, out_w: int, out_h: int):
+    """uint8 [H,W,C] -> uint8 [out_h,out_w,C], Pillow Image.resize(BICUBIC): horizontal pass over the source rows the
+    vertical pass needs, uint8 in between, both in 22-bit fixed point with round-half-up and clamp (Resample.c
+    ImagingResampleHorizontal_8bpc / Vertical_8bpc)."""
+    import numpy as np
+    H, W, _ = img.shape
+
+    def run(src, bounds, kk):                  # resample axis 1
+        s64 = src.astype(np.int64)
+        out = np.empty((src.shape[0], bounds.shape[0], src.shape[2]), dtype=np.uint8)
+        for xx in range(bounds.shape[0]):
+            x0, n = int(bounds[xx, 0]), int(bounds[xx, 1])
+            acc = (1 << 21) + (s64[:, x0:x0 + n, :] * kk[xx, :n].astype(np.int64)[None, :, None]).sum(1)
+            out[:, xx, :] = np.clip(acc >> 22, 0, 255).astype(np.uint8)
+        return out
+
+    cur = img
+    bv, kv = pillow_coeffs(H, out_h)
+    if out_w != W:
+        bh, kh = pillow_coeffs(W, out_w)
+        if out_h != H:
+            first, last = int(bv[0, 0]), int(bv[-1, 0] + bv[-1, 1])
+            cur = cur[first:last]
+            bv = bv.copy()
+            bv[:, 0] -= first
+        cur = run(cur, bh, kh)
+    if out_h != H:
+        cur = run(cur.transpose(1, 0, 2), bv, kv).transpose(1, 0, 2)
+    return cur
+
+
+def preprocess_frames(frames_u8, image_mean, image_std, size: int, pad: bool):
+    """uint8 [T,H,W,3] -> float32 [T,3,size,size] as process_video does it (mm_utils.py:456-462): optional expand2square
+    with background int(mean*255) (mm_utils.py:259-270), resize so the shorter side is `size` (longer side int(size*long/short),
+    HF get_resize_output_image_size), centre crop (top = (h-size)//2, left = (w-size)//2), float32(float64(u8)*(1/255)),
+    (x - float32(mean)) / float32(std)."""
+    import numpy as np
+    mean = np.asarray(image_mean, dtype=np.float32)
+    std = np.asarray(image_std, dtype=np.float32)
+    out = []
+    for f in np.asarray(frames_u8):
+        H, W, _ = f.shape
+        if pad and H != W:
+            S = max(H, W)
+            canvas = np.empty((S, S, 3), dtype=np.uint8)
+            canvas[:] = np.array([int(float(m) * 255) for m in image_mean], dtype=np.uint8)
+            if W > H:
+                y0 = (W - H) // 2
+                canvas[y0:y0 + H] = f
+            else:
+                x0 = (H - W) // 2
+                canvas[:, x0:x0 + W] = f
+            f, H, W = canvas, S, S
+        if W <= H:
+            nw, nh = size, int(size * H / W)
+        else:
+            nh, nw = size, int(size * W / H)
+        r = pillow_resize(f, nw, nh)
+        top, left = (nh - size) // 2, (nw - size) // 2
+        c = r[top:top + size, left:left + size]
+        x = (c.astype(np.float64) * (1 / 255)).astype(np.float32)
+        x = (x - mean) / std
+        out.append(x.transpose(2, 0, 1))
+    return np.stack(out).astype(np.float32)
+
+
 class Oracle:
     def __init__(self, cfg, weights: Dict[str, torch.Tensor], emulate_bf16: bool = False):
         self.cfg = cfg

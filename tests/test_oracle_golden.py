@@ -122,3 +122,26 @@ def test_swap_head():
     cfg = tcfg.trace_7b()
     assert O.swap_head(cfg, 32000, 0) == 1 and O.swap_head(cfg, 32001, 1) == 2 and O.swap_head(cfg, 32014, 2) == 0
     assert O.swap_head(cfg, 17, 0) == 0 and O.swap_head(cfg, 32005, 1) == 1
+
+
+def test_preprocess_matches_reference_fixture(golden_dir):
+    """Frame preprocessing restatement (Pillow 8-bit bicubic + HF rescale/normalise) vs outputs of the reference's
+    expand2square + the HF CLIPImageProcessor it calls, captured by oracle/make_goldens.py: bit-exact float32."""
+    G = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    mean, std = G["image_mean"].tolist(), G["image_std"].tolist()
+    for tag in ("land", "port", "square", "up"):
+        for mode in ("pad", "plain"):
+            got = O.preprocess_frames(G[f"{tag}_frames"], mean, std, 56, pad=(mode == "pad"))
+            ref = G[f"{tag}_{mode}"]
+            assert got.shape == ref.shape
+            assert np.array_equal(got, ref), f"{tag}/{mode}: max diff {np.abs(got - ref).max()}"
+
+
+def test_pillow_resize_restatement_is_pillow():
+    """The integer restatement of Pillow's resampler equals Pillow itself (the third-party code the reference runs)."""
+    from PIL import Image
+    rng = np.random.RandomState(0)
+    for (H, W, oh, ow) in [(48, 64, 33, 44), (72, 128, 56, 99), (20, 7, 56, 19), (56, 56, 56, 56), (10, 16, 56, 89)]:
+        img = rng.randint(0, 256, size=(H, W, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((ow, oh), resample=Image.BICUBIC))
+        assert np.array_equal(O.pillow_resize(img, ow, oh), ref), (H, W, oh, ow)

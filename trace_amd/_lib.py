@@ -35,6 +35,7 @@ SIGNATURES = {
     "trace_ctx_load_tensor": (I, [P, C.c_char_p, P, I, C.POINTER(C.c_int64), I]),
     "trace_ctx_finalize": (I, [P]),
     "trace_ctx_device_bytes": (C.c_int64, [P]),
+    "trace_preprocess_frames": (I, [P, P, I, I, I, I, P, P, P, I, P]),
     "trace_vit_forward": (I, [P, P, I, I, P, P]),
     "trace_slot_pool": (I, [P, P, I, P, P]),
     "trace_stc_connector": (I, [P, P, I, P, C.POINTER(I), P]),

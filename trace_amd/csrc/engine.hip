@@ -69,6 +69,7 @@ struct trace_ctx {
     // decode state
     bf16_t *dX, *dH, *dQKV, *dO, *dACT, *xlast;   // [16, *]
     float* attn_ws; unsigned int* tickets;
+    void* pp_buf = nullptr; size_t pp_bytes = 0;       // frame preprocessing: tap tables + staged rows (grow-only)
     float* sk_ws = nullptr; unsigned int* sk_tickets = nullptr; size_t sk_ws_floats = 0; int sk_ntickets = 0;   // decode GEMV K-chunk partials
     float* part_val; int32_t* part_idx;
     int32_t *d_slots, *d_pos, *d_heads, *d_done, *d_out_ids, *d_out_len, *d_step, *d_forced, *d_params;
@@ -244,6 +245,7 @@ extern "C" int trace_ctx_destroy(trace_ctx* c) {
     if (c->gev0) hipEventDestroy(c->gev0);
     if (c->gev1) hipEventDestroy(c->gev1);
     for (void* p : c->allocs) hipFree(p);
+    if (c->pp_buf) hipFree(c->pp_buf);
     if (c->h_kind) hipHostFree(c->h_kind);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -644,6 +646,103 @@ extern "C" int trace_splice_embeds(trace_ctx* c, const int32_t* ids, int n_ids, 
     c->spliced_len = L;
     if (L_out) *L_out = L;
     if (embeds_out) HIPCHK(hipMemcpyAsync(embeds_out, c->pX, (size_t)L * c->H * 2, hipMemcpyDeviceToDevice, s));
+    return TRACE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ frame preprocessing
+// Pillow's Resample.c precompute_coeffs + normalize_coeffs_8bpc for the BICUBIC filter, in its operation order (double).
+#pragma clang fp contract(off)
+static double pil_bicubic(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+static int pil_coeffs(int in_size, int out_size, std::vector<int32_t>& bounds, std::vector<int32_t>& kk) {
+    double scale, filterscale;
+    scale = filterscale = (double)in_size / out_size;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 2.0 * filterscale;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    bounds.assign((size_t)out_size * 2, 0);
+    kk.assign((size_t)out_size * ksize, 0);
+    std::vector<double> w(ksize);
+    const double ss = 1.0 / filterscale;
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; ++x) { w[x] = pil_bicubic((x + xmin - center + 0.5) * ss); ww += w[x]; }
+        for (int x = 0; x < xmax; ++x) {
+            const double k = ww != 0.0 ? w[x] / ww : w[x];
+            kk[(size_t)xx * ksize + x] = k < 0 ? (int)(-0.5 + k * (1 << 22)) : (int)(0.5 + k * (1 << 22));
+        }
+        bounds[2 * xx] = xmin; bounds[2 * xx + 1] = xmax;
+    }
+    return ksize;
+}
+
+extern "C" int trace_preprocess_frames(trace_ctx* c, const void* frames_u8, int T, int H, int W, int pad_to_square,
+                                       const float* image_mean, const float* image_std, void* out, int out_dtype, void* stream) {
+    if (!c) return fail(TRACE_ERR_ARG, "null ctx");
+    if (!frames_u8 || !out || !image_mean || !image_std || T < 1 || H < 1 || W < 1 || (out_dtype != 0 && out_dtype != 1))
+        return fail(TRACE_ERR_ARG, "bad preprocess arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = c->c.v_image;
+    // geometry: expand2square (mm_utils.py:259-270), shortest edge -> S (HF get_resize_output_image_size), centre crop
+    int PH = H, PW = W, y0 = 0, x0 = 0;
+    if (pad_to_square && H != W) {
+        PH = PW = H > W ? H : W;
+        if (W > H) y0 = (W - H) / 2; else x0 = (H - W) / 2;
+    }
+    int nh, nw;
+    if (PW <= PH) { nw = S; nh = (int)((double)((long)S * PH) / (double)PW); }
+    else { nh = S; nw = (int)((double)((long)S * PW) / (double)PH); }
+    const int top = (nh - S) / 2, left = (nw - S) / 2;
+    std::vector<int32_t> bh, kh, bv, kv;
+    const int ksh = pil_coeffs(PW, nw, bh, kh), ksv = pil_coeffs(PH, nh, bv, kv);
+    const int row_first = bv[2 * top], row_last = bv[2 * (top + S - 1)] + bv[2 * (top + S - 1) + 1];
+    const int nrows = row_last - row_first;
+    // device tables: cropped columns / rows only; vertical bounds relative to the first staged row
+    std::vector<int32_t> tab((size_t)S * 2 * 2 + (size_t)S * (ksh + ksv));
+    int32_t* tbh = tab.data(); int32_t* tbv = tbh + 2 * S; int32_t* tkh = tbv + 2 * S; int32_t* tkv = tkh + (size_t)S * ksh;
+    for (int j = 0; j < S; ++j) {
+        tbh[2 * j] = bh[2 * (left + j)]; tbh[2 * j + 1] = bh[2 * (left + j) + 1];
+        tbv[2 * j] = bv[2 * (top + j)] - row_first; tbv[2 * j + 1] = bv[2 * (top + j) + 1];
+        memcpy(tkh + (size_t)j * ksh, kh.data() + (size_t)(left + j) * ksh, (size_t)ksh * 4);
+        memcpy(tkv + (size_t)j * ksv, kv.data() + (size_t)(top + j) * ksv, (size_t)ksv * 4);
+    }
+    // rescale + normalise of an 8-bit value, in the reference's arithmetic: float32(float64(u) * (1/255)), (x - mean) / std
+    std::vector<float> lut(3 * 256);
+    uint32_t bg = 0;
+    for (int ch = 0; ch < 3; ++ch) {
+        for (int u = 0; u < 256; ++u) {
+            const float x = (float)((double)u * (1.0 / 255));
+            lut[ch * 256 + u] = (x - image_mean[ch]) / image_std[ch];
+        }
+        bg |= (uint32_t)((int)(image_mean[ch] * 255) & 255) << (8 * ch);       // int(x*255), mm_utils.py:457
+    }
+    const size_t tab_bytes = tab.size() * 4, lut_bytes = lut.size() * 4, tmp_bytes = (size_t)T * nrows * S * 3;
+    if (c->pp_bytes < tab_bytes + lut_bytes + tmp_bytes + 512) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (c->pp_buf) hipFree(c->pp_buf);
+        c->pp_bytes = tab_bytes + lut_bytes + tmp_bytes + 512;
+        HIPCHK(hipMalloc(&c->pp_buf, c->pp_bytes));
+    }
+    char* base = (char*)c->pp_buf;
+    int32_t* d_tab = (int32_t*)base;
+    float* d_lut = (float*)(base + ((tab_bytes + 255) & ~(size_t)255));
+    uint8_t* d_tmp = (uint8_t*)d_lut + ((lut_bytes + 255) & ~(size_t)255);
+    HIPCHK(hipMemcpyAsync(d_tab, tab.data(), tab_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_lut, lut.data(), lut_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));                      // host vectors go out of scope below
+    LCHK(launch_resize_h((const uint8_t*)frames_u8, T, H, W, y0, x0, bg, d_tab, d_tab + 4 * S, ksh, row_first, nrows, S, d_tmp, s));
+    LCHK(launch_resize_v_norm(d_tmp, T, nrows, S, d_tab + 2 * S, d_tab + 4 * S + (size_t)S * ksh, ksv, d_lut, out, out_dtype, s));
     return TRACE_OK;
 }
 

@@ -124,3 +124,9 @@ int launch_scale_rows(bf16_t* x, const bf16_t* gate /*[N][C]*/, int N, int HW, i
 int launch_add_act(bf16_t* x, const bf16_t* y, long n, int act, hipStream_t s);
 int launch_im2col3d(const bf16_t* x, bf16_t* A, int T, int H, int W, int C, int To, int Ho, int Wo, hipStream_t s);
 int launch_permute_conv3d_w(const bf16_t* w, bf16_t* out, int Co, int Ci, hipStream_t s);
+
+// ---- frame preprocessing (preproc.hip): Pillow 8-bit bicubic resample passes + rescale/normalise table ----
+int launch_resize_h(const uint8_t* frames, int T, int H, int W, int y0, int x0, uint32_t bg, const int32_t* bounds,
+                    const int32_t* kk, int ksize, int row_first, int nrows, int S, uint8_t* tmp, hipStream_t s);
+int launch_resize_v_norm(const uint8_t* tmp, int T, int nrows, int S, const int32_t* bounds, const int32_t* kk, int ksize,
+                         const float* lut, void* out, int out_f32, hipStream_t s);

@@ -92,6 +92,27 @@ class TraceEngine:
         frames = frames.to(self.device).contiguous()
         return frames, (1 if frames.dtype == torch.float32 else 0)
 
+    CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+    CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+    def preprocess_frames(self, frames_u8, pad: bool = True, image_mean: Sequence[float] = CLIP_MEAN,
+                          image_std: Sequence[float] = CLIP_STD, dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+        """process_video's per-frame image work (mm_utils.py:456-462) on the device: uint8 RGB [T,H,W,3] (tensor or numpy,
+        host or device) -> [T,3,S,S] `dtype` (bf16 for the engine, fp32 = the reference's FloatTensor bit for bit)."""
+        x = torch.as_tensor(frames_u8)
+        if x.dtype != torch.uint8 or x.dim() != 4 or x.shape[-1] != 3:
+            raise ValueError(f"expected uint8 [T,H,W,3] RGB frames, got {x.dtype} {tuple(x.shape)}")
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("dtype must be bfloat16 or float32")
+        x = x.to(self.device).contiguous()
+        T, H, W, _ = x.shape
+        S = self.cfg.vision_image_size
+        out = torch.empty((T, 3, S, S), dtype=dtype, device=self.device)
+        mean, std = (C.c_float * 3)(*image_mean), (C.c_float * 3)(*image_std)
+        _lib.check(self.lib.trace_preprocess_frames(self.h, _ptr(x), T, H, W, int(bool(pad)), mean, std, _ptr(out),
+                                                    1 if dtype == torch.float32 else 0, _stream()))
+        return out
+
     def vit_forward(self, frames: torch.Tensor, want_output: bool = True) -> Optional[torch.Tensor]:
         frames, dt = self._frames(frames)
         T = frames.shape[0]

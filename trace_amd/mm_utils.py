@@ -75,8 +75,11 @@ def _to_frames(video, fps):
 
 
 def process_video(video_path, processor, aspect_ratio="pad", num_frames=NUM_FRAMES, image_grid=False,
-                  sample_scheme="uniform", fps: Optional[float] = None):
-    """-> (FloatTensor[T,3,S,S], [[t_seconds]] * T)   (mm_utils.py:379-471)."""
+                  sample_scheme="uniform", fps: Optional[float] = None, engine=None):
+    """-> (FloatTensor[T,3,S,S], [[t_seconds]] * T)   (mm_utils.py:379-471).
+    `engine` (a TraceEngine, or a model carrying one as `.engine`): run the per-frame image work — expand2square, bicubic
+    resize, centre crop, rescale, normalise — on the GPU (trace_preprocess_frames) and return a bf16 device tensor the
+    model consumes directly; same values as the host path (the resize is Pillow's resampler bit for bit)."""
     src, local_fps = _to_frames(video_path, fps)
     duration = len(src)
     idx, video_timestamps = sample_indices_and_timestamps(duration, local_fps, num_frames, sample_scheme)
@@ -86,15 +89,22 @@ def process_video(video_path, processor, aspect_ratio="pad", num_frames=NUM_FRAM
         frames = [f for f in data]
     else:
         frames = [src[int(i)] for i in idx]
+    # mm_utils.py:466-469 (error types kept; the reference checks after preprocessing, which has no side effects)
+    if video_timestamps[-1][0] > 9999:
+        raise ImportError("The video is too long!")
+    if video_timestamps[0][0] < 0:
+        raise ImportError("Timestamp can not be less than zero")
+    eng = getattr(engine, "engine", engine)
+    if eng is not None:
+        arr = np.stack([np.asarray(f.convert("RGB") if isinstance(f, Image.Image) else f) for f in frames])
+        mean = getattr(processor, "image_mean", None) or eng.CLIP_MEAN
+        std = getattr(processor, "image_std", None) or eng.CLIP_STD
+        return eng.preprocess_frames(arr, pad=(aspect_ratio == "pad"), image_mean=mean, image_std=std), video_timestamps
     images = [f if isinstance(f, Image.Image) else Image.fromarray(np.asarray(f)) for f in frames]
     if aspect_ratio == "pad":
         bg = tuple(int(x * 255) for x in processor.image_mean)           # mm_utils.py:456-458
         images = [expand2square(im, bg) for im in images]
     video = processor.preprocess(images, return_tensors="pt")["pixel_values"]
-    if video_timestamps[-1][0] > 9999:                                    # mm_utils.py:466-469 (error types kept)
-        raise ImportError("The video is too long!")
-    if video_timestamps[0][0] < 0:
-        raise ImportError("Timestamp can not be less than zero")
     return video, video_timestamps
 
 

@@ -106,3 +106,29 @@ def test_safetensors_checkpoint_loader(tmp_path_factory, loaded):
     o2 = model2.generate(ids.unsqueeze(0), heads=[1], **kw)
     assert torch.equal(o1, o2)
     model2.engine.close()
+
+
+def test_batched_generate_and_device_preprocess(loaded):
+    """the drivers' API with B > 1 (`images_or_videos=[v1, v2]`, `heads=[1, 1]`, equal prompt lengths — the only
+    case the reference's own forward supports, trace_arch.py:502-517) gives each row what the single-video call gives, pads
+    with pad_token_id and mutates `heads` per row; and frames preprocessed on the device (process_video(engine=model)) decode
+    to the same ids as frames from the host PIL path."""
+    cfg, tok, model, proc, _ = loaded
+    t1, ts1, ids = _driver_inputs(cfg, tok, proc, seed=1)
+    t2, ts2, _ = _driver_inputs(cfg, tok, proc, seed=2)
+    kw = dict(modal_list=["video"], do_sample=False, max_new_tokens=10, use_cache=True, pad_token_id=tok.eos_token_id)
+    o1 = model.generate(ids.unsqueeze(0), images_or_videos=[t1], video_timestamps=[ts1], heads=[1], **kw)
+    o2 = model.generate(ids.unsqueeze(0), images_or_videos=[t2], video_timestamps=[ts2], heads=[1], **kw)
+    heads = [1, 1]
+    kw["modal_list"] = ["video", "video"]
+    ob = model.generate(torch.stack([ids, ids]), images_or_videos=[t1, t2], video_timestamps=[ts1, ts2], heads=heads, **kw)
+    assert ob.shape[0] == 2 and ob.dtype == torch.long
+    assert ob[0, : o1.shape[1]].tolist() == o1[0].tolist() and ob[1, : o2.shape[1]].tolist() == o2[0].tolist()
+    assert all(h in (0, 1, 2) for h in heads)
+    # device preprocessing inside the driver loop
+    raw = np.random.RandomState(1).randint(0, 255, size=(40, 48, 64, 3), dtype=np.uint8)
+    dev, ts_d = process_video(raw, proc, "pad", 4, fps=8.0, engine=model)
+    assert ts_d == ts1 and dev.is_cuda and torch.equal(dev.cpu(), t1.to(torch.bfloat16))
+    kw["modal_list"] = ["video"]
+    od = model.generate(ids.unsqueeze(0), images_or_videos=[dev], video_timestamps=[ts_d], heads=[1], **kw)
+    assert od.tolist() == o1.tolist()

@@ -41,6 +41,8 @@ __device__ __forceinline__ int swz(int row, int kc) { return row * 128 + ((kc ^ 
 // almost additively (458 us together), in either loop structure, also with the DMA confined to the read phases.  A
 // 256x256 tile cannot lower DMA bytes per flop (the accumulators already fill half the register file), so the next
 // step is hiding the per-tile 8 us (epilogue 4 + stores 2 + prologue 1.6) rather than re-shaping the K loop.
+// (6) operand panels read K-tile-contiguously (what a tiled producer layout would give; timing experiment on the same
+// bytes): +2-4 % only — unlike the decode GEMV, these panels come from L2 / infinity cache, not DRAM pages.
 // Per-tile cost after the epilogue fixes (tools/gemm_trace.py): ~8 us fixed + ~1.7 us per K-tile.
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {

@@ -93,6 +93,10 @@ int trace_splice_embeds(trace_ctx* ctx, const int32_t* ids, int n_ids, const int
  * spliced rows (embeds == NULL: internal buffer) through the decoder into KV slot `slot`.  hidden_out (device
  * [L,hidden] bf16, may be NULL) receives the final-norm hidden states (tests). */
 int trace_llm_prefill(trace_ctx* ctx, int slot, const void* embeds, int L, void* hidden_out, void* stream);
+/* Two prompts of EQUAL spliced length prefilled in one pass (GEMM M = 2L fills the MFMA tile grid in whole rounds): embeds0 / embeds1
+ * [L, hidden] bf16 device (the embeds_out of two trace_splice_embeds calls) -> KV slots slot0 and slot0 + 1.  Same results as two
+ * trace_llm_prefill calls. */
+int trace_llm_prefill_pair(trace_ctx* ctx, int slot0, const void* embeds0, const void* embeds1, int L, void* stream);
 
 /* generate() = greedy loop with head switching (trace_mistral.py:268-347 + HF greedy search).
  * begin: sequences = the given KV slots (each prefilled); heads[b] in {0 text,1 time,2 score} (callers pass [1]);

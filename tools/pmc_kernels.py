@@ -5,16 +5,16 @@ from trace_amd import engine as E
 from trace_amd.engine import ops
 dev = torch.device("cuda", 0)
 rnd = lambda *s, scale=1.0: (torch.randn(*s, device=dev) * scale).to(torch.bfloat16)
-what = sys.argv[1] if len(sys.argv) > 1 else "all"
-if what in ("all", "attn"):
+what = sys.argv[1:] or ["all"]
+if "all" in what or "attn" in what:
     q, k, v = rnd(32, 577, 16, 64), rnd(32, 577, 16, 64), rnd(32, 577, 16, 64)
     for _ in range(3):
         ops.attention(q, k, v, False, 0.125)
-if what in ("all", "gemm"):
+if "all" in what or "gemm" in what:
     A, W, b = rnd(73856, 1024), rnd(4096, 1024, scale=0.02), rnd(4096)
     for _ in range(3):
         ops.gemm(A, W, bias=b, epilogue=E.EPI_QUICKGELU)
-if what in ("all", "gemv"):      # the decode step's dominant kernel: gate|up GEMV, batch 64 (the bench default), tile-layout weights, fp32 partial rows
+if "all" in what or "gemv" in what:      # the decode step's dominant kernel: gate|up GEMV, batch 64 (the bench default), tile-layout weights, fp32 partial rows
     Ws = [ops.tile_pack(rnd(28672, 4096, scale=0.02)) for _ in range(3)]
     X = rnd(64, 4096)
     for i in range(6):

@@ -1,5 +1,5 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs — the TCC block cannot hold both) over
-`tools/pmc_kernels.py gemv` into profiles/traffic.json: HBM-side bytes per launch of the decode gate|up GEMV.
+`tools/pmc_kernels.py gemm gemv` into profiles/traffic.json: HBM-side bytes per launch of the decode gate|up GEMV.
 usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> > profiles/traffic.json
 Corrections (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE (KB) counts wide coalesced streaming reads at
 half their bytes -> x2; WRITE_SIZE is uncalibrated (reported as measured, it is ~3 % of the traffic here)."""
@@ -19,9 +19,20 @@ def counter_mean(d, counter, kernel_sub):
 
 fetch_kb, n1 = counter_mean(sys.argv[1], "FETCH_SIZE", "skinny_lds_kernel")
 write_kb, n2 = counter_mean(sys.argv[2], "WRITE_SIZE", "skinny_lds_kernel")
+gf_kb, g1 = counter_mean(sys.argv[1], "FETCH_SIZE", "gemm_glds_kernel<256, 256, 2, 4, 2>")
+gw_kb, g2 = counter_mean(sys.argv[2], "WRITE_SIZE", "gemm_glds_kernel<256, 256, 2, 4, 2>")
+g_alg = 73856 * 1024 * 2 + 4096 * 1024 * 2 + 73856 * 4096 * 2
+g_total = gf_kb * 1024 * 2 + gw_kb * 1024
 alg = 28672 * 4096 * 2
 total = fetch_kb * 1024 * 2 + write_kb * 1024
 json.dump({
+    "gemm_fc1_bytes_per_launch": g_total,
+    "gemm_fc1_detail": {
+        "kernel": "gemm_glds_kernel<256,256,EPI_QUICKGELU> (ViT fc1, M=73856 N=4096 K=1024), 3 launches",
+        "FETCH_SIZE_KB_mean": gf_kb, "WRITE_SIZE_KB_mean": gw_kb, "launches": [g1, g2],
+        "correction": "FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 (same gfx950 corrections as below; operand panels re-read by "
+                      "other column tiles are served by L2 / infinity cache and only partly reach the memory-side counters)",
+        "algorithmic_bytes": g_alg, "ratio_traffic_over_algorithmic": g_total / g_alg},
     "skinny_gateup_bytes_per_launch": total,
     "detail": {
         "kernel": "skinny_lds_kernel<EPI_PARTIAL, NB=4, NT=2> (decode gate|up GEMV), B=64, 6 launches over 3 rotating weight copies",

@@ -199,8 +199,9 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     }
     // --- prefill workspaces ---
     const size_t Lm = c->max_ctx;
-    A(c->pX, Lm * H); A(c->pH, Lm * H); A(c->pQKV, Lm * c->QKV);
-    A(c->pO, Lm * H); A(c->pACT, Lm * I);
+    // prefill workspaces hold two sequences (trace_llm_prefill_pair)
+    A(c->pX, 2 * Lm * H); A(c->pH, 2 * Lm * H); A(c->pQKV, 2 * Lm * c->QKV);
+    A(c->pO, 2 * Lm * H); A(c->pACT, 2 * Lm * I);
     A(c->d_kind, Lm); A(c->d_row, Lm);
     // --- decode ---
     A(c->dX, SK_ROWS * H); A(c->dH, SK_ROWS * H); A(c->dQKV, SK_ROWS * (size_t)c->QKV); A(c->dO, SK_ROWS * H); A(c->dACT, SK_ROWS * I);
@@ -747,44 +748,62 @@ extern "C" int trace_preprocess_frames(trace_ctx* c, const void* frames_u8, int 
 }
 
 // ------------------------------------------------------------------------------------------------ LLM prefill
-extern "C" int trace_llm_prefill(trace_ctx* c, int slot, const void* embeds, int L, void* hidden_out, void* stream) {
-    if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
-    if (slot < 0 || slot >= c->max_B || L < 1 || L > c->max_ctx) return fail(TRACE_ERR_ARG, "bad slot / L");
-    hipStream_t s = (hipStream_t)stream;
-    const int H = c->H, I = c->I, HD = c->HD, QKV = c->QKV;
-    if (embeds) HIPCHK(hipMemcpyAsync(c->pX, embeds, (size_t)L * H * 2, hipMemcpyDeviceToDevice, s));
-    const int Lpad = round_up(L, 64);
+// nb equal-length sequences laid end to end in pX (rows [b*L, (b+1)*L)) -> slots slot0 .. slot0+nb-1.  Two 1967-row
+// prompts give the GEMMs M = 3934: 16 row tiles fill the 256x256 tile grid in whole rounds (gate|up 1792 tiles = 7.0
+// rounds instead of 896 = 3.5) and o-proj / down-proj reach the 256^2 kernel.
+static int prefill_impl(trace_ctx* c, int slot0, int nb, int L, void* hidden_out, hipStream_t s) {
+    const int H = c->H, I = c->I, HD = c->HD, QKV = c->QKV, M = nb * L;
     AttnArgs a{};
     a.Q = c->pQKV; a.O = c->pO;
-    a.q_bs = 0; a.q_hs = HD; a.q_rs = QKV;
-    a.k_bs = 0; a.k_hs = (long)c->kv_head_stride; a.k_rs = HD;
-    a.v_bs = 0; a.v_hs = (long)c->kv_head_stride; a.v_rs = c->ctx_pad;      // V^T straight from the cache
-    a.o_bs = 0; a.o_hs = HD; a.o_rs = H;
-    a.nq_rows = L; a.nkv_rows = L; a.batch = 1; a.heads = c->NQ; a.kv_heads = c->NKV;
+    a.q_bs = (long)L * QKV; a.q_hs = HD; a.q_rs = QKV;
+    a.k_bs = (long)c->slot_stride; a.k_hs = (long)c->kv_head_stride; a.k_rs = HD;
+    a.v_bs = (long)c->slot_stride; a.v_hs = (long)c->kv_head_stride; a.v_rs = c->ctx_pad;      // V^T straight from the cache
+    a.o_bs = (long)L * H; a.o_hs = HD; a.o_rs = H;
+    a.nq_rows = L; a.nkv_rows = L; a.batch = nb; a.heads = c->NQ; a.kv_heads = c->NKV;
     a.scale = 1.0f / sqrtf((float)HD); a.causal = 1;
     for (int l = 0; l < c->NL; ++l) {
         const LlmLayer& W = c->llm[l];
         bf16_t* kc = c->kcache + (size_t)l * c->layer_stride;
         bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
-        LCHK(launch_rmsnorm(c->pX, H, c->pH, H, W.rms1, L, H, c->c.rms_eps, s));
-        TRY(gemm(c->pH, H, W.wqkv, H, c->pQKV, QKV, nullptr, nullptr, 0, L, QKV, H, EPI_NONE, s));
-        LCHK(launch_rope_kv(c->pQKV, QKV, kc, nullptr, (long)c->slot_stride, (long)c->kv_head_stride, nullptr, nullptr, slot, 0, L,
-                            c->NQ, c->NKV, HD, c->rope_cos, c->rope_sin, s));
+        LCHK(launch_rmsnorm(c->pX, H, c->pH, H, W.rms1, M, H, c->c.rms_eps, s));
+        TRY(gemm(c->pH, H, W.wqkv, H, c->pQKV, QKV, nullptr, nullptr, 0, M, QKV, H, EPI_NONE, s));
+        LCHK(launch_rope_kv(c->pQKV, QKV, kc, nullptr, (long)c->slot_stride, (long)c->kv_head_stride, nullptr, nullptr, slot0, 0, M,
+                            c->NQ, c->NKV, HD, c->rope_cos, c->rope_sin, L, s));
         // V goes into the cache transposed ([kvh][hd][ctx_pad]; positions L..Lpad-1 are zero-filled, later overwritten)
-        LCHK(launch_transpose_v(c->pQKV + (size_t)(c->NQ + c->NKV) * HD, 0, HD, QKV, vc + (size_t)slot * c->slot_stride, 0,
-                                (long)c->kv_head_stride, c->ctx_pad, L, HD, c->NKV, 1, s));
-        a.K = kc + (size_t)slot * c->slot_stride;
-        a.V = vc + (size_t)slot * c->slot_stride;
+        LCHK(launch_transpose_v(c->pQKV + (size_t)(c->NQ + c->NKV) * HD, (long)L * QKV, HD, QKV, vc + (size_t)slot0 * c->slot_stride,
+                                (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, L, HD, c->NKV, nb, s));
+        a.K = kc + (size_t)slot0 * c->slot_stride;
+        a.V = vc + (size_t)slot0 * c->slot_stride;
         LCHK(launch_attn_prefill(a, s));
-        TRY(gemm(c->pO, H, W.wo, H, c->pX, H, nullptr, c->pX, H, L, H, H, EPI_RESIDUAL, s));
-        LCHK(launch_rmsnorm(c->pX, H, c->pH, H, W.rms2, L, H, c->c.rms_eps, s));
-        TRY(gemm(c->pH, H, W.wgu, H, c->pACT, I, nullptr, nullptr, 0, L, 2 * I, H, EPI_SWIGLU, s));
-        TRY(gemm(c->pACT, I, W.wd, I, c->pX, H, nullptr, c->pX, H, L, H, I, EPI_RESIDUAL, s));
+        TRY(gemm(c->pO, H, W.wo, H, c->pX, H, nullptr, c->pX, H, M, H, H, EPI_RESIDUAL, s));
+        LCHK(launch_rmsnorm(c->pX, H, c->pH, H, W.rms2, M, H, c->c.rms_eps, s));
+        TRY(gemm(c->pH, H, W.wgu, H, c->pACT, I, nullptr, nullptr, 0, M, 2 * I, H, EPI_SWIGLU, s));
+        TRY(gemm(c->pACT, I, W.wd, I, c->pX, H, nullptr, c->pX, H, M, H, I, EPI_RESIDUAL, s));
     }
-    if (hidden_out) LCHK(launch_rmsnorm(c->pX, H, (bf16_t*)hidden_out, H, c->final_norm, L, H, c->c.rms_eps, s));
-    LCHK(launch_rmsnorm(c->pX + (size_t)(L - 1) * H, H, c->xlast + (size_t)slot * H, H, c->final_norm, 1, H, c->c.rms_eps, s));
-    c->slot_len[slot] = L;
+    if (hidden_out) LCHK(launch_rmsnorm(c->pX, H, (bf16_t*)hidden_out, H, c->final_norm, M, H, c->c.rms_eps, s));
+    for (int b = 0; b < nb; ++b) {
+        LCHK(launch_rmsnorm(c->pX + ((size_t)b * L + L - 1) * H, H, c->xlast + (size_t)(slot0 + b) * H, H, c->final_norm, 1, H,
+                            c->c.rms_eps, s));
+        c->slot_len[slot0 + b] = L;
+    }
     return TRACE_OK;
+}
+
+extern "C" int trace_llm_prefill(trace_ctx* c, int slot, const void* embeds, int L, void* hidden_out, void* stream) {
+    if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
+    if (slot < 0 || slot >= c->max_B || L < 1 || L > c->max_ctx) return fail(TRACE_ERR_ARG, "bad slot / L");
+    hipStream_t s = (hipStream_t)stream;
+    if (embeds) HIPCHK(hipMemcpyAsync(c->pX, embeds, (size_t)L * c->H * 2, hipMemcpyDeviceToDevice, s));
+    return prefill_impl(c, slot, 1, L, hidden_out, s);
+}
+
+extern "C" int trace_llm_prefill_pair(trace_ctx* c, int slot0, const void* embeds0, const void* embeds1, int L, void* stream) {
+    if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
+    if (slot0 < 0 || slot0 + 1 >= c->max_B || L < 1 || L > c->max_ctx || !embeds0 || !embeds1) return fail(TRACE_ERR_ARG, "bad slot / L / embeds");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(c->pX, embeds0, (size_t)L * c->H * 2, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->pX + (size_t)L * c->H, embeds1, (size_t)L * c->H * 2, hipMemcpyDeviceToDevice, s));
+    return prefill_impl(c, slot0, 2, L, nullptr, s);
 }
 
 // ------------------------------------------------------------------------------------------------ decode

@@ -71,7 +71,7 @@ int launch_gather_rows(const GatherTabs& tabs, const int32_t* kind, const int32_
 // Row r: pos = pos_arr ? pos_arr[r] : pos0 + r ; slot = slot_arr ? slot_arr[r] : slot0.
 int launch_rope_kv(bf16_t* qkv, int ld, bf16_t* kcache, bf16_t* vcache, long slot_stride, long kv_head_stride,
                    const int32_t* slot_arr, const int32_t* pos_arr, int slot0, int pos0, int R, int nq, int nkv, int hd,
-                   const float* cos_t, const float* sin_t, hipStream_t s);
+                   const float* cos_t, const float* sin_t, int seq_len, hipStream_t s);   // seq_len > 0: R/seq_len prefill sequences end to end -> slots slot0, slot0+1, ...
 
 // ---- decode (decode.hip) ----
 // out[b, n] = sum_k X[b,k] W[n,k]  (B <= 64) (+ residual / SwiGLU on interleaved W)

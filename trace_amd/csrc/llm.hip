@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(bf16_t* __restrict__ qkv, 
                                                       bf16_t* __restrict__ vcache, long slot_stride, long kv_head_stride,
                                                       const int32_t* __restrict__ slot_arr, const int32_t* __restrict__ pos_arr,
                                                       int slot0, int pos0, int R, int nq, int nkv, int hd,
-                                                      const float* __restrict__ cos_t, const float* __restrict__ sin_t) {
+                                                      const float* __restrict__ cos_t, const float* __restrict__ sin_t, int seq_len) {
     const int half = hd >> 1, lph = half >> 3;           // lanes per head
     const int nh = nq + 2 * nkv;
     const long total = (long)R * nh * lph;
@@ -33,8 +33,11 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(bf16_t* __restrict__ qkv, 
         const int c = (int)(i % lph);
         const long rh = i / lph;
         const int hh = (int)(rh % nh), r = (int)(rh / nh);
-        const int pos = pos_arr ? pos_arr[r] : pos0 + r;
-        const int slot = slot_arr ? slot_arr[r] : slot0;
+        // rows are either one decode row per sequence (slot_arr / pos_arr), or `R / seq_len` equal-length prefill sequences
+        // laid end to end going to consecutive slots
+        const int sq = seq_len > 0 ? r / seq_len : 0;
+        const int pos = pos_arr ? pos_arr[r] : pos0 + r - sq * seq_len;
+        const int slot = slot_arr ? slot_arr[r] : slot0 + sq;
         bf16_t* x = qkv + (size_t)r * ld + (size_t)hh * hd;
         const uint4 u1 = *reinterpret_cast<const uint4*>(x + c * 8);
         const uint4 u2 = *reinterpret_cast<const uint4*>(x + half + c * 8);
@@ -78,11 +81,11 @@ int launch_gather_rows(const GatherTabs& tabs, const int32_t* kind, const int32_
 
 int launch_rope_kv(bf16_t* qkv, int ld, bf16_t* kcache, bf16_t* vcache, long slot_stride, long kv_head_stride,
                    const int32_t* slot_arr, const int32_t* pos_arr, int slot0, int pos0, int R, int nq, int nkv, int hd,
-                   const float* cos_t, const float* sin_t, hipStream_t s) {
+                   const float* cos_t, const float* sin_t, int seq_len, hipStream_t s) {
     if (R <= 0 || hd % 16 || (ld % 8)) return TRACE_ERR_ARG;
     const long total = (long)R * (nq + 2 * nkv) * (hd / 16);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(rope_kv_kernel, dim3(grid), dim3(256), 0, s, qkv, ld, kcache, vcache, slot_stride, kv_head_stride,
-                       slot_arr, pos_arr, slot0, pos0, R, nq, nkv, hd, cos_t, sin_t);
+                       slot_arr, pos_arr, slot0, pos0, R, nq, nkv, hd, cos_t, sin_t, seq_len);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }

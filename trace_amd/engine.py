@@ -179,6 +179,12 @@ class TraceEngine:
         _lib.check(self.lib.trace_llm_prefill(self.h, slot, _ptr(embeds), L, _ptr(hid), _stream()))
         return hid
 
+    def prefill_pair(self, slot0: int, embeds0: torch.Tensor, embeds1: torch.Tensor):
+        """two spliced prompts of equal length -> KV slots slot0, slot0 + 1 in one pass (trace_llm_prefill_pair)"""
+        assert embeds0.shape == embeds1.shape and embeds0.dtype == torch.bfloat16 and embeds0.is_cuda
+        _lib.check(self.lib.trace_llm_prefill_pair(self.h, slot0, _ptr(embeds0.contiguous()), _ptr(embeds1.contiguous()),
+                                                   embeds0.shape[0], _stream()))
+
     # ---- decode --------------------------------------------------------------------------------
     def decode_begin(self, slots: Sequence[int], heads: Sequence[int], max_new: int, eos: int = -1,
                      forced: Optional[Sequence[Sequence[int]]] = None, want_logits: bool = False):
@@ -234,10 +240,23 @@ class TraceEngine:
         B = len(videos)
         if B > self.max_batch:
             raise ValueError(f"batch {B} exceeds engine max_batch {self.max_batch}")
+        # prefill: neighbours whose spliced prompts have the same length share one pass (M = 2L fills the GEMM tile grid)
+        held = None                                   # (slot, spliced embeds) waiting for a partner
         for b in range(B):
             self.encode_video(videos[b], timestamps[b])
-            L = self.splice(input_ids[b])
-            self.prefill(b, L)
+            if b + 1 < B or held is not None:
+                L, emb = self.splice(input_ids[b], want_output=True)
+                if held is not None and held[1].shape[0] == L and held[0] + 1 == b:
+                    self.prefill_pair(held[0], held[1], emb)
+                    held = None
+                    continue
+                if held is not None:
+                    self.prefill(held[0], held[1].shape[0], embeds=held[1])
+                held = (b, emb)
+            else:
+                self.prefill(b, self.splice(input_ids[b]))
+        if held is not None:
+            self.prefill(held[0], held[1].shape[0], embeds=held[1])
         self.decode_begin(list(range(B)), heads, max_new_tokens, eos, forced)
         if max_new_tokens > 1:
             if eos < 0:

@@ -14,7 +14,7 @@ def timeit(fn, iters=50, warmup=5):
     return s.elapsed_time(e) / iters * 1e3
 nq, nkv, max_ctx = 32, 8, 2304
 L = _lib.load()
-for Bn in (1, 4, 16, 32):
+for Bn in (1, 16, 32, 64):
     q = torch.randn(Bn, nq * 128, device=dev).to(torch.bfloat16)
     kc = torch.randn(Bn, nkv, max_ctx, 128, device=dev).to(torch.bfloat16)
     vt = torch.randn(Bn, nkv, 128, max_ctx, device=dev).to(torch.bfloat16)
@@ -22,7 +22,7 @@ for Bn in (1, 4, 16, 32):
     ws = torch.zeros((Bn * nq * 64 * 130,), dtype=torch.float32, device=dev)
     o = torch.empty_like(q)
     byts = Bn * nkv * 2101 * 128 * 2 * 2
-    for nsplit in (1, 2, 4, 8, 16, 32, 64):
+    for nsplit in ((1, 2, 4) if Bn >= 32 else (2, 4, 8, 16)):
         fn = lambda: _lib.check(L.trace_op_attn_decode(_ptr(q), _ptr(kc), _ptr(vt), _ptr(pos), _ptr(o), _ptr(ws), Bn, nq, nkv, max_ctx, nsplit, 0.088, _stream()))
         t = timeit(fn)
         print(f"B={Bn} nsplit={nsplit}: {t:.1f} us  {byts / t / 1e6:.2f} TB/s", flush=True)

@@ -253,10 +253,17 @@ __global__ __launch_bounds__(256) void swiglu_combine_kernel(const float* __rest
     const int b = idx / I4, j4 = idx - b * I4;
     const int p = j4 >> 2, i = (j4 & 3) * 4;
     const float* base = part + (size_t)b * N2 + p * 32 + i;
-    f32x4_t gt = *reinterpret_cast<const f32x4_t*>(base), up = *reinterpret_cast<const f32x4_t*>(base + 16);
-    for (int k2 = 1; k2 < KS; ++k2) {
-        gt += *reinterpret_cast<const f32x4_t*>(base + (size_t)k2 * SK_ROWS * N2);
-        up += *reinterpret_cast<const f32x4_t*>(base + (size_t)k2 * SK_ROWS * N2 + 16);
+    f32x4_t gt = {0.f, 0.f, 0.f, 0.f}, up = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < KS; k0 += 4) {              // chunk rows fetched four at a time, summed in chunk order
+        f32x4_t tg[4], tu[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = k0 + u < KS;
+            tg[u] = ok ? *reinterpret_cast<const f32x4_t*>(base + (size_t)(k0 + u) * SK_ROWS * N2) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            tu[u] = ok ? *reinterpret_cast<const f32x4_t*>(base + (size_t)(k0 + u) * SK_ROWS * N2 + 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { gt += tg[u]; up += tu[u]; }
     }
     float o[4];
 #pragma unroll
@@ -278,46 +285,51 @@ __global__ __launch_bounds__(256) void tile_pack_kernel(const bf16_t* __restrict
 }
 
 // Decode residual add + RMSNorm fed by EPI_PARTIAL: x = bf16(sum_ks part[ks][b][:]) + R[b][:] (the GEMV epilogue's
-// rounding), stored as the new residual stream, then y = RMSNorm(x) * w.  One workgroup per sequence.
-__global__ __launch_bounds__(256) void add_rmsnorm_kernel(const float* __restrict__ part, int KS, const bf16_t* __restrict__ R, int ldr,
-                                                          bf16_t* __restrict__ xout, int ldx, const bf16_t* __restrict__ w,
-                                                          bf16_t* __restrict__ y, int ldy, int N, float eps) {
-    constexpr int MAXC = 4;                            // 256 threads x 4 chunks x 4 elements = 4096
-    __shared__ float s_red[4];
+// rounding), stored as the new residual stream, then y = RMSNorm(x) * w.  One 1024-thread workgroup per sequence, 4
+// elements per thread; the k-chunk rows are fetched eight at a time (a plain accumulate loop serialises one HBM round
+// trip per chunk: 13 us at 16 chunks) and summed in chunk order.
+__global__ __launch_bounds__(1024) void add_rmsnorm_kernel(const float* __restrict__ part, int KS, const bf16_t* __restrict__ R, int ldr,
+                                                           bf16_t* __restrict__ xout, int ldx, const bf16_t* __restrict__ w,
+                                                           bf16_t* __restrict__ y, int ldy, int N, float eps) {
+    __shared__ float s_red[16];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int nch = N >> 2;
-    float v[MAXC][4];
-    uint2 wv[MAXC];
+    const int c = tid;                                 // N <= 4096: one 4-element chunk per thread
+    const bool on = c < (N >> 2);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    uint2 wv = make_uint2(0u, 0u);
     float ss = 0.f;
+    if (on) {
+        wv = *reinterpret_cast<const uint2*>(w + c * 4);
+        const uint2 rr = *reinterpret_cast<const uint2*>(R + (size_t)b * ldr + c * 4);
+        const float* p0 = part + (size_t)b * N + c * 4;
+        f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < KS; k0 += 8) {
+            f32x4_t t[8];
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = tid + i * 256;
-        if (c < nch) {
-            wv[i] = *reinterpret_cast<const uint2*>(w + c * 4);
-            f32x4_t a = *reinterpret_cast<const f32x4_t*>(part + (size_t)b * N + c * 4);
-            for (int k2 = 1; k2 < KS; ++k2) a += *reinterpret_cast<const f32x4_t*>(part + ((size_t)k2 * SK_ROWS + b) * N + c * 4);
-            const uint2 rr = *reinterpret_cast<const uint2*>(R + (size_t)b * ldr + c * 4);
-            const float x0 = bf2f(f2bf(a[0])) + bflo(rr.x), x1 = bf2f(f2bf(a[1])) + bfhi(rr.x);
-            const float x2 = bf2f(f2bf(a[2])) + bflo(rr.y), x3 = bf2f(f2bf(a[3])) + bfhi(rr.y);
-            const uint2 xo = make_uint2(pack2bf(x0, x1), pack2bf(x2, x3));
-            *reinterpret_cast<uint2*>(xout + (size_t)b * ldx + c * 4) = xo;
-            v[i][0] = bflo(xo.x); v[i][1] = bfhi(xo.x); v[i][2] = bflo(xo.y); v[i][3] = bfhi(xo.y);
+            for (int u = 0; u < 8; ++u)
+                t[u] = k0 + u < KS ? *reinterpret_cast<const f32x4_t*>(p0 + (size_t)(k0 + u) * SK_ROWS * N) : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ss += v[i][e] * v[i][e];
+            for (int u = 0; u < 8; ++u) a += t[u];
         }
+        const float x0 = bf2f(f2bf(a[0])) + bflo(rr.x), x1 = bf2f(f2bf(a[1])) + bfhi(rr.x);
+        const float x2 = bf2f(f2bf(a[2])) + bflo(rr.y), x3 = bf2f(f2bf(a[3])) + bfhi(rr.y);
+        const uint2 xo = make_uint2(pack2bf(x0, x1), pack2bf(x2, x3));
+        *reinterpret_cast<uint2*>(xout + (size_t)b * ldx + c * 4) = xo;
+        v[0] = bflo(xo.x); v[1] = bfhi(xo.x); v[2] = bflo(xo.y); v[3] = bfhi(xo.y);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += v[e] * v[e];
     }
     ss = wave_sum(ss);
     if ((tid & 63) == 0) s_red[tid >> 6] = ss;
     __syncthreads();
-    const float rstd = rsqrtf((s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (float)N + eps);
+    float tot = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = tid + i * 256;
-        if (c < nch) {
-            const float o0 = v[i][0] * rstd * bflo(wv[i].x), o1 = v[i][1] * rstd * bfhi(wv[i].x);
-            const float o2 = v[i][2] * rstd * bflo(wv[i].y), o3 = v[i][3] * rstd * bfhi(wv[i].y);
-            *reinterpret_cast<uint2*>(y + (size_t)b * ldy + c * 4) = make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));
-        }
+    for (int i = 0; i < 16; ++i) tot += s_red[i];
+    const float rstd = rsqrtf(tot / (float)N + eps);
+    if (on) {
+        const float o0 = v[0] * rstd * bflo(wv.x), o1 = v[1] * rstd * bfhi(wv.x);
+        const float o2 = v[2] * rstd * bflo(wv.y), o3 = v[3] * rstd * bfhi(wv.y);
+        *reinterpret_cast<uint2*>(y + (size_t)b * ldy + c * 4) = make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));
     }
 }
 
@@ -895,7 +907,7 @@ int launch_tile_pack(const bf16_t* src, int ldw, bf16_t* dst, int N, int K, hipS
 int launch_add_rmsnorm(const float* part, int KS, const bf16_t* R, int ldr, bf16_t* xout, int ldx, const bf16_t* w, bf16_t* y,
                        int ldy, int B, int N, float eps, hipStream_t s) {
     if (B < 1 || B > SK_ROWS || KS < 1 || N % 4 || N > 4096 || (ldr % 4) || (ldx % 4) || (ldy % 4)) return TRACE_ERR_ARG;
-    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(B), dim3(256), 0, s, part, KS, R, ldr, xout, ldx, w, y, ldy, N, eps);
+    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(B), dim3(1024), 0, s, part, KS, R, ldr, xout, ldx, w, y, ldy, N, eps);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 

@@ -385,10 +385,17 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
     auto slice8 = [&](int n) -> u32x4_t {
         if (!qpart) return *reinterpret_cast<const u32x4_t*>(row + n);
         const float* pp = qpart + (size_t)b * ldq + n;
-        f32x4_t a = *reinterpret_cast<const f32x4_t*>(pp), c = *reinterpret_cast<const f32x4_t*>(pp + 4);
-        for (int k2 = 1; k2 < qks; ++k2) {
-            a += *reinterpret_cast<const f32x4_t*>(pp + (size_t)k2 * SK_ROWS * ldq);
-            c += *reinterpret_cast<const f32x4_t*>(pp + (size_t)k2 * SK_ROWS * ldq + 4);
+        f32x4_t a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < qks; k0 += 4) {          // chunk rows fetched four at a time, summed in chunk order
+            f32x4_t ta[4], tc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = k0 + u < qks;
+                ta[u] = ok ? *reinterpret_cast<const f32x4_t*>(pp + (size_t)(k0 + u) * SK_ROWS * ldq) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                tc[u] = ok ? *reinterpret_cast<const f32x4_t*>(pp + (size_t)(k0 + u) * SK_ROWS * ldq + 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a += ta[u]; c += tc[u]; }
         }
         return u32x4_t{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(c[0], c[1]), pack2bf(c[2], c[3])};
     };

@@ -28,7 +28,7 @@ __device__ __forceinline__ int kswz(int row, int kc) {
 }
 
 template <int HD, bool GQA>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_body(AttnArgs a) {
     constexpr int KT_BYTES = BKV * HD * 2;
     constexpr int VT_BYTES = HD * VROW;
     constexpr int BUF = KT_BYTES + VT_BYTES;
@@ -232,6 +232,13 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
         }
         *reinterpret_cast<uint4*>(d + (size_t)dd * dst_rs + t0 + tc * 8) = make_uint4(o[0], o[1], o[2], o[3]);
     }
+}
+
+// HD = 128 needs 238 VGPRs (two waves per SIMD); HD = 64 needs 140, and its loop is softmax-VALU heavy (32 exp2 per lane per
+// key tile against 16 MFMAs), so a third wave per SIMD gives the VALU and matrix pipes more independent work to overlap.
+template <int HD, bool GQA>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 3 : 2, HD == 64 ? 3 : 2))) void attn_kernel(AttnArgs a) {
+    attn_body<HD, GQA>(a);
 }
 
 template <int HD, bool GQA>

@@ -109,3 +109,24 @@ def test_compat_aliases():
     from Trace.trace.constants import DEFAULT_MMODAL_TOKEN, MMODAL_TOKEN_INDEX  # noqa: F401
     from Trace.trace.mm_utils import get_model_name_from_path, tokenizer_MMODAL_token_all, process_video, KeywordsStoppingCriteria  # noqa: F401
     assert MMODAL_TOKEN_INDEX["SYNC"] == -205
+
+
+def test_bench_dvc_schedule_walks_the_heads():
+    """bench.py's forced feed schedule: per event 14 time-head, 4 score-head and 33 text-head steps, every fed
+    token inside the vocabulary range of the head that is active when it is produced (trace_mistral.py:86-88,244-252)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from oracle import trace_oracle as O
+    from trace_amd import config as tcfg
+    cfg = tcfg.trace_7b(128)
+    ids = bench.dvc_schedule(cfg, 256, seed=3)
+    assert len(ids) == 256
+    head, counts = 1, {0: 0, 1: 0, 2: 0}
+    for t in ids:
+        lo, hi = O.head_range(cfg, head)
+        assert lo <= t < hi, (t, head)
+        counts[head] += 1
+        head = O.swap_head(cfg, t, head)
+    assert counts[1] == 14 * 5 + 1 and counts[2] == 4 * 5 and counts[0] == 33 * 5, counts

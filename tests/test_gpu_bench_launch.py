@@ -27,3 +27,28 @@ def test_bench_tiny_under_torchrun():
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["unit"] == "videos/s" and d["scaling"] == "weak"
     assert d["config"]["videos_per_step_per_gpu"] == 3
     assert "roofline" in d and "cpu_baseline" in d
+
+
+def test_evaluate_driver_under_torchrun(tmp_path):
+    """python -m trace_amd.evaluate under torch.distributed.run: sharding, device preprocessing, batched decode, the RCCL
+    gather of packed ids and the parser, end to end on a synthetic tiny checkpoint and .npy frame files."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from trace_amd import config as tcfg
+    from trace_amd.model.builder import save_synthetic_checkpoint
+    ckpt = save_synthetic_checkpoint(str(tmp_path / "trace-tiny"), tcfg.tiny(num_frames=4))
+    items = []
+    for i in range(3):
+        f = str(tmp_path / f"v{i}.npy")
+        np.save(f, np.random.RandomState(i).randint(0, 255, size=(24, 40, 56, 3), dtype=np.uint8))
+        items.append({"id": i, "video": f, "fps": 8.0})
+    (tmp_path / "items.json").write_text(json.dumps(items))
+    env = dict(os.environ, TRACE_FORCE_PG="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", "-m", "trace_amd.evaluate", "--model", ckpt, "--items", str(tmp_path / "items.json"),
+           "--out", str(tmp_path / "out.json"), "--num-frames", "4", "--max-new-tokens", "8", "--batch-size", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads((tmp_path / "out.json").read_text())
+    assert [x["id"] for x in res] == [0, 1, 2] and all(1 <= len(x["output_ids"]) <= 8 for x in res)
+    assert all(x["video"].endswith(".npy") for x in res)

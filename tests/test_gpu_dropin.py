@@ -132,3 +132,39 @@ def test_batched_generate_and_device_preprocess(loaded):
     kw["modal_list"] = ["video"]
     od = model.generate(ids.unsqueeze(0), images_or_videos=[dev], video_timestamps=[ts_d], heads=[1], **kw)
     assert od.tolist() == o1.tolist()
+
+
+def test_evaluate_videos_equals_the_driver_loop(loaded):
+    """trace_amd.evaluate.evaluate_videos (batched, device preprocessing) returns, per video and in input order, exactly
+    what the reference's one-video-at-a-time loop (evaluate.py:298-417) produces through model.generate + its parser."""
+    from trace_amd import evaluate as ev
+    cfg, tok, model, proc, _ = loaded
+    rng = np.random.RandomState(11)
+    items = [{"id": f"v{i}", "video": rng.randint(0, 255, size=(30, 48, 64 if i != 2 else 40, 3), dtype=np.uint8), "fps": 10.0}
+             for i in range(3)]
+    prompt = "find events"
+
+    orig = ev.build_prompt_ids
+
+    def short_ids(q):                      # the byte-level stand-in tokenizer makes the llama_2 system prompt very long
+        ids = orig(q, tok)
+        vp = int(torch.nonzero(ids == -201)[0])
+        return torch.cat([ids[:1], ids[vp - 20: vp + 20], ids[-3:]])
+    ev.build_prompt_ids = lambda q, t, conv_mode="llama_2": short_ids(q)
+    try:
+        res = ev.evaluate_videos(model, tok, proc, items, prompt, num_frames=4, max_new_tokens=10, batch_size=2)
+    finally:
+        ev.build_prompt_ids = orig
+    assert [r["id"] for r in res] == ["v0", "v1", "v2"]
+    for it, r in zip(items, res):
+        tensor, ts = process_video(it["video"], proc, "pad", 4, fps=it["fps"])
+        out = model.generate(short_ids(prompt).unsqueeze(0), images_or_videos=[tensor], modal_list=["video"], do_sample=False,
+                             max_new_tokens=10, use_cache=True, pad_token_id=tok.eos_token_id, video_timestamps=[ts], heads=[1])
+        n = len(r["output_ids"])
+        assert out[0, :n].tolist() == r["output_ids"]
+        try:
+            ref = ev.parse_output_ids(out[0, :n].tolist(), tok, model, ev.stop_string())
+        except ValueError:             # random weights can emit malformed numbers; the batched driver records that as an error
+            assert "error" in r
+            continue
+        assert (r["timestamps"], r["scores"], r["captions"]) == (ref["timestamps"], ref["scores"], ref["captions"])

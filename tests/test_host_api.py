@@ -130,3 +130,33 @@ def test_bench_dvc_schedule_walks_the_heads():
         counts[head] += 1
         head = O.swap_head(cfg, t, head)
     assert counts[1] == 14 * 5 + 1 and counts[2] == 4 * 5 and counts[0] == 33 * 5, counts
+
+
+def test_evaluate_parser_and_prompt():
+    """trace_amd.evaluate: the drivers' id-stream parser (evaluate.py:360-411) against the oracle's restatement on a stream
+    that visits all three heads, and the prompt builder against the captured llama_2 + <sync> placeholder layout."""
+    from types import SimpleNamespace
+    from oracle import trace_oracle as O
+    from trace_amd import config as tcfg, evaluate as ev
+    from trace_amd.model.encoders import NumberTokenizer
+    cfg = tcfg.trace_7b(8)
+    V, Tv = cfg.vocab_size, cfg.time_vocab_size
+    meta = SimpleNamespace(time_tokenizer=NumberTokenizer(), score_tokenizer=NumberTokenizer())
+    model = SimpleNamespace(config=cfg, get_model=lambda: meta)
+    tok = SimpleNamespace(decode=lambda ids, skip_special_tokens=True: " ".join(str(i) for i in ids))
+    t = lambda s: [V + 1 + O.NUM_VOCAB[ch] for ch in s]
+    sc = lambda s: [V + Tv + 1 + O.NUM_VOCAB[ch] for ch in s]
+    ids = (t("0012.5") + [V + 2] + t("0030.0") + [V + 1] + sc("4.5") + [V + Tv + 1] + [11, 12, 13, V]
+           + t("0040.0") + [V + 2] + t("0055.5") + [V + 1] + sc("3.0") + [V + Tv + 1] + [21, 22])
+    got = ev.parse_output_ids(ids, tok, model)
+    ref = O.parse_output_ids(cfg, ids)
+    assert got["timestamps"] == ref["timestamps"] == [[12.5, 30.0], [40.0, 55.5]]
+    assert got["scores"] == ref["scores"] == [[4.5], [3.0]]
+    assert got["captions"] == ["11 12 13", "21 22"] and ref["captions"][0] == [11, 12, 13]
+    # stop string inside a flushed caption ends the parse (evaluate.py:380-381)
+    tok2 = SimpleNamespace(decode=lambda ids, skip_special_tokens=True: "done </s>")
+    assert ev.parse_output_ids([5, V, 6, V], tok2, model, stop_str="</s>")["captions"] == ["done </s>"]
+    # prompt: BOS ... <video> ... <sync> last
+    from trace_amd.model.builder import ByteTokenizer
+    p = ev.build_prompt_ids("find events", ByteTokenizer(cfg.vocab_size))
+    assert int((p == -201).sum()) == 1 and int(p[-1]) == -205 and ev.stop_string() == "</s>"

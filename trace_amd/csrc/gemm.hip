@@ -296,8 +296,11 @@ int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
     {
         int v = g_gemm_variant;
         if (v == 0) {
+            // 256^2 tiles (one workgroup per CU) when they fill whole rounds of the 256 CUs reasonably well; otherwise the
+            // 128^2 kernel (two workgroups per CU) — e.g. the paired-prefill qkv GEMM, 384 tiles = 1.5 rounds: 233 vs 193 us
             const long blocks256 = (long)((p.M + 255) / 256) * (p.N / 256);
-            v = (p.N % 256 == 0 && p.M >= 1024 && blocks256 >= 200) ? 3 : 2;
+            const long rounds = (blocks256 + 255) / 256;
+            v = (p.N % 256 == 0 && p.M >= 1024 && blocks256 >= 200 && blocks256 * 5 >= rounds * 256 * 4) ? 3 : 2;
         }
         if (v == 3 && p.N % 256 == 0) return launch_glds<256, 256, 2, 4>(p, epi, s);
     }

@@ -199,7 +199,9 @@ def main():
         line["roofline_hbm"] = {"bound": "hbm", "kernel": "skinny_lds_kernel<EPI_PARTIAL,NB,NT=2> (decode gate|up GEMV, 1 bracketed launch per decode step)",
                                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
                                 "traffic": traffic, "algorithmic_bytes_per_launch": k_bytes, "avg_launch_ms": k_ms, "samples": k_n}
-        if not args.no_cpu_baseline and not args.tiny:
+        if world > 1:
+            line["cpu_baseline"] = None            # timed on rank 0 of the single-GPU run only
+        elif not args.no_cpu_baseline and not args.tiny:
             try:
                 cores = len(os.sched_getaffinity(0))
             except AttributeError:

@@ -156,6 +156,10 @@ def main():
         eng.encode_video(videos[b], ts[b]); eng.prefill(b, eng.splice(ids))
     eng.decode_begin(list(range(B)), heads, n_new, -1, forced)
     t_dec = ev_time(lambda: eng.decode_steps(n_new - 1, use_graph=args.graph))
+    # the drivers' shape of use: ONE video, batch 1, end to end (latency, not part of `value`)
+    one = lambda: eng.generate(videos[:1], ts[:1], prompt[:1], heads[:1], n_new, eos=-1, use_graph=True, forced=forced[:1])
+    one()                                            # captures the batch-1 decode graph
+    t_one = ev_time(one)
 
     if rank == 0:
         vps = world * B * args.steps / dt
@@ -187,6 +191,7 @@ def main():
             "decode_tok_s": world * B * (n_new - 1) / (t_dec * 1e-3),
             "stages_ms": {"vit_slotpool_per_video": t_enc, "prefill_per_video": t_pre, f"decode_{n_new - 1}_steps_batch{B}": t_dec,
                           "decode_ms_per_step": t_dec / (n_new - 1), "weights_load_s": t_load},
+            "single_video_latency_ms": t_one,
             "mfma_util": {"vit": vit_flops / (t_enc * 1e-3) / 2.5e15, "prefill": pre_flops / (t_pre * 1e-3) / 2.5e15},
             # dominant kernel of the run: the 256x256 MFMA GEMM (its four epilogue variants are ~47 % of GPU time; the probe
             # brackets its largest instance, the ViT fc1 projection, once per video inside the timed region)

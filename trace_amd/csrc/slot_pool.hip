@@ -6,8 +6,8 @@
 // HBM-bound (one read of the 576x1024 frame features); one workgroup per frame, one wave per patch row.
 // Pass 1 computes LN statistics + logits (slot matrix in LDS in lane-major order: conflict-free b128 reads),
 // the 576-way softmax runs on the LDS logits, pass 2 re-reads the (L2-resident) row, re-applies LN+RoPE from
-// the saved statistics and accumulates the 8 x 1024 weighted sums in registers; waves combine through LDS
-// float atomics.  All arithmetic fp32; output bf16 [T*S, D], consumed by the readout GEMM.
+// the saved statistics and accumulates the 8 x 1024 weighted sums in registers; the waves add them into LDS one
+// after the other (fixed order: bit-reproducible).  All arithmetic fp32; output bf16 [T*S, D], consumed by the readout GEMM.
 #include "common.h"
 #include "kernels.h"
 
@@ -160,15 +160,21 @@ __global__ __launch_bounds__(256) void slot_pool_kernel(const bf16_t* __restrict
                 for (int k = 0; k < NS; ++k) { a1[k][e] += pr[k] * r1; a2[k][e] += pr[k] * r2; }
             }
         }
-#pragma unroll
-        for (int k = 0; k < NS; ++k)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                atomicAdd(&s_res[k * D + lane * 8 + e], a1[k][e]);
-                atomicAdd(&s_res[k * D + H2 + lane * 8 + e], a2[k][e]);
-            }
     }
-    __syncthreads();
+    // the four waves add their partial sums one after the other (LDS float atomics would add them in arrival order: the
+    // result then differs in the last bit from run to run, which 32 decoder layers amplify to 0.2 in the prefill hidden state)
+    for (int w = 0; w < 4; ++w) {
+        if (on && wid == w) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s_res[k * D + lane * 8 + e] += a1[k][e];
+                    s_res[k * D + H2 + lane * 8 + e] += a2[k][e];
+                }
+        }
+        __syncthreads();
+    }
     bf16_t* out = res + (size_t)t * NS * D;
     for (int i = tid; i < NS * D / 2; i += 256) {
         const float2 v = *reinterpret_cast<const float2*>(s_res + 2 * i);

@@ -106,3 +106,32 @@ def test_bit_reproducible(big):
         lg.append(torch.stack(steps))
     assert torch.equal(hid[0], hid[1])
     assert torch.equal(lg[0], lg[1])
+
+
+def test_batch_40_equals_singles():
+    """40 different videos decoded together (four 16-row MFMA groups, K cut in 4-16 chunks of partial rows, second head pass,
+    paired prefill) vs three of them decoded alone: step-0 logits within the bf16 budget, greedy ids equal up to the first
+    near-tie (the k-chunk partition, hence the fp32 rounding, depends on the batch size)."""
+    cfg = tcfg.trace_7b(128)
+    ids = synth.synth_prompt_ids(cfg, n_text=176, video_pos=150).tolist()
+    L = 176 - 1 + 128 * cfg.tokens_per_frame
+    nb, n_new = 40, 16
+    eng = TraceEngine(cfg, max_batch=nb, max_ctx=(L + n_new + 63) // 64 * 64, max_frames=128, max_new_tokens=n_new)
+    eng.load_weights(synth.iter_weights(cfg, device="cuda:0"))
+    ts = [[float(i)] for i in range(128)]
+    vids = [synth.synth_frames(cfg, 100 + b, num_frames=128).to(torch.bfloat16).cuda() for b in range(nb)]
+    out, _ = eng.generate(vids, [ts] * nb, [ids] * nb, [1] * nb, n_new, eos=-1)
+    # step-0 logits of the whole batch (all slots are still prefilled)
+    lgb = eng.decode_begin(list(range(nb)), [1] * nb, n_new, eos=-1, want_logits=True).float().cpu()
+    for b in (0, 17, 39):
+        eng.encode_video(vids[b], ts)
+        eng.prefill(0, eng.splice(ids))
+        lg1 = eng.decode_begin([0], [1], n_new, eos=-1, want_logits=True).float().cpu()[0]
+        fin = torch.isfinite(lg1)
+        assert torch.equal(torch.isfinite(lgb[b]), fin)
+        if b != 0:           # slot 0 was just overwritten by this video's prefill; the batch logits of slot 0 were read before
+            assert (lgb[b][fin] - lg1[fin]).abs().max().item() < LOGIT_TOL
+        single, _ = eng.generate([vids[b]], [ts], [ids], [1], n_new, eos=-1)
+        first_diff = next((i for i, (x, y) in enumerate(zip(out[b], single[0])) if x != y), n_new)
+        assert first_diff >= 6, (b, first_diff, out[b], single[0])
+    eng.close()

@@ -129,6 +129,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     if (c->HD != 128 || c->NQ != 4 * c->NKV) return bad("LLM kernels need head_dim 128 and 4:1 GQA");
     if (c->vh / c->vheads != 64) return bad("ViT kernels need head_dim 64");
     if (c->H % 128 || c->I % 128 || c->vh % 128 || c->vi % 128 || c->QKV % 128) return bad("dims must be multiples of 128");
+    if (c->H > 4096) return bad("hidden_size > 4096: the decode row kernels (norms, residual add) hold one 4096-wide row per workgroup");
     c->stc = cfg->projector_type == 1;
     if (!c->stc && (c->S != 8 || c->vh > 1024)) return bad("slot pool kernel needs 8 slots and mm_hidden <= 1024");
     if (c->max_B < 1 || c->max_B > 64) return bad("max_batch (KV slots) must be in [1,64]");
@@ -139,7 +140,6 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
         if (cfg->max_frames < 1 || vis_rows > c->max_ctx) return bad("visual tokens of max_frames exceed max_ctx");
         if (c->stc && cfg->max_frames > 32) return bad("STC connector path supports at most 32 frames");
     }
-    if (c->Tv != 13 || c->Sv != 13) { /* any size works; kept for clarity */ }
 
     const size_t H = c->H, I = c->I, vh = c->vh, vi = c->vi;
     int rc = TRACE_OK;

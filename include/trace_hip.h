@@ -34,7 +34,7 @@ typedef struct trace_config {
     float slot_eps, slot_rope_base;
     int32_t max_frames;      /* largest T per video                                    */
     int32_t max_ctx;         /* KV-cache length per sequence slot (prefill + new tokens) */
-    int32_t max_batch;       /* KV-cache sequence slots, <= 64 (at most 32 decode together) */
+    int32_t max_batch;       /* KV-cache sequence slots = largest decode batch, <= 64      */
     int32_t max_new_tokens;  /* capacity of the on-device output id buffer               */
     int32_t projector_type;  /* 0 = spatial_slot (TRACE), 1 = stc_connector (legacy API) */
 } trace_config;

@@ -132,10 +132,15 @@ def main():
     eng.set_profile(2)
     tdist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
+    outs = []
     for _ in range(args.steps):
-        out = step()
+        outs.append(step())
     tdist.barrier(); torch.cuda.synchronize()
     dt = tdist.max_over_ranks(time.perf_counter() - t0)
+    out = outs[-1]
+    # every step runs the same inputs through a path whose reductions all have a fixed order: the ids must repeat exactly
+    if any(o != outs[0] for o in outs[1:]):
+        raise SystemExit("bench: output ids differ between identical steps (a race or an unordered reduction)")
     prof = eng.get_profile()
     eng.set_profile(0)
 

@@ -115,7 +115,7 @@ def main():
     torch.cuda.synchronize()
     t_load = time.perf_counter() - t0
     # inputs resident in HBM before the timed region
-    videos = [synth.synth_frames(cfg, rank * B + b, num_frames=args.frames).to(torch.bfloat16).to(dev) for b in range(B)]
+    videos = [synth.synth_frames(cfg, rank * B + b, num_frames=args.frames, dtype=torch.bfloat16, device=dev) for b in range(B)]
     ts = [[[float(i)] for i in range(args.frames)] for _ in range(B)]
     prompt = [ids] * B
     heads = [1] * B

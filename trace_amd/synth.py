@@ -159,13 +159,15 @@ def state_dict(cfg: TraceConfig, dtype=torch.bfloat16, base_seed: int = BASE_SEE
 
 
 def synth_frames(cfg: TraceConfig, video_idx: int = 0, num_frames: int | None = None,
-                 dtype=torch.float32) -> torch.Tensor:
-    """[T,3,S,S] N(0,1) frames: post-CLIP-normalisation statistics."""
+                 dtype=torch.float32, device="cpu") -> torch.Tensor:
+    """[T,3,S,S] N(0,1) frames: post-CLIP-normalisation statistics.  device="cpu" is the canonical
+    stream (parity tests, goldens); a CUDA device draws from the device generator instead (benchmarks: 64 clips per
+    rank would otherwise cost ~20 s of host RNG per rank)."""
     T = num_frames or cfg.num_frames
-    g = torch.Generator(device="cpu")
+    g = torch.Generator(device=device)
     g.manual_seed(42 + video_idx)
     S = cfg.vision_image_size
-    return torch.randn((T, 3, S, S), generator=g, dtype=torch.float32).to(dtype)
+    return torch.randn((T, 3, S, S), generator=g, dtype=torch.float32, device=device).to(dtype)
 
 
 def synth_prompt_ids(cfg: TraceConfig, n_text: int = 176, video_pos: int = 150, seed: int = 7) -> torch.Tensor:

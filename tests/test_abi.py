@@ -50,3 +50,18 @@ def test_engine_fails_loudly_without_gpu():
     from trace_amd._lib import TraceHipError
     with pytest.raises(TraceHipError, match="no CPU fallback"):
         TraceEngine(tcfg.tiny())
+
+
+def test_header_is_plain_c_and_example_links(tmp_path):
+    """include/trace_hip.h is consumed by a C compiler (gcc, not hipcc / C++), and the plain-C example client links against the
+    library: the boundary really is a C ABI."""
+    import shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("needs gcc and the ROCm headers")
+    exe = str(tmp_path / "preprocess_demo")
+    cmd = ["gcc", "-O1", "-std=c99", "-Wall", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+           os.path.join(root, "examples", "preprocess_demo.c"), "-L", os.path.join(root, "trace_amd"), "-ltrace_hip",
+           "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + os.path.join(root, "trace_amd"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]

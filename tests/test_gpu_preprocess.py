@@ -62,3 +62,31 @@ def test_process_video_device_path(eng56):
     dev, ts_d = mm_utils.process_video(raw, proc, aspect_ratio="pad", num_frames=4, fps=5.0, engine=eng56)
     assert ts_h == ts_d and dev.is_cuda and dev.dtype == torch.bfloat16
     assert torch.equal(dev.cpu(), host.to(torch.bfloat16))
+
+
+def test_plain_c_client_matches_python(eng56, tmp_path):
+    """examples/preprocess_demo.c (gcc, no Python, no torch) calls trace_preprocess_frames through the C ABI; its output
+    checksum equals the one computed from the Python path on the same pixels."""
+    import shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    exe = str(tmp_path / "preprocess_demo")
+    r = subprocess.run(["gcc", "-O1", "-std=c99", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                        os.path.join(root, "examples", "preprocess_demo.c"), "-L", os.path.join(root, "trace_amd"), "-ltrace_hip",
+                        "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + os.path.join(root, "trace_amd"), "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    T, H, W = 3, 70, 120
+    run = subprocess.run([exe, str(T), str(H), str(W)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    line = [l for l in run.stdout.splitlines() if "checksum" in l][0]
+    c_sum = int(line.split()[-1])
+    i = np.arange(T * H * W * 3, dtype=np.uint64)
+    frames = (((i * np.uint64(2654435761)) >> np.uint64(24)) & np.uint64(0xFF)).astype(np.uint8).reshape(T, H, W, 3)
+    out = eng56.preprocess_frames(frames, pad=True).cpu().view(torch.int16).numpy().astype(np.uint16).reshape(-1)
+    s = 0
+    for v in out.tolist():
+        s = (s * 1000003 + v) & 0xFFFFFFFFFFFFFFFF
+    assert s == c_sum
+    assert "error path" in run.stdout

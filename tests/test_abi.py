@@ -52,7 +52,7 @@ def test_engine_fails_loudly_without_gpu():
         TraceEngine(tcfg.tiny())
 
 
-def test_header_is_plain_c_and_example_links(tmp_path):
+def test_header_is_plain_c_and_example_links(lib, tmp_path):
     """include/trace_hip.h is consumed by a C compiler (gcc, not hipcc / C++), and the plain-C example client links against the
     library: the boundary really is a C ABI."""
     import shutil, subprocess

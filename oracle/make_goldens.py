@@ -293,6 +293,29 @@ def int_goldens():
     print("host_functions.json written:", list(G.keys()))
 
 
+def medium_goldens(tmp):
+    """Real CLIP-ViT-L/14-336 geometry (hidden 1024, 24 layers, 16 heads, 577 tokens) for ONE frame through the reference's
+    own vision tower + SpatialSlotPool: pins the 577-token attention, the 23-layer depth and quick-GELU at the
+    size the product runs.  Stored as float16 to keep the fixture near 1 MB (values are O(1))."""
+    import dataclasses
+    from trace_amd import config as tcfg, synth
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=1), vision_hidden_size=1024, vision_intermediate_size=4096, vision_num_layers=24,
+                              vision_num_heads=16, vision_image_size=336, vision_patch_size=14, mm_hidden_size=1024)
+    model = build_reference_model(cfg, os.path.join(tmp, "medium"))
+    load_synth(model, cfg)
+    frames = synth.synth_frames(cfg, 7, num_frames=1).to(torch.bfloat16).float()
+    with torch.no_grad():
+        vt = model.get_model().get_vision_tower()
+        feats = vt(frames)                                           # [1,576,1024]  clip_encoder.py:41-53
+        slots = model.get_model().mm_projector(feats[None])          # [1,1,8,4096]
+        clip_hs = vt.vision_tower(frames, output_hidden_states=True).hidden_states
+        assert len(clip_hs) == 25 and torch.equal(clip_hs[-2][:, 1:], feats)
+    np.savez_compressed(os.path.join(OUT, "medium_vit.npz"), vit_feats=feats[0].numpy().astype(np.float16),
+                        slots=slots[0, 0].numpy().astype(np.float32),
+                        feat_abs_mean=np.array(feats.abs().mean().item()), video_idx=np.array(7))
+    print("medium_vit: feats", tuple(feats.shape), "abs mean %.4f max %.3f" % (feats.abs().mean().item(), feats.abs().max().item()))
+
+
 def preprocess_goldens():
     """Frame preprocessing of process_video (mm_utils.py:456-462): the reference's own expand2square + the HF
     CLIPImageProcessor it delegates to (PIL backend), on small synthetic frames, 'pad' and plain modes.  The processor is
@@ -326,6 +349,10 @@ if __name__ == "__main__":
     if "--preprocess-only" in sys.argv:
         preprocess_goldens()
         sys.exit(0)
+    if "--medium-only" in sys.argv:
+        medium_goldens(tmp)
+        sys.exit(0)
     int_goldens()
     fp_goldens(tmp)
+    medium_goldens(tmp)
     preprocess_goldens()

@@ -245,3 +245,39 @@ def test_ragged_batch_and_context_limits(setup):
     with pytest.raises(TraceHipError, match="exceeds max_ctx"):
         small.decode_begin([0], [1], 9, eos=-1)
     small.close()
+
+
+def test_vit_large_geometry_vs_reference_fixture(golden_dir):
+    """The real CLIP-ViT-L/14-336 geometry (1024 wide, 23 of 24 layers, 16 heads, 577 tokens) for one frame: HIP ViT + slot
+    pool against the fixture captured from the reference's own vision tower + SpatialSlotPool (tests/golden/medium_vit.npz)
+    and against the bf16-emulating oracle.  Features are O(2) (max 12.7); 46 bf16-rounded residual updates put the HIP path
+    within 0.5 abs / 2 % mean (relative L2 < 2 %) of the fp32 reference."""
+    import dataclasses
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=1), vision_hidden_size=1024, vision_intermediate_size=4096, vision_num_layers=24,
+                              vision_num_heads=16, vision_image_size=336, vision_patch_size=14, mm_hidden_size=1024)
+    M = np.load(os.path.join(golden_dir, "medium_vit.npz"))
+    sd = synth.state_dict(cfg)
+    eng = TraceEngine(cfg, max_batch=1, max_ctx=256, max_frames=1, max_new_tokens=8)
+    eng.load_weights(sd.items())
+    frames = synth.synth_frames(cfg, int(M["video_idx"]), num_frames=1).to(torch.bfloat16)
+    feats = eng.vit_forward(frames).float().cpu()[0]
+    ref = torch.from_numpy(M["vit_feats"].astype(np.float32))
+    err = (feats - ref).abs()
+    assert torch.isfinite(feats).all()
+    print("vs fp32 reference: max", err.max().item(), "mean", err.mean().item(), "ref abs mean", ref.abs().mean().item())
+    assert err.max().item() < 0.5 and err.mean().item() < 0.02 * ref.abs().mean().item(), (err.max().item(), err.mean().item())
+    ora = O.Oracle(cfg, {k: v for k, v in sd.items() if "vision_tower" in k or "mm_projector" in k}, emulate_bf16=True)
+    of = ora.vit_forward(frames.float())
+    e2 = (feats - of.reshape(ref.shape)).abs()
+    print("vs bf16 oracle: max", e2.max().item(), "mean", e2.mean().item())
+    # two bf16 implementations that sum in different orders round differently at every layer: after 23 layers they are as far
+    # from each other as from the fp32 reference (measured: mean 0.025 = 1.2 %, max 0.25-0.32), so the same budget applies
+    assert e2.max().item() < 0.5 and e2.mean().item() < 0.02 * ref.abs().mean().item(), (e2.max().item(), e2.mean().item())
+    rel_l2 = (feats - ref).norm().item() / ref.norm().item()
+    assert rel_l2 < 0.02, rel_l2
+    slots = eng.slot_pool(None, 1).float().cpu()[0]
+    rs = torch.from_numpy(M["slots"])
+    es = (slots - rs).abs()
+    print("slots: max err", es.max().item(), "ref max", rs.abs().max().item())
+    assert es.max().item() < 0.05 * max(1.0, rs.abs().max().item()), (es.max().item(), rs.abs().max().item())
+    eng.close()

@@ -145,3 +145,30 @@ def test_pillow_resize_restatement_is_pillow():
         img = rng.randint(0, 256, size=(H, W, 3), dtype=np.uint8)
         ref = np.asarray(Image.fromarray(img).resize((ow, oh), resample=Image.BICUBIC))
         assert np.array_equal(O.pillow_resize(img, ow, oh), ref), (H, W, oh, ow)
+
+
+def _medium_cfg():
+    import dataclasses
+    return dataclasses.replace(tcfg.tiny(num_frames=1), vision_hidden_size=1024, vision_intermediate_size=4096, vision_num_layers=24,
+                               vision_num_heads=16, vision_image_size=336, vision_patch_size=14, mm_hidden_size=1024)
+
+
+def test_medium_vit_matches_reference_fixture(golden_dir):
+    """Real CLIP-ViT-L/14-336 geometry, one frame: the oracle's ViT (23 of 24 layers, CLS dropped) and slot pool against the
+    reference's own vision tower + SpatialSlotPool (fixture stored as float16: 1e-3 relative)."""
+    cfg = _medium_cfg()
+    M = np.load(os.path.join(golden_dir, "medium_vit.npz"))
+    sd = {n: synth.synth_tensor(n, shp, kind, torch.bfloat16).float() for n, shp, kind in synth.weight_specs(cfg)
+          if "vision_tower" in n or "mm_projector" in n}          # the fixture generator loads the bf16-rounded weights too
+    ora = O.Oracle(cfg, sd, emulate_bf16=False)
+    frames = synth.synth_frames(cfg, int(M["video_idx"]), num_frames=1).to(torch.bfloat16).float()
+    with torch.no_grad():
+        feats = ora.vit_forward(frames)
+        slots = ora.slot_pool(feats)
+    ref = torch.from_numpy(M["vit_feats"].astype(np.float32))
+    assert feats.shape[-2:] == ref.shape
+    err = (feats.reshape(ref.shape) - ref).abs()
+    assert err.max().item() < 2e-2 and err.mean().item() < 2e-3, (err.max().item(), err.mean().item())
+    rs = torch.from_numpy(M["slots"])
+    es = (slots.reshape(rs.shape) - rs).abs()
+    assert es.max().item() < 5e-3 * max(1.0, rs.abs().max().item()), es.max().item()

@@ -316,6 +316,26 @@ def medium_goldens(tmp):
     print("medium_vit: feats", tuple(feats.shape), "abs mean %.4f max %.3f" % (feats.abs().mean().item(), feats.abs().max().item()))
 
 
+def medium_llm_goldens(tmp):
+    """One decoder layer at the REAL Mistral-7B widths (hidden 4096, intermediate 14336, 32/8 heads x 128) behind the tiny ViT:
+    teacher-forced logits of the reference over a stream that visits all three heads.  Pins the K = 14336 down-projection
+    (the decode GEMV's many-chunk partial rows) and the 28672-wide gate|up product against the reference itself."""
+    import dataclasses
+    from trace_amd import config as tcfg, synth
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336, num_hidden_layers=1)
+    model = build_reference_model(cfg, os.path.join(tmp, "medllm"))
+    load_synth(model, cfg)
+    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16).float()
+    ts = [[float(i) * 2.5] for i in range(cfg.num_frames)]
+    input_ids = synth.synth_prompt_ids(cfg, n_text=24, video_pos=10)
+    forced = scripted_ids(cfg)
+    tf_logits, tf_argmax, L = run_reference(model, cfg, input_ids, frames, ts, forced=forced)
+    np.savez_compressed(os.path.join(OUT, "medium_llm.npz"), input_ids=input_ids.numpy(), timestamps=np.array(ts, dtype=np.float64),
+                        forced_ids=np.array(forced), tf_logits=tf_logits.numpy().astype(np.float32), tf_argmax=np.array(tf_argmax),
+                        prefill_len=np.array(L))
+    print("medium_llm: L=%d steps=%d" % (L, len(tf_argmax)))
+
+
 def preprocess_goldens():
     """Frame preprocessing of process_video (mm_utils.py:456-462): the reference's own expand2square + the HF
     CLIPImageProcessor it delegates to (PIL backend), on small synthetic frames, 'pad' and plain modes.  The processor is
@@ -352,7 +372,11 @@ if __name__ == "__main__":
     if "--medium-only" in sys.argv:
         medium_goldens(tmp)
         sys.exit(0)
+    if "--medium-llm-only" in sys.argv:
+        medium_llm_goldens(tmp)
+        sys.exit(0)
     int_goldens()
     fp_goldens(tmp)
     medium_goldens(tmp)
+    medium_llm_goldens(tmp)
     preprocess_goldens()

@@ -281,3 +281,37 @@ def test_vit_large_geometry_vs_reference_fixture(golden_dir):
     print("slots: max err", es.max().item(), "ref max", rs.abs().max().item())
     assert es.max().item() < 0.05 * max(1.0, rs.abs().max().item()), (es.max().item(), rs.abs().max().item())
     eng.close()
+
+
+def test_real_width_decoder_layer_vs_reference_fixture(golden_dir):
+    """One decoder layer at the real Mistral-7B widths (hidden 4096, intermediate 14336): teacher-forced decode through the
+    HIP path (K = 14336 down-projection in 4-16 chunks of partial rows, 28672-wide gate|up) against logits captured from the
+    reference (tests/golden/medium_llm.npz) — alone (B = 1) and inside batches of 20 and 40 copies (two and four MFMA row groups)."""
+    import dataclasses
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336, num_hidden_layers=1)
+    M = np.load(os.path.join(golden_dir, "medium_llm.npz"))
+    eng = TraceEngine(cfg, max_batch=40, max_ctx=192, max_frames=4, max_new_tokens=64)
+    eng.load_weights(synth.state_dict(cfg).items())
+    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16)
+    forced, ref_lg, ref_ids = M["forced_ids"].tolist(), torch.from_numpy(M["tf_logits"]), M["tf_argmax"].tolist()
+    n = len(forced) + 1
+    fin = torch.isfinite(ref_lg)
+    srt = torch.sort(torch.where(fin, ref_lg, torch.full_like(ref_lg, -1e30)), dim=-1, descending=True).values
+    margin = (srt[:, 0] - srt[:, 1]).tolist()
+    for nb in (1, 20, 40):
+        for b in range(nb):
+            eng.encode_video(frames, M["timestamps"].tolist())
+            eng.prefill(b, eng.splice(M["input_ids"].tolist()))
+        lgs = [eng.decode_begin(list(range(nb)), [1] * nb, n, eos=-1, forced=[forced] * nb, want_logits=True).float().cpu()]
+        for _ in range(n - 1):
+            lgs.append(eng.decode_steps(1, use_graph=False, want_logits=True).float().cpu())
+        ids, _ = eng.decode_read()
+        for b in (0, nb - 1):
+            lg = torch.stack([x[b] for x in lgs])
+            assert torch.equal(torch.isfinite(lg), fin)
+            err = (lg[fin] - ref_lg[fin]).abs().max().item()
+            assert err < LOGIT_TOL, (nb, b, err)
+            for i, (a, r, m) in enumerate(zip(ids[b], ref_ids, margin)):
+                if m > 2 * LOGIT_TOL:
+                    assert a == r, (nb, b, i, a, r, m)
+    eng.close()

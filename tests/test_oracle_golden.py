@@ -172,3 +172,18 @@ def test_medium_vit_matches_reference_fixture(golden_dir):
     rs = torch.from_numpy(M["slots"])
     es = (slots.reshape(rs.shape) - rs).abs()
     assert es.max().item() < 5e-3 * max(1.0, rs.abs().max().item()), es.max().item()
+
+
+def test_medium_llm_matches_reference_fixture(golden_dir):
+    """One decoder layer at the real Mistral-7B widths (intermediate 14336): oracle teacher-forced logits vs the reference's."""
+    import dataclasses
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336, num_hidden_layers=1)
+    M = np.load(os.path.join(golden_dir, "medium_llm.npz"))
+    sd = {k: v.float() for k, v in synth.state_dict(cfg).items()}
+    ora = O.Oracle(cfg, sd, emulate_bf16=False)
+    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16).float()
+    forced = M["forced_ids"].tolist()
+    ids, lg = ora.generate(torch.from_numpy(M["input_ids"]), frames, M["timestamps"].tolist(), head=1,
+                           max_new_tokens=len(forced) + 1, forced_ids=forced, return_logits=True)
+    assert ids == M["tf_argmax"].tolist()
+    _cmp_logits(lg.numpy(), M["tf_logits"])

@@ -336,6 +336,27 @@ def medium_llm_goldens(tmp):
     print("medium_llm: L=%d steps=%d" % (L, len(tf_argmax)))
 
 
+def long_ctx_goldens(tmp):
+    """The C2 context length against the reference: 128 (tiny-ViT) frames -> 1792 visual rows, a 176-id prompt -> prefill
+    L = 1967, one decoder layer at the real Mistral-7B widths, then teacher-forced decode (contexts 1968 ..).  Pins the causal
+    prefill attention, the 256x256-tile GEMMs at M ~ 2k and the decode attention over a 2k-token KV cache."""
+    import dataclasses
+    from trace_amd import config as tcfg, synth
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=128), intermediate_size=14336, num_hidden_layers=1)
+    model = build_reference_model(cfg, os.path.join(tmp, "longctx"))
+    load_synth(model, cfg)
+    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16).float()
+    ts = [[float(i)] for i in range(cfg.num_frames)]
+    input_ids = synth.synth_prompt_ids(cfg, n_text=176, video_pos=150)
+    forced = scripted_ids(cfg)[:24]
+    tf_logits, tf_argmax, L = run_reference(model, cfg, input_ids, frames, ts, forced=forced)
+    assert L == 1967, L
+    np.savez_compressed(os.path.join(OUT, "long_ctx.npz"), input_ids=input_ids.numpy(), timestamps=np.array(ts, dtype=np.float64),
+                        forced_ids=np.array(forced), tf_logits=tf_logits.numpy().astype(np.float32), tf_argmax=np.array(tf_argmax),
+                        prefill_len=np.array(L))
+    print("long_ctx: L=%d steps=%d" % (L, len(tf_argmax)))
+
+
 def preprocess_goldens():
     """Frame preprocessing of process_video (mm_utils.py:456-462): the reference's own expand2square + the HF
     CLIPImageProcessor it delegates to (PIL backend), on small synthetic frames, 'pad' and plain modes.  The processor is
@@ -375,8 +396,12 @@ if __name__ == "__main__":
     if "--medium-llm-only" in sys.argv:
         medium_llm_goldens(tmp)
         sys.exit(0)
+    if "--long-ctx-only" in sys.argv:
+        long_ctx_goldens(tmp)
+        sys.exit(0)
     int_goldens()
     fp_goldens(tmp)
     medium_goldens(tmp)
     medium_llm_goldens(tmp)
+    long_ctx_goldens(tmp)
     preprocess_goldens()

@@ -315,3 +315,38 @@ def test_real_width_decoder_layer_vs_reference_fixture(golden_dir):
                 if m > 2 * LOGIT_TOL:
                     assert a == r, (nb, b, i, a, r, m)
     eng.close()
+
+
+def test_c2_context_length_vs_reference_fixture(golden_dir):
+    """The C2 context: 128 frames -> prefill L = 1967, one real-width decoder layer, teacher-forced decode at contexts
+    1968.. against logits captured from the reference (tests/golden/long_ctx.npz).  Exercises the causal prefill attention
+    and the 256x256-tile GEMMs at M ~ 2k (single and paired prefill), and the decode attention over a 2k-token cache with
+    the split counts of batch 1 and batch 20."""
+    import dataclasses
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=128), intermediate_size=14336, num_hidden_layers=1)
+    M = np.load(os.path.join(golden_dir, "long_ctx.npz"))
+    eng = TraceEngine(cfg, max_batch=20, max_ctx=2048, max_frames=128, max_new_tokens=32)
+    eng.load_weights(synth.state_dict(cfg).items())
+    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16)
+    ts, ids = M["timestamps"].tolist(), M["input_ids"].tolist()
+    forced, ref_lg = M["forced_ids"].tolist(), torch.from_numpy(M["tf_logits"])
+    n = len(forced) + 1
+    fin = torch.isfinite(ref_lg)
+    for nb in (1, 20):
+        eng.encode_video(frames, ts)
+        L, emb = eng.splice(ids, want_output=True)
+        assert L == int(M["prefill_len"]) == 1967
+        if nb == 1:
+            eng.prefill(0, L)
+        else:
+            for b in range(0, nb, 2):
+                eng.prefill_pair(b, emb, emb)                      # paired prefill: M = 3934
+        lgs = [eng.decode_begin(list(range(nb)), [1] * nb, n, eos=-1, forced=[forced] * nb, want_logits=True).float().cpu()]
+        for _ in range(n - 1):
+            lgs.append(eng.decode_steps(1, use_graph=False, want_logits=True).float().cpu())
+        for b in (0, nb - 1):
+            lg = torch.stack([x[b] for x in lgs])
+            assert torch.equal(torch.isfinite(lg), fin)
+            err = (lg[fin] - ref_lg[fin]).abs().max().item()
+            assert err < LOGIT_TOL, (nb, b, err)
+    eng.close()

@@ -187,3 +187,18 @@ def test_medium_llm_matches_reference_fixture(golden_dir):
                            max_new_tokens=len(forced) + 1, forced_ids=forced, return_logits=True)
     assert ids == M["tf_argmax"].tolist()
     _cmp_logits(lg.numpy(), M["tf_logits"])
+
+
+def test_long_context_matches_reference_fixture(golden_dir):
+    """Prefill length 1967 (the C2 context) + teacher-forced decode, one real-width decoder layer: oracle vs the reference."""
+    import dataclasses
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=128), intermediate_size=14336, num_hidden_layers=1)
+    M = np.load(os.path.join(golden_dir, "long_ctx.npz"))
+    sd = {k: v.float() for k, v in synth.state_dict(cfg).items()}
+    ora = O.Oracle(cfg, sd, emulate_bf16=False)
+    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16).float()
+    forced = M["forced_ids"].tolist()
+    ids, lg = ora.generate(torch.from_numpy(M["input_ids"]), frames, M["timestamps"].tolist(), head=1,
+                           max_new_tokens=len(forced) + 1, forced_ids=forced, return_logits=True)
+    assert ids == M["tf_argmax"].tolist()
+    _cmp_logits(lg.numpy(), M["tf_logits"])

@@ -357,6 +357,33 @@ def long_ctx_goldens(tmp):
     print("long_ctx: L=%d steps=%d" % (L, len(tf_argmax)))
 
 
+def real_vocab_goldens(tmp):
+    """The real vocabulary (V = 32000 -> 32027 global ids: lm_head 32000 rows, <sync> 32000, time 32001..32013, score
+    32014..32026) on the tiny two-layer model: teacher-forced reference logits.  Full rows are 128 KB per step, so the fixture
+    keeps, per step, the top-2 (value, index), 96 fixed sampled columns and the -inf pattern boundaries."""
+    import dataclasses
+    from trace_amd import config as tcfg, synth
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), vocab_size=32000)
+    model = build_reference_model(cfg, os.path.join(tmp, "realvocab"))
+    load_synth(model, cfg)
+    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16).float()
+    ts = [[float(i) * 2.5] for i in range(cfg.num_frames)]
+    input_ids = synth.synth_prompt_ids(cfg, n_text=24, video_pos=10)
+    forced = scripted_ids(cfg)
+    forced = [t if t >= cfg.vocab_size else (t * 97 + 13) % cfg.vocab_size for t in forced]     # spread the text ids over the table
+    tf_logits, tf_argmax, L = run_reference(model, cfg, input_ids, frames, ts, forced=forced)
+    NV = tf_logits.shape[1]
+    cols = np.unique(np.concatenate([np.random.RandomState(3).randint(0, NV, size=80), np.arange(NV - 28, NV), [0, 1, 31999]]))
+    fin = torch.isfinite(tf_logits)
+    masked = torch.where(fin, tf_logits, torch.full_like(tf_logits, -1e30))
+    top = torch.topk(masked, 2, dim=-1)
+    np.savez_compressed(os.path.join(OUT, "real_vocab.npz"), input_ids=input_ids.numpy(), timestamps=np.array(ts, dtype=np.float64),
+                        forced_ids=np.array(forced), tf_argmax=np.array(tf_argmax), cols=cols,
+                        sampled=tf_logits[:, cols].numpy().astype(np.float32), top_val=top.values.numpy().astype(np.float32),
+                        top_idx=top.indices.numpy(), finite_count=fin.sum(-1).numpy(), prefill_len=np.array(L))
+    print("real_vocab: NV=%d steps=%d finite counts %s" % (NV, len(tf_argmax), sorted(set(fin.sum(-1).tolist()))))
+
+
 def preprocess_goldens():
     """Frame preprocessing of process_video (mm_utils.py:456-462): the reference's own expand2square + the HF
     CLIPImageProcessor it delegates to (PIL backend), on small synthetic frames, 'pad' and plain modes.  The processor is
@@ -399,9 +426,13 @@ if __name__ == "__main__":
     if "--long-ctx-only" in sys.argv:
         long_ctx_goldens(tmp)
         sys.exit(0)
+    if "--real-vocab-only" in sys.argv:
+        real_vocab_goldens(tmp)
+        sys.exit(0)
     int_goldens()
     fp_goldens(tmp)
     medium_goldens(tmp)
     medium_llm_goldens(tmp)
     long_ctx_goldens(tmp)
+    real_vocab_goldens(tmp)
     preprocess_goldens()

@@ -350,3 +350,40 @@ def test_c2_context_length_vs_reference_fixture(golden_dir):
             err = (lg[fin] - ref_lg[fin]).abs().max().item()
             assert err < LOGIT_TOL, (nb, b, err)
     eng.close()
+
+
+def test_real_vocabulary_vs_reference_fixture(golden_dir):
+    """The real vocabulary: 32000-row lm_head (2002 head tiles), <sync> at 32000, time ids 32001.., score ids 32014..: teacher-
+    forced decode against the reference's logits (tests/golden/real_vocab.npz: sampled columns, top-2, finite counts), alone
+    and in a batch of 40 (two passes of the head kernel)."""
+    import dataclasses
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), vocab_size=32000)
+    M = np.load(os.path.join(golden_dir, "real_vocab.npz"))
+    eng = TraceEngine(cfg, max_batch=40, max_ctx=192, max_frames=4, max_new_tokens=64)
+    eng.load_weights(synth.state_dict(cfg).items())
+    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16)
+    ts, ids, forced = M["timestamps"].tolist(), M["input_ids"].tolist(), M["forced_ids"].tolist()
+    cols = torch.from_numpy(M["cols"])
+    ref_s, ref_top, ref_idx = torch.from_numpy(M["sampled"]), torch.from_numpy(M["top_val"]), M["top_idx"]
+    n = len(forced) + 1
+    for nb in (1, 40):
+        for b in range(nb):
+            eng.encode_video(frames, ts)
+            eng.prefill(b, eng.splice(ids))
+        lgs = [eng.decode_begin(list(range(nb)), [1] * nb, n, eos=-1, forced=[forced] * nb, want_logits=True).float().cpu()]
+        for _ in range(n - 1):
+            lgs.append(eng.decode_steps(1, use_graph=False, want_logits=True).float().cpu())
+        out, _ = eng.decode_read()
+        for b in (0, nb - 1):
+            lg = torch.stack([x[b] for x in lgs])
+            assert torch.isfinite(lg).sum(-1).tolist() == M["finite_count"].tolist()          # 13 / 32001 active ids per step
+            s = lg[:, cols]
+            fin = torch.isfinite(ref_s)
+            assert torch.equal(torch.isfinite(s), fin)
+            assert (s[fin] - ref_s[fin]).abs().max().item() < LOGIT_TOL
+            top = torch.topk(torch.where(torch.isfinite(lg), lg, torch.full_like(lg, -1e30)), 2, dim=-1)
+            assert (top.values[:, 0] - ref_top[:, 0]).abs().max().item() < LOGIT_TOL
+            for i in range(n):                                       # arg-max (the emitted id) wherever the reference margin allows
+                if ref_top[i, 0] - ref_top[i, 1] > 2 * LOGIT_TOL:
+                    assert out[b][i] == int(ref_idx[i, 0]), (nb, b, i)
+    eng.close()

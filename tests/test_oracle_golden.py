@@ -202,3 +202,21 @@ def test_long_context_matches_reference_fixture(golden_dir):
                            max_new_tokens=len(forced) + 1, forced_ids=forced, return_logits=True)
     assert ids == M["tf_argmax"].tolist()
     _cmp_logits(lg.numpy(), M["tf_logits"])
+
+
+def test_real_vocab_matches_reference_fixture(golden_dir):
+    """V = 32000 (32027 global ids): oracle teacher-forced logits vs the reference's at sampled columns + top-2."""
+    import dataclasses
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), vocab_size=32000)
+    M = np.load(os.path.join(golden_dir, "real_vocab.npz"))
+    sd = {k: v.float() for k, v in synth.state_dict(cfg).items()}
+    ora = O.Oracle(cfg, sd, emulate_bf16=False)
+    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16).float()
+    forced = M["forced_ids"].tolist()
+    ids, lg = ora.generate(torch.from_numpy(M["input_ids"]), frames, M["timestamps"].tolist(), head=1,
+                           max_new_tokens=len(forced) + 1, forced_ids=forced, return_logits=True)
+    assert ids == M["tf_argmax"].tolist()
+    assert torch.isfinite(lg).sum(-1).tolist() == M["finite_count"].tolist()
+    _cmp_logits(lg[:, torch.from_numpy(M["cols"])].numpy(), M["sampled"])
+    top = torch.topk(torch.where(torch.isfinite(lg), lg, torch.full_like(lg, -1e30)), 2, dim=-1)
+    np.testing.assert_allclose(top.values.numpy(), M["top_val"], rtol=2e-4, atol=2e-4)

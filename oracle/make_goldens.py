@@ -384,6 +384,25 @@ def real_vocab_goldens(tmp):
     print("real_vocab: NV=%d steps=%d finite counts %s" % (NV, len(tf_argmax), sorted(set(fin.sum(-1).tolist()))))
 
 
+def deep_llm_goldens(tmp):
+    """Depth: EIGHT decoder layers at the real Mistral-7B widths (1.74 B parameters, a quarter of the real stack) behind the
+    tiny ViT, teacher-forced.  Shows how the bf16 noise of the HIP path accumulates with depth against the fp32 reference."""
+    import dataclasses
+    from trace_amd import config as tcfg, synth
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336, num_hidden_layers=8)
+    model = build_reference_model(cfg, os.path.join(tmp, "deepllm"))
+    load_synth(model, cfg)
+    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16).float()
+    ts = [[float(i) * 2.5] for i in range(cfg.num_frames)]
+    input_ids = synth.synth_prompt_ids(cfg, n_text=24, video_pos=10)
+    forced = scripted_ids(cfg)
+    tf_logits, tf_argmax, L = run_reference(model, cfg, input_ids, frames, ts, forced=forced)
+    np.savez_compressed(os.path.join(OUT, "deep_llm.npz"), input_ids=input_ids.numpy(), timestamps=np.array(ts, dtype=np.float64),
+                        forced_ids=np.array(forced), tf_logits=tf_logits.numpy().astype(np.float32), tf_argmax=np.array(tf_argmax),
+                        prefill_len=np.array(L))
+    print("deep_llm: L=%d steps=%d logit std %.3f" % (L, len(tf_argmax), tf_logits[torch.isfinite(tf_logits)].std().item()))
+
+
 def preprocess_goldens():
     """Frame preprocessing of process_video (mm_utils.py:456-462): the reference's own expand2square + the HF
     CLIPImageProcessor it delegates to (PIL backend), on small synthetic frames, 'pad' and plain modes.  The processor is
@@ -429,10 +448,14 @@ if __name__ == "__main__":
     if "--real-vocab-only" in sys.argv:
         real_vocab_goldens(tmp)
         sys.exit(0)
+    if "--deep-llm-only" in sys.argv:
+        deep_llm_goldens(tmp)
+        sys.exit(0)
     int_goldens()
     fp_goldens(tmp)
     medium_goldens(tmp)
     medium_llm_goldens(tmp)
     long_ctx_goldens(tmp)
     real_vocab_goldens(tmp)
+    deep_llm_goldens(tmp)
     preprocess_goldens()

@@ -317,6 +317,42 @@ def test_real_width_decoder_layer_vs_reference_fixture(golden_dir):
     eng.close()
 
 
+def test_deep_real_width_stack_vs_reference_fixture(golden_dir):
+    """Depth: eight decoder layers at the real Mistral-7B widths (1.7 B parameters, a quarter of the real stack), teacher-forced
+    decode against logits captured from the reference (tests/golden/deep_llm.npz), at B = 1 and inside a batch of 40.  Shows the
+    bf16 noise of the HIP path (bf16 weights, activations and KV cache; fp32 accumulation) stays inside the logit tolerance as
+    layers stack, and that wherever the reference's top-2 margin exceeds twice the tolerance the greedy id is the reference's."""
+    import dataclasses
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336, num_hidden_layers=8)
+    M = np.load(os.path.join(golden_dir, "deep_llm.npz"))
+    eng = TraceEngine(cfg, max_batch=40, max_ctx=192, max_frames=4, max_new_tokens=64)
+    eng.load_weights(synth.iter_weights(cfg))
+    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16)
+    forced, ref_lg, ref_ids = M["forced_ids"].tolist(), torch.from_numpy(M["tf_logits"]), M["tf_argmax"].tolist()
+    n = len(forced) + 1
+    fin = torch.isfinite(ref_lg)
+    srt = torch.sort(torch.where(fin, ref_lg, torch.full_like(ref_lg, -1e30)), dim=-1, descending=True).values
+    margin = (srt[:, 0] - srt[:, 1]).tolist()
+    for nb in (1, 40):
+        for b in range(nb):
+            eng.encode_video(frames, M["timestamps"].tolist())
+            eng.prefill(b, eng.splice(M["input_ids"].tolist()))
+        lgs = [eng.decode_begin(list(range(nb)), [1] * nb, n, eos=-1, forced=[forced] * nb, want_logits=True).float().cpu()]
+        for _ in range(n - 1):
+            lgs.append(eng.decode_steps(1, use_graph=False, want_logits=True).float().cpu())
+        ids, _ = eng.decode_read()
+        for b in (0, nb - 1):
+            lg = torch.stack([x[b] for x in lgs])
+            assert torch.equal(torch.isfinite(lg), fin)
+            err = (lg[fin] - ref_lg[fin]).abs().max().item()
+            print("deep stack nb=%d b=%d max |dlogit| %.4f" % (nb, b, err))
+            assert err < LOGIT_TOL, (nb, b, err)
+            for i, (a, r, m) in enumerate(zip(ids[b], ref_ids, margin)):
+                if m > 2 * LOGIT_TOL:
+                    assert a == r, (nb, b, i, a, r, m)
+    eng.close()
+
+
 def test_c2_context_length_vs_reference_fixture(golden_dir):
     """The C2 context: 128 frames -> prefill L = 1967, one real-width decoder layer, teacher-forced decode at contexts
     1968.. against logits captured from the reference (tests/golden/long_ctx.npz).  Exercises the causal prefill attention

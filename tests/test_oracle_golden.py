@@ -204,6 +204,21 @@ def test_long_context_matches_reference_fixture(golden_dir):
     _cmp_logits(lg.numpy(), M["tf_logits"])
 
 
+def test_deep_llm_matches_reference_fixture(golden_dir):
+    """Eight decoder layers at the real Mistral-7B widths (1.7 B parameters): oracle teacher-forced logits vs the reference's."""
+    import dataclasses
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336, num_hidden_layers=8)
+    M = np.load(os.path.join(golden_dir, "deep_llm.npz"))
+    sd = {k: v.float() for k, v in synth.state_dict(cfg).items()}
+    ora = O.Oracle(cfg, sd, emulate_bf16=False)
+    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16).float()
+    forced = M["forced_ids"].tolist()
+    ids, lg = ora.generate(torch.from_numpy(M["input_ids"]), frames, M["timestamps"].tolist(), head=1,
+                           max_new_tokens=len(forced) + 1, forced_ids=forced, return_logits=True)
+    assert ids == M["tf_argmax"].tolist()
+    _cmp_logits(lg.numpy(), M["tf_logits"])
+
+
 def test_real_vocab_matches_reference_fixture(golden_dir):
     """V = 32000 (32027 global ids): oracle teacher-forced logits vs the reference's at sampled columns + top-2."""
     import dataclasses

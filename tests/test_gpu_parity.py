@@ -189,10 +189,11 @@ def test_errors_are_python_exceptions(setup):
         eng.time_ids([[1.0], [2.0, 3.0]])       # unequal time-token length (trace_arch.py:285)
 
 
-@pytest.mark.parametrize("nb", [20, 40])
+@pytest.mark.parametrize("nb", [20, 40, 64])
 def test_big_batch_equals_single(setup, nb):
     """B > 16 / B > 32 exercise the two- and four-group decode GEMV (NB = 2, 4) and the second head pass: nb sequences
-    (two distinct videos, alternating) must reproduce the B = 1 streams."""
+    (two distinct videos, alternating) must reproduce the B = 1 streams — through the captured hipGraph (one per batch size,
+    up to the 64-row maximum) and through eager launches."""
     cfg, eng, ora, E, frames = setup
     f2 = synth.synth_frames(cfg, 1).to(torch.bfloat16)
     ts, ids = E["timestamps"].tolist(), E["input_ids"].tolist()
@@ -202,9 +203,11 @@ def test_big_batch_equals_single(setup, nb):
     big = TraceEngine(cfg, max_batch=nb, max_ctx=192, max_frames=4, max_new_tokens=32)
     big.load_weights(synth.state_dict(cfg).items())
     vids = [frames if i % 2 == 0 else f2 for i in range(nb)]
-    out, _ = big.generate(vids, [ts] * nb, [ids] * nb, [1] * nb, n)
+    out, _ = big.generate(vids, [ts] * nb, [ids] * nb, [1] * nb, n, use_graph=True)
     for i in range(nb):
         assert out[i] == (a[0] if i % 2 == 0 else b[0]), i
+    out_e, _ = big.generate(vids, [ts] * nb, [ids] * nb, [1] * nb, n, use_graph=False)
+    assert out_e == out
     big.close()
 
 

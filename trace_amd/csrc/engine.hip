@@ -76,7 +76,7 @@ struct trace_ctx {
     int B = 0, max_new = 0, eos = -1, has_forced = 0, ntiles = 0, nsplit = 32;
     int slot_len[64] = {0};
     int host_mode = 0, fed = 0;        // host-driven token selection (sampling): head logits only, ids fed back by the host
-    hipGraphExec_t graphs[33] = {nullptr};
+    hipGraphExec_t graphs[SK_ROWS + 1] = {nullptr};   // one captured decode step per batch size
     hipStream_t cap_stream = nullptr;
     // profiling
     int profile = 0;                  // 1: time decode_steps calls; 2: also bracket the layer-0 gate|up GEMV launch
@@ -305,7 +305,7 @@ extern "C" int trace_ctx_load_tensor(trace_ctx* c, const char* name_, const void
             HIPCHK(hipDeviceSynchronize());
             return done();
         }
-        if ((k[0] == 's') && (k[1] == '1' || k[1] == '2') && k[2] == '.' && k[3] == 'b' && k[5] == '.') {
+        if (k.size() > 6 && (k[0] == 's') && (k[1] == '1' || k[1] == '2') && k[2] == '.' && k[3] == 'b' && k[5] == '.') {
             const int st = k[1] - '1', b = k[4] - '1';
             if (b < 0 || b > 3) return fail(TRACE_ERR_ARG, "bad STC block in " + name);
             StcBlock& q = c->stc_blk[st][b];

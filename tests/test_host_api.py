@@ -160,3 +160,54 @@ def test_evaluate_parser_and_prompt():
     from trace_amd.model.builder import ByteTokenizer
     p = ev.build_prompt_ids("find events", ByteTokenizer(cfg.vocab_size))
     assert int((p == -201).sum()) == 1 and int(p[-1]) == -205 and ev.stop_string() == "</s>"
+
+
+def test_checkpoint_iterator_layouts(tmp_path):
+    """SURVEY §8f-2 host logic (no GPU): a TRACE checkpoint directory whose shards are mixed safetensors-less `.bin` files with
+    the serialised rotary buffers older transformers wrote, NO vision tower inside, and `mm_vision_tower` pointing at a local
+    CLIPModel directory (vision_model.* beside text_model.* / logit_scale, geometry in its config.json) must yield exactly the
+    tensors of the path under the reference's state-dict names."""
+    import dataclasses, json
+    from trace_amd import config as tcfg, synth
+    from trace_amd.model import builder
+    cfg = tcfg.tiny()
+    clip_dir = tmp_path / "tiny-clip"
+    clip_dir.mkdir()
+    sd = synth.state_dict(cfg)
+    vis = {k[len("model.vision_tower.vision_tower."):]: v for k, v in sd.items() if ".vision_tower." in k}
+    vis["text_model.embeddings.token_embedding.weight"] = torch.zeros(4, 4)
+    vis["logit_scale"] = torch.tensor(1.0)
+    vis["vision_model.embeddings.position_ids"] = torch.arange(17).unsqueeze(0)
+    torch.save(vis, clip_dir / "pytorch_model.bin")
+    json.dump({"model_type": "clip", "vision_config": {
+        "hidden_size": cfg.vision_hidden_size, "intermediate_size": cfg.vision_intermediate_size, "num_hidden_layers": cfg.vision_num_layers,
+        "num_attention_heads": cfg.vision_num_heads, "image_size": cfg.vision_image_size, "patch_size": cfg.vision_patch_size,
+        "layer_norm_eps": cfg.vision_layer_norm_eps}}, open(clip_dir / "config.json", "w"))
+    ckpt = tmp_path / "trace-tiny"
+    ckpt.mkdir()
+    d = dataclasses.replace(cfg, mm_vision_tower=str(clip_dir)).to_dict()
+    for k in list(d):
+        if k.startswith("vision_") and k != "vision_layers_used":
+            d.pop(k)                                  # a real TRACE config.json does not spell the CLIP geometry out
+    json.dump(d, open(ckpt / "config.json", "w"))
+    rest = [(k, v) for k, v in sd.items() if ".vision_tower." not in k]
+    a = dict(rest[0::2])
+    b = dict(rest[1::2])
+    b["model.layers.0.self_attn.rotary_emb.inv_freq"] = torch.ones(64)
+    torch.save(a, ckpt / "pytorch_model-00001-of-00002.bin")
+    torch.save(b, ckpt / "pytorch_model-00002-of-00002.bin")
+    cfg2 = tcfg.TraceConfig.from_pretrained(str(ckpt))
+    assert dataclasses.replace(cfg2, mm_vision_tower=cfg.mm_vision_tower) == cfg
+    got = dict(builder._iter_checkpoint(str(ckpt), cfg2))
+    assert set(got) == set(sd)
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+    # a checkpoint that does carry the tower wins over the CLIP directory
+    torch.save({k: v + 1 for k, v in sd.items() if ".vision_tower." in k}, ckpt / "pytorch_model-00003-of-00003.bin")
+    got = dict(builder._iter_checkpoint(str(ckpt), cfg2))
+    k0 = synth.VIS + "pre_layrnorm.weight"
+    assert torch.equal(got[k0], sd[k0] + 1)
+    # no tower anywhere -> a clear error, not a hub download
+    (ckpt / "pytorch_model-00003-of-00003.bin").unlink()
+    bad = dataclasses.replace(cfg2, mm_vision_tower="openai/clip-vit-large-patch14-336")
+    with pytest.raises(FileNotFoundError, match="no hub access"):
+        dict(builder._iter_checkpoint(str(ckpt), bad))

@@ -124,6 +124,15 @@ class TraceConfig:
         for k, v in vis.items():
             if k in alias:
                 d.setdefault(alias[k], v)
+        # a real TRACE config.json names the CLIP tower (`mm_vision_tower`) instead of spelling out its geometry: read it
+        # from that directory's config.json when it is a local path (CLIPVisionConfig.from_pretrained, clip_encoder.py:21)
+        tower_cfg = os.path.join(str(d.get("mm_vision_tower", "")), "config.json")
+        if os.path.isfile(tower_cfg):
+            with open(tower_cfg) as f:
+                c = json.load(f)
+            for k, v in (c.get("vision_config") or c).items():
+                if k in alias:
+                    d.setdefault(alias[k], v)
         return cls.from_dict(d)
 
     def save_pretrained(self, path: str) -> None:

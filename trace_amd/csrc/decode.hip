@@ -1,4 +1,4 @@
-// Decode-step kernels (1 new token for each of B <= 32 sequences).  This is the HBM-bound heart of the path:
+// Decode-step kernels (1 new token for each of B <= 64 sequences).  This is the HBM-bound heart of the path:
 // every step streams all 7.2 B bf16 weights once plus the KV cache of every sequence (reference:
 // TraceMistralForCausalLM.forward with input_ids [B,1] + past_key_values, trace/model/language_model/trace_mistral.py:114-264).
 //
@@ -34,7 +34,7 @@ union Frag { uint4 u; bf16x8_t v; };
 // straight into MFMA fragments.  At B = 32 that L2 stream is as large as the weight stream itself and cost 30-60 %
 // (gate|up 72 us vs 55 us with the X loads neutered, down 45 vs 29, qkv 26 vs 16); its 16 interleaved 8 KB-strided
 // row streams per wave also thrashed DRAM pages (the same bytes read as one contiguous run: 51.7 -> 41.7 us).
-// Now one workgroup per CU parks a K-chunk of X (<= 128 KB: 4096 k for 16 rows, 2048 k for 32) in LDS once, in
+// Now one workgroup per CU parks a K-chunk of X (<= 128 KB: 4096 k for 16 rows, 2048 k for 32, 1024 k for 64) in LDS once, in
 // MFMA-fragment order (every later read is a lane-linear ds_read_b128), and streams several weight tiles against it:
 //   grid = KS k-chunks x row-groups (<= #CUs workgroups), workgroup = T <= 16 tasks on <= 8 waves; a task is NT 16-row
 //   weight tiles over the chunk; when T <= 4 its k-units are split over WPT waves (LDS-reduced, fixed order).
@@ -872,7 +872,7 @@ static int skinny_lds_launch(const SkinnyPlan& p, const bf16_t* X, int ldx, cons
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 
-// EPI_PARTIAL: `out` is unused, ldo = N, the fp32 partial rows [KS = skinny_ks()][32][N] land in ws.
+// EPI_PARTIAL: `out` is unused, ldo = N, the fp32 partial rows [KS = skinny_ks()][SK_ROWS][N] land in ws.
 int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R, int ldr,
                        int B, int N, int K, int epi, int tiled, float* ws, size_t ws_floats, unsigned int* tickets, int ntickets,
                        hipStream_t s) {

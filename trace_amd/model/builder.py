@@ -2,7 +2,8 @@
     tokenizer, model, processor, context_len = load_pretrained_model(model_path, model_base, model_name, ...)
 
 A model directory holds `config.json` (TraceConfig keys = the reference's config keys) and either HF-format weight
-shards (`*.safetensors`, reference state-dict names; both transformers CLIP key layouts are accepted) or
+shards (`*.safetensors` or `pytorch_model*.bin`, reference state-dict names; both transformers CLIP key layouts are
+accepted; when the shards carry no vision tower it is read from the local CLIP directory `mm_vision_tower` names) or
 `"synthetic_weights": true` (random-init weights of the exact architecture — what the build container and the GPU box
 use, since no checkpoint can be downloaded).  8-bit / 4-bit / LoRA branches of the reference are load-time conveniences
 outside the accelerated path and raise NotImplementedError."""
@@ -60,15 +61,53 @@ def save_synthetic_checkpoint(path: str, cfg: TraceConfig) -> str:
     return path
 
 
-def _iter_safetensors(model_path: str):
-    from safetensors import safe_open
-    files = sorted(glob.glob(os.path.join(model_path, "*.safetensors")))
-    if not files:
-        raise FileNotFoundError(f"no *.safetensors under {model_path}")
-    for fn in files:
+def _checkpoint_files(path: str):
+    """HF weight shards of a model directory: `*.safetensors` if there are any, else `pytorch_model*.bin`."""
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    return files or sorted(glob.glob(os.path.join(path, "pytorch_model*.bin")))
+
+
+def _iter_file(fn: str):
+    if fn.endswith(".safetensors"):
+        from safetensors import safe_open
         with safe_open(fn, framework="pt", device="cpu") as f:
             for k in f.keys():
                 yield k, f.get_tensor(k)
+    else:
+        sd = torch.load(fn, map_location="cpu", weights_only=True)
+        yield from sd.items()
+
+
+# buffers older transformers versions serialise; not parameters of the path
+_SKIP_SUFFIXES = ("rotary_emb.inv_freq", "embeddings.position_ids")
+
+
+def _iter_checkpoint(model_path: str, cfg: TraceConfig):
+    """(reference state-dict name, tensor) for every tensor of the path.  The reference builds the CLIP tower from
+    `config.mm_vision_tower` first (clip_encoder.py:23-29, trace_arch.py:35) and then loads the TRACE checkpoint over it
+    (builder.py:114), so tower weights come from the checkpoint when it has them and from the CLIP directory otherwise."""
+    files = _checkpoint_files(model_path)
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors / pytorch_model*.bin under {model_path}")
+    seen_vision = False
+    for fn in files:
+        for k, t in _iter_file(fn):
+            if k.endswith(_SKIP_SUFFIXES):
+                continue
+            seen_vision |= ".vision_tower." in k
+            yield k, t
+    if seen_vision:
+        return
+    vdir = cfg.mm_vision_tower
+    vfiles = _checkpoint_files(vdir) if os.path.isdir(vdir) else []
+    if not vfiles:
+        raise FileNotFoundError(f"the checkpoint holds no vision-tower weights and mm_vision_tower={vdir!r} is not a local "
+                                "CLIP directory with weight files (there is no hub access: point it at a downloaded copy)")
+    for fn in vfiles:
+        for k, t in _iter_file(fn):
+            # a CLIPModel checkpoint also carries text_model.* / visual_projection / logit_scale: not on the path
+            if k.startswith("vision_model.") and not k.endswith(_SKIP_SUFFIXES):
+                yield "model.vision_tower.vision_tower." + k, t
 
 
 def _image_processor(cfg: TraceConfig, model_path: str):
@@ -111,7 +150,7 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
         eng.load_weights(synth.iter_weights(cfg, device="cpu" if small else f"cuda:{dev_index}"))
         tokenizer = ByteTokenizer(cfg.vocab_size)
     else:
-        eng.load_weights(_iter_safetensors(model_path))
+        eng.load_weights(_iter_checkpoint(model_path, cfg))
         has_tok = any(os.path.exists(os.path.join(model_path, f)) for f in ("tokenizer.model", "tokenizer.json", "tokenizer_config.json"))
         if has_tok:
             from transformers import AutoTokenizer

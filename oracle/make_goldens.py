@@ -287,6 +287,57 @@ def int_goldens():
         e2s.append({"in": arr.tolist(), "bg": list(bg), "out": np.array(out).tolist()})
     G["expand2square"] = e2s
 
+    # process_video itself (mm_utils.py:379-471), driven through fake readers: frame k is a 4x6 image filled with k, the fake
+    # processor reports (fill value, width) of every image it is handed -> which frames, in which order, after which padding
+    class FakeVR:
+        def __init__(self, uri=None, ctx=None, num_threads=0):
+            self.n, self.fps = FakeVR.spec
+
+        def __len__(self):
+            return self.n
+
+        def get_avg_fps(self):
+            return self.fps
+
+        def get_batch(self, ids):
+            arr = np.stack([np.full((4, 6, 3), int(i) % 251, dtype=np.uint8) for i in ids])
+            return types.SimpleNamespace(numpy=lambda: arr)
+
+    class FakeProc:
+        image_mean = [0.48145466, 0.4578275, 0.40821073]
+
+        def preprocess(self, images, return_tensors="pt"):
+            return {"pixel_values": torch.tensor([[int(np.asarray(im)[im.size[1] // 2, im.size[0] // 2, 0]), im.size[0], im.size[1]]
+                                                  for im in images])}
+
+    ref_mm.VideoReader, ref_mm.cpu = FakeVR, (lambda i: None)
+    pv = []
+    import random as _random
+    for (n, fps, nf, scheme, grid, aspect) in [
+            (300, 30.0, 8, "uniform", False, "pad"), (50, 10.0, 128, "uniform", False, "pad"), (3000, 25.0, 128, "uniform", False, "no"),
+            (900, 30.0, 8, "fps", False, "pad"), (100, 24.0, 8, "fps", False, "pad"), (400, 25.0, 8, "rand", False, "pad"),
+            (64, 8.0, 9, "uniform", True, "pad"), (400000, 30.0, 8, "uniform", False, "pad"), (20, 5.0, 8, "bogus", False, "pad")]:
+        FakeVR.spec = (n, fps)
+        _random.seed(1234)
+        case = {"kind": "frames", "duration": n, "fps": fps, "num_frames": nf, "scheme": scheme, "image_grid": grid, "aspect": aspect}
+        try:
+            v, ts = ref_mm.process_video("x.mp4", FakeProc(), aspect_ratio=aspect, num_frames=nf, image_grid=grid, sample_scheme=scheme)
+            case.update(picked=v.tolist(), timestamps=ts)
+        except Exception as e:
+            case.update(error=type(e).__name__ + ": " + str(e))
+        pv.append(case)
+    for (n, nf) in [(12, 8), (5, 8), (40, 6)]:
+        frames = [np.full((4, 6, 3), 10 * (k % 25), dtype=np.uint8) for k in range(n)]
+        ref_mm.imageio.get_reader = lambda path, frames=frames: list(frames)
+        v, ts = ref_mm.process_video("x.gif", FakeProc(), aspect_ratio="pad", num_frames=nf)
+        pv.append({"kind": "gif", "duration": n, "num_frames": nf, "picked": v.tolist(), "timestamps": ts})
+    G["process_video"] = pv
+    grids = []
+    for (t, rows, cols) in [(5, None, None), (4, 2, 2), (7, None, 3), (6, 2, None), (9, 3, 3)]:
+        arr = np.arange(t * 2 * 3 * 3, dtype=np.uint8).reshape(t, 2, 3, 3)
+        grids.append({"t": t, "rows": rows, "cols": cols, "out": ref_mm.create_photo_grid(arr, rows, cols).tolist()})
+    G["create_photo_grid"] = grids
+
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, "host_functions.json"), "w") as f:
         json.dump(G, f, indent=0)
@@ -433,6 +484,9 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     tmp = install_shim()
+    if "--int-only" in sys.argv:
+        int_goldens()
+        sys.exit(0)
     if "--preprocess-only" in sys.argv:
         preprocess_goldens()
         sys.exit(0)

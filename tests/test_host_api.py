@@ -211,3 +211,58 @@ def test_checkpoint_iterator_layouts(tmp_path):
     bad = dataclasses.replace(cfg2, mm_vision_tower="openai/clip-vit-large-patch14-336")
     with pytest.raises(FileNotFoundError, match="no hub access"):
         dict(builder._iter_checkpoint(str(ckpt), bad))
+
+
+class _IndexCodedReader:
+    """decord-like reader whose frame k is a 4x6 image filled with k % 251 (what oracle/make_goldens.py fed the reference)"""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def get_batch(self, ids):
+        arr = np.stack([np.full((4, 6, 3), int(i) % 251, dtype=np.uint8) for i in ids])
+        return types.SimpleNamespace(numpy=lambda: arr)
+
+
+class _ReportingProcessor:
+    image_mean = [0.48145466, 0.4578275, 0.40821073]
+
+    def preprocess(self, images, return_tensors="pt"):
+        return {"pixel_values": torch.tensor([[int(np.asarray(im)[im.size[1] // 2, im.size[0] // 2, 0]), im.size[0], im.size[1]]
+                                              for im in images])}
+
+
+def test_process_video_against_reference_runs(G, tmp_path):
+    """process_video end to end (sampling scheme, MAX_FRAMES cap, GIF de-duplication at 10 fps, photo grid, padding, timestamp
+    guards) against what the reference's own process_video returned for the same index-coded clips (captured through fake
+    readers by oracle/make_goldens.py): same frames in the same order, same sizes after padding, same timestamps, same errors."""
+    import random
+    for c in G["process_video"]:
+        if c["kind"] == "gif":
+            path = str(tmp_path / f"clip{c['duration']}.gif")
+            frames = [Image.fromarray(np.full((4, 6), 10 * (k % 25), dtype=np.uint8), mode="L") for k in range(c["duration"])]
+            frames[0].save(path, save_all=True, append_images=frames[1:], duration=100, loop=0)
+            v, ts = mm_utils.process_video(path, _ReportingProcessor(), aspect_ratio="pad", num_frames=c["num_frames"])
+        else:
+            random.seed(1234)
+            call = lambda: mm_utils.process_video(_IndexCodedReader(c["duration"]), _ReportingProcessor(), aspect_ratio=c["aspect"],
+                                                  num_frames=c["num_frames"], image_grid=c["image_grid"],
+                                                  sample_scheme=c["scheme"], fps=c["fps"])
+            if "error" in c:
+                kind, msg = c["error"].split(": ", 1)
+                with pytest.raises(ImportError) as ei:
+                    call()
+                assert kind == "ImportError" and str(ei.value) == msg
+                continue
+            v, ts = call()
+        assert v.tolist() == c["picked"], c
+        assert ts == c["timestamps"], c
+
+
+def test_create_photo_grid(G):
+    for c in G["create_photo_grid"]:
+        arr = np.arange(c["t"] * 2 * 3 * 3, dtype=np.uint8).reshape(c["t"], 2, 3, 3)
+        assert mm_utils.create_photo_grid(arr, c["rows"], c["cols"]).tolist() == c["out"], (c["t"], c["rows"], c["cols"])

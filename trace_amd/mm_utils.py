@@ -32,6 +32,29 @@ def expand2square(pil_img, background_color):
     return canvas
 
 
+def create_photo_grid(arr, rows=None, cols=None):
+    """mm_utils.py:303-355: tile T equally sized frames row by row into one [rows*h, cols*w, c] image (zeros where the
+    grid has spare cells).  Missing rows/cols default to a near-square layout."""
+    if isinstance(arr, (list, tuple)):
+        if not len(arr) or not isinstance(arr[0], (Image.Image, np.ndarray)):
+            raise ValueError("Invalid input type. Expected list of Images or numpy arrays.")
+        arr = np.stack([np.asarray(a) for a in arr])
+    t, h, w, c = arr.shape
+    if rows is None and cols is None:
+        rows = math.ceil(math.sqrt(t))
+    if cols is None:
+        cols = math.ceil(t / rows)
+    if rows is None:
+        rows = math.ceil(t / cols)
+    if rows * cols < t:
+        raise ValueError(f"Not enough grid cells ({rows}x{cols}) to hold all images ({t}).")
+    grid = np.zeros((rows * h, cols * w, c), dtype=arr.dtype)
+    for i in range(t):
+        y, x = divmod(i, cols)
+        grid[y * h:(y + 1) * h, x * w:(x + 1) * w] = arr[i]
+    return grid
+
+
 def frame_sample(duration: int, num_frames: int = NUM_FRAMES, mode: str = "uniform", local_fps: Optional[float] = None):
     """mm_utils.py:380-400 (closure inside process_video in the reference)."""
     if mode == "uniform":
@@ -55,10 +78,22 @@ def sample_indices_and_timestamps(duration: int, fps: float, num_frames: int, mo
     return idx, [[float(i / fps)] for i in idx]
 
 
+class _GifFrames(list):
+    """marker: the reference's GIF branch keeps each sampled index ONCE, in increasing order (`index in frame_id_list`)"""
+
+
 def _to_frames(video, fps):
     if isinstance(video, str):
         if video.endswith(".npy"):
             return np.load(video), float(fps or 1.0)
+        if video.lower().endswith(".gif"):
+            # the reference reads GIFs with imageio at a nominal 10 fps (mm_utils.py:404-413); Pillow decodes them as well
+            with Image.open(video) as im:
+                frames = []
+                for i in range(getattr(im, "n_frames", 1)):
+                    im.seek(i)
+                    frames.append(np.array(im.convert("RGB")))
+            return _GifFrames(frames), 10.0
         if os.path.isdir(video):
             names = sorted(n for n in os.listdir(video) if n.lower().endswith((".png", ".jpg", ".jpeg", ".bmp")))
             return [np.array(Image.open(os.path.join(video, n)).convert("RGB")) for n in names], float(fps or 1.0)
@@ -83,6 +118,9 @@ def process_video(video_path, processor, aspect_ratio="pad", num_frames=NUM_FRAM
     src, local_fps = _to_frames(video_path, fps)
     duration = len(src)
     idx, video_timestamps = sample_indices_and_timestamps(duration, local_fps, num_frames, sample_scheme)
+    if isinstance(src, _GifFrames):
+        idx = sorted(set(int(i) for i in idx))
+        video_timestamps = [[i / local_fps] for i in idx]
     if hasattr(src, "get_batch"):
         batch = src.get_batch(idx)
         data = batch.asnumpy() if hasattr(batch, "asnumpy") else batch.numpy()
@@ -94,8 +132,12 @@ def process_video(video_path, processor, aspect_ratio="pad", num_frames=NUM_FRAM
         raise ImportError("The video is too long!")
     if video_timestamps[0][0] < 0:
         raise ImportError("Timestamp can not be less than zero")
+    if image_grid:                                                       # mm_utils.py:450-453: the photo grid goes first
+        side = math.ceil(math.sqrt(num_frames))
+        as_np = [np.asarray(f.convert("RGB") if isinstance(f, Image.Image) else f) for f in frames]
+        frames = [create_photo_grid(as_np, side, side), *as_np]
     eng = getattr(engine, "engine", engine)
-    if eng is not None:
+    if eng is not None and not image_grid:                               # (the grid image has a different size: host path)
         arr = np.stack([np.asarray(f.convert("RGB") if isinstance(f, Image.Image) else f) for f in frames])
         mean = getattr(processor, "image_mean", None) or eng.CLIP_MEAN
         std = getattr(processor, "image_std", None) or eng.CLIP_STD
@@ -111,6 +153,9 @@ def process_video(video_path, processor, aspect_ratio="pad", num_frames=NUM_FRAM
 def process_image(image_path, processor, aspect_ratio="pad", num_frames=NUM_FRAMES, image_grid=False):
     image = image_path if isinstance(image_path, Image.Image) else Image.open(image_path).convert("RGB")
     images = [np.array(image)]
+    if image_grid:                                                       # mm_utils.py:361-366
+        side = math.ceil(math.sqrt(num_frames))
+        images = [create_photo_grid(np.stack([images[0]] * num_frames), side, side), images[0]]
     images = [Image.fromarray(f) for f in images]
     if aspect_ratio == "pad":
         images = [expand2square(im, tuple(int(x * 255) for x in processor.image_mean)) for im in images]

@@ -37,6 +37,9 @@ typedef struct trace_config {
     int32_t max_batch;       /* KV-cache sequence slots = largest decode batch, <= 64      */
     int32_t max_new_tokens;  /* capacity of the on-device output id buffer               */
     int32_t projector_type;  /* 0 = spatial_slot (TRACE), 1 = stc_connector (legacy API) */
+    int32_t vit_batch_frames; /* frames one trace_vit_forward call may take (ViT workspaces); 0 = max_frames.  Larger than
+                               * max_frames lets a caller push the frames of several videos through the tower together (the
+                               * tower is per-frame: results do not depend on the grouping) */
 } trace_config;
 
 const char* trace_last_error(void);
@@ -80,6 +83,10 @@ int trace_stc_connector(trace_ctx* ctx, const void* feats, int T, void* out, int
  * video_out (device, may be NULL) receives a copy. */
 int trace_encode_video(trace_ctx* ctx, const void* frames, int frames_dtype, int T, const int32_t* time_ids,
                        void* video_out, void* stream);
+
+/* The same from ViT features computed earlier (trace_vit_forward with feats_out, possibly in a call that carried the frames
+ * of several videos, see vit_batch_frames): feats [T, patches, v_hidden] bf16 (device) -> slot pool + time-token rows. */
+int trace_encode_features(trace_ctx* ctx, const void* feats, int T, const int32_t* time_ids, void* video_out, void* stream);
 
 /* prepare_inputs_labels_for_multimodal, prefill branch (trace/model/trace_arch.py:377-456): HOST ids with the
  * modal placeholders (-201 video, -203 time, -204 score, -205 sync); the single video placeholder expands to

@@ -121,6 +121,12 @@ def test_batch_40_equals_singles():
     ts = [[float(i)] for i in range(128)]
     vids = [synth.synth_frames(cfg, 100 + b, num_frames=128).to(torch.bfloat16).cuda() for b in range(nb)]
     out, _ = eng.generate(vids, [ts] * nb, [ids] * nb, [1] * nb, n_new, eos=-1)
+    # the tower ran over the batch's frame stream 170 frames at a time (whole GEMM rounds): same features as one video alone
+    assert eng.vit_batch_frames == 170
+    many = eng.vit_forward_many(vids[:3])              # 384 frames = 170 + 170 + 44, every chunk spans a video boundary
+    for b in range(3):
+        assert torch.equal(many[b], eng.vit_forward(vids[b]))
+    del many
     # step-0 logits of the whole batch (all slots are still prefilled)
     lgb = eng.decode_begin(list(range(nb)), [1] * nb, n_new, eos=-1, want_logits=True).float().cpu()
     for b in (0, 17, 39):

@@ -211,6 +211,27 @@ def test_big_batch_equals_single(setup, nb):
     big.close()
 
 
+def test_tower_over_frame_stream_equals_per_video(setup):
+    """Several videos' frames pushed through the ViT `vit_batch_frames` at a time, chunks spanning video boundaries (4 + 2 + 4
+    frames in chunks of 5): features, and the [slots | time] rows built from them, are bit-identical to per-video calls."""
+    from trace_amd._lib import TraceHipError
+    cfg, eng, ora, E, frames = setup
+    e3 = TraceEngine(cfg, max_batch=3, max_ctx=192, max_frames=4, max_new_tokens=16, vit_batch_frames=5)
+    e3.load_weights(synth.state_dict(cfg).items())
+    vids = [frames, synth.synth_frames(cfg, 1, num_frames=2).to(torch.bfloat16), synth.synth_frames(cfg, 2).to(torch.bfloat16)]
+    tss = [[[float(i) * 2.5] for i in range(v.shape[0])] for v in vids]
+    many = e3.vit_forward_many(vids)
+    for v, f, ts in zip(vids, many, tss):
+        assert f.shape[0] == v.shape[0]
+        assert torch.equal(f, e3.vit_forward(v))
+        a = e3.encode_video(v, ts, want_output=True).clone()
+        b = e3.encode_features(f.contiguous(), ts, want_output=True)
+        assert torch.equal(a, b)
+    with pytest.raises(TraceHipError, match="max_frames"):
+        e3.encode_video(torch.cat([frames, frames[:1]]), [[0.0]] * 5)       # 5 frames fit the tower batch but not one video
+    e3.close()
+
+
 def test_ragged_batch_and_context_limits(setup):
     """Ragged batch: videos with different frame counts (2 vs 4 -> 28 vs 56 visual rows) and different prompt lengths decode
     together exactly as they do alone, and match the bf16-emulating oracle on the 13-way heads.  Context edge: a prompt

@@ -11,7 +11,7 @@ if "all" in what or "attn" in what:
     for _ in range(3):
         ops.attention(q, k, v, False, 0.125)
 if "all" in what or "gemm" in what:
-    A, W, b = rnd(73856, 1024), rnd(4096, 1024, scale=0.02), rnd(4096)
+    A, W, b = rnd(170 * 577, 1024), rnd(4096, 1024, scale=0.02), rnd(4096)      # the bench's probe shape: one 170-frame ViT call
     for _ in range(3):
         ops.gemm(A, W, bias=b, epilogue=E.EPI_QUICKGELU)
 if "all" in what or "gemv" in what:      # the decode step's dominant kernel: gate|up GEMV, batch 64 (the bench default), tile-layout weights, fp32 partial rows

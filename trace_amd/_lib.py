@@ -22,6 +22,7 @@ class TraceConfigC(C.Structure):
         ("slot_eps", C.c_float), ("slot_rope_base", C.c_float),
         ("max_frames", C.c_int32), ("max_ctx", C.c_int32), ("max_batch", C.c_int32), ("max_new_tokens", C.c_int32),
         ("projector_type", C.c_int32),
+        ("vit_batch_frames", C.c_int32),
     ]
 
 
@@ -40,6 +41,7 @@ SIGNATURES = {
     "trace_slot_pool": (I, [P, P, I, P, P]),
     "trace_stc_connector": (I, [P, P, I, P, C.POINTER(I), P]),
     "trace_encode_video": (I, [P, P, I, I, P, P, P]),
+    "trace_encode_features": (I, [P, P, I, P, P, P]),
     "trace_splice_embeds": (I, [P, P, I, P, I, P, I, C.POINTER(I), P, P]),
     "trace_llm_prefill": (I, [P, I, P, I, P, P]),
     "trace_llm_prefill_pair": (I, [P, I, P, P, I, P]),

@@ -38,6 +38,7 @@ struct trace_ctx {
     int vh, vi, vL, vheads, G, GG, NT, P, Kpatch, Kpad, tokpad;
     int S, TPF;                      // slots per frame, tokens per frame (slots + 6)
     int max_ctx, max_B, ctx_pad;
+    int vit_frames;                  // frames one trace_vit_forward call may take (>= max_frames)
     std::vector<void*> allocs;
     size_t total_bytes = 0;
     std::unordered_map<std::string, int> loaded;
@@ -86,7 +87,7 @@ struct trace_ctx {
     hipEvent_t gev0 = nullptr, gev1 = nullptr;   // pair recorded from inside the captured graph
     double ksum_ms = 0.0; int ksamples = 0;
     hipEvent_t mev0 = nullptr, mev1 = nullptr;   // bracket of one ViT fc1 GEMM launch per trace_vit_forward (profile == 2)
-    double msum_ms = 0.0; int msamples = 0; double mflops = 0.0;
+    double msum_ms = 0.0; int msamples = 0; double mflops = 0.0; int mM = 0;
     float prof[8] = {0};
 };
 
@@ -125,6 +126,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     c->Kpatch = 3 * c->P * c->P; c->Kpad = round_up(c->Kpatch, 64); c->tokpad = round_up(c->NT, 64);
     c->S = cfg->num_slots; c->TPF = c->S + 6;
     c->max_ctx = cfg->max_ctx; c->max_B = cfg->max_batch; c->ctx_pad = round_up(c->max_ctx, 64);
+    c->vit_frames = cfg->vit_batch_frames > cfg->max_frames ? cfg->vit_batch_frames : cfg->max_frames;
     auto bad = [&](const char* m) { delete c; return fail(TRACE_ERR_ARG, m); };
     if (c->HD != 128 || c->NQ != 4 * c->NKV) return bad("LLM kernels need head_dim 128 and 4:1 GQA");
     if (c->vh / c->vheads != 64) return bad("ViT kernels need head_dim 64");
@@ -185,10 +187,10 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     c->layer_stride = c->slot_stride * c->max_B;
     A(c->kcache, c->layer_stride * c->NL); A(c->vcache, c->layer_stride * c->NL);
     // --- ViT workspaces ---
-    const size_t Tm = cfg->max_frames, Mv = Tm * c->NT;
-    A(c->vX, Mv * vh); A(c->vH, Mv * vh); A(c->vQKV, Mv * 3 * vh); A(c->vVT, Tm * vh * c->tokpad);
+    const size_t Tm = cfg->max_frames, Tv_ = c->vit_frames, Mv = Tv_ * c->NT;      // tower workspaces: vit_batch_frames at a time
+    A(c->vX, Mv * vh); A(c->vH, Mv * vh); A(c->vQKV, Mv * 3 * vh); A(c->vVT, Tv_ * vh * c->tokpad);
     {
-        const size_t mlp = Mv * vi, im2 = Tm * c->GG * c->Kpad;
+        const size_t mlp = Mv * vi, im2 = Tv_ * c->GG * c->Kpad;
         A(c->vMLP, mlp > im2 ? mlp : im2);
     }
     A(c->sl_res, Tm * c->S * vh); A(c->sl_out, Tm * c->S * H);
@@ -465,7 +467,7 @@ static int gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* C, i
 
 extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dtype, int T, void* feats_out, void* stream) {
     if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
-    if (!frames || T < 1 || T > c->c.max_frames) return fail(TRACE_ERR_ARG, "bad frames / T");
+    if (!frames || T < 1 || T > c->vit_frames) return fail(TRACE_ERR_ARG, "bad frames / T (more than max_frames / vit_batch_frames)");
     hipStream_t s = (hipStream_t)stream;
     const int vh = c->vh, vi = c->vi, NT = c->NT, GG = c->GG, Mv = T * NT;
     bf16_t* im2 = c->vMLP;                       // [T*GG, Kpad]
@@ -490,13 +492,16 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
         LCHK(launch_attn_vit(a, s));
         TRY(gemm(c->vH, vh, L.wo, vh, c->vX, vh, L.bo, c->vX, vh, Mv, vh, vh, EPI_RESIDUAL, s));
         LCHK(launch_layernorm(c->vX, vh, c->vH, vh, L.ln2w, L.ln2b, Mv, vh, c->c.v_eps, s));
-        const bool probe = (l == 0 && c->profile == 2);      // MFMA roofline probe: HIP events around ONE fc1 GEMM launch
+        // MFMA roofline probe: HIP events around ONE fc1 GEMM launch per call — of the largest shape seen since
+        // trace_set_profile only (the short tail call of a frame stream would mix two shapes into one average)
+        if (l == 0 && c->profile == 2 && Mv > c->mM) { c->mM = Mv; c->msum_ms = 0.0; c->msamples = 0; }
+        const bool probe = (l == 0 && c->profile == 2 && Mv == c->mM);
         if (probe) hipEventRecord(c->mev0, s);
         TRY(gemm(c->vH, vh, L.w1, vh, c->vMLP, vi, L.b1, nullptr, 0, Mv, vi, vh, EPI_QUICKGELU, s));
         if (probe) { hipEventRecord(c->mev1, s); c->mflops = 2.0 * Mv * (double)vi * vh; }
         TRY(gemm(c->vMLP, vi, L.w2, vi, c->vX, vh, L.b2, c->vX, vh, Mv, vh, vi, EPI_RESIDUAL, s));
     }
-    if (c->profile == 2 && c->vL > 0) {
+    if (c->profile == 2 && c->vL > 0 && Mv == c->mM) {
         hipEventSynchronize(c->mev1);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->mev0, c->mev1) == hipSuccess) { c->msum_ms += ms; c->msamples += 1; }
@@ -581,12 +586,10 @@ extern "C" int trace_stc_connector(trace_ctx* c, const void* feats, int T, void*
     return TRACE_OK;
 }
 
-extern "C" int trace_encode_video(trace_ctx* c, const void* frames, int frames_dtype, int T, const int32_t* time_ids,
-                                  void* video_out, void* stream) {
-    if (!time_ids) return fail(TRACE_ERR_ARG, "null time_ids");
+// slot pool on `feats` (nullptr = the tower's internal buffer) + the per-frame time-token rows -> c->video
+static int encode_tail(trace_ctx* c, const void* feats, int T, const int32_t* time_ids, void* video_out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    TRY(trace_vit_forward(c, frames, frames_dtype, T, nullptr, stream));
-    TRY(trace_slot_pool(c, nullptr, T, nullptr, stream));
+    TRY(trace_slot_pool(c, feats, T, nullptr, stream));
     const int rows = T * c->TPF;
     HIPCHK(hipStreamSynchronize(s));        // pinned staging buffer reuse
     for (int t = 0; t < T; ++t)
@@ -607,6 +610,19 @@ extern "C" int trace_encode_video(trace_ctx* c, const void* frames, int frames_d
     c->video_rows = rows;
     if (video_out) HIPCHK(hipMemcpyAsync(video_out, c->video, (size_t)rows * c->H * 2, hipMemcpyDeviceToDevice, s));
     return TRACE_OK;
+}
+
+extern "C" int trace_encode_video(trace_ctx* c, const void* frames, int frames_dtype, int T, const int32_t* time_ids,
+                                  void* video_out, void* stream) {
+    if (!time_ids) return fail(TRACE_ERR_ARG, "null time_ids");
+    if (c && T > c->c.max_frames) return fail(TRACE_ERR_ARG, "bad T (more frames than max_frames)");
+    TRY(trace_vit_forward(c, frames, frames_dtype, T, nullptr, stream));
+    return encode_tail(c, nullptr, T, time_ids, video_out, stream);
+}
+
+extern "C" int trace_encode_features(trace_ctx* c, const void* feats, int T, const int32_t* time_ids, void* video_out, void* stream) {
+    if (!time_ids || !feats) return fail(TRACE_ERR_ARG, "null feats / time_ids");
+    return encode_tail(c, feats, T, time_ids, video_out, stream);
 }
 
 extern "C" int trace_splice_embeds(trace_ctx* c, const int32_t* ids, int n_ids, const int32_t* time_rows, int n_time,
@@ -988,7 +1004,7 @@ extern "C" int trace_decode_feed(trace_ctx* c, const int32_t* tokens, int B, voi
 
 extern "C" int trace_set_profile(trace_ctx* c, int on) {
     if (!c) return fail(TRACE_ERR_ARG, "null ctx");
-    c->profile = on; c->ksum_ms = 0.0; c->ksamples = 0; c->kev_used = 0; c->msum_ms = 0.0; c->msamples = 0;
+    c->profile = on; c->ksum_ms = 0.0; c->ksamples = 0; c->kev_used = 0; c->msum_ms = 0.0; c->msamples = 0; c->mM = 0;
     return TRACE_OK;
 }
 extern "C" int trace_get_profile(trace_ctx* c, float* out, int n) {

@@ -29,7 +29,7 @@ def _i32(seq) -> "C.Array":
 
 class TraceEngine:
     def __init__(self, cfg: TraceConfig, device: int = 0, max_batch: int = 1, max_ctx: Optional[int] = None,
-                 max_frames: Optional[int] = None, max_new_tokens: int = 1024):
+                 max_frames: Optional[int] = None, max_new_tokens: int = 1024, vit_batch_frames: Optional[int] = None):
         if not torch.cuda.is_available():
             raise _lib.TraceHipError("no HIP device visible: the TRACE hot path only runs on an MI355X (no CPU fallback)")
         self.lib = _lib.load()
@@ -42,19 +42,32 @@ class TraceEngine:
                    else max_frames * cfg.tokens_per_frame)
             max_ctx = min(cfg.max_position_embeddings, vis + 1024 + max_new_tokens)
         self.max_batch, self.max_ctx, self.max_frames, self.max_new_tokens = max_batch, max_ctx, max_frames, max_new_tokens
+        if vit_batch_frames is None:
+            vit_batch_frames = self.full_round_frames(cfg) if max_batch > 1 else max_frames
+        self.vit_batch_frames = max(int(vit_batch_frames), max_frames)
         c = _lib.TraceConfigC(
             cfg.vocab_size, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.num_attention_heads,
             cfg.num_key_value_heads, cfg.time_vocab_size, cfg.score_vocab_size, cfg.rms_norm_eps, cfg.rope_theta,
             cfg.vision_hidden_size, cfg.vision_intermediate_size, cfg.vision_layers_used, cfg.vision_num_heads,
             cfg.vision_image_size, cfg.vision_patch_size, cfg.vision_layer_norm_eps, cfg.num_slots, cfg.slot_ln_eps,
             cfg.slot_rope_base, max_frames, max_ctx, max_batch, max_new_tokens,
-            1 if cfg.mm_projector_type == "stc_connector" else 0)
+            1 if cfg.mm_projector_type == "stc_connector" else 0, self.vit_batch_frames)
         h = C.c_void_p()
         _lib.check(self.lib.trace_ctx_create(C.byref(c), device, C.byref(h)))
         self.h = h
         self.time_tower, self.score_tower = TimeTower(), ScoreTower()
         self._B = 0
         self._max_new = 0
+
+    @staticmethod
+    def full_round_frames(cfg: TraceConfig) -> int:
+        """Frames per ViT call when several videos are encoded together: the largest count whose token rows fill 384 row
+        tiles of 256 (170 frames x 577 tokens = 383.2 tiles), so that every ViT GEMM — 4 / 12 / 16 column tiles — runs in
+        whole rounds of the 256 CUs (6 / 18 / 24) while the fc1 input panel (201 MB) still fits the 256 MB Infinity Cache.
+        One 128-frame video alone is 289 row tiles: 4.5 / 13.5 / 18.1 rounds, the last round of each launch half empty.
+        Measured (tools/vit_chunk_sweep.py, tower ms per video): 128 -> 55.0, 170 -> 53.9, 227 (512 tiles; the fc1 panel
+        spills the cache: 931 vs 979 TFLOP/s on that launch) -> 53.6, 64 -> 58.6."""
+        return max(1, min(256, (384 * 256) // cfg.vision_tokens))
 
     def close(self):
         if getattr(self, "h", None):
@@ -160,6 +173,55 @@ class TraceEngine:
         _lib.check(self.lib.trace_encode_video(self.h, _ptr(frames), dt, T, ids, _ptr(out), _stream()))
         return out
 
+    def encode_features(self, feats: torch.Tensor, timestamps, want_output: bool = False):
+        """encode_video from ViT features computed earlier (vit_forward on a frame batch that may span several videos)"""
+        T = feats.shape[0]
+        assert feats.dtype == torch.bfloat16 and feats.is_cuda and feats.is_contiguous()
+        ids = _i32(self.time_ids(timestamps))
+        out = None
+        if want_output:
+            out = torch.empty((T * self.cfg.tokens_per_frame, self.cfg.hidden_size), dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.trace_encode_features(self.h, _ptr(feats), T, ids, _ptr(out), _stream()))
+        return out
+
+    def vit_forward_many(self, videos: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """ViT features of several videos, the frames pushed through the tower `vit_batch_frames` at a time regardless of
+        video boundaries (per-frame arithmetic: identical to per-video calls).  Returns one [T_v, patches, v_hidden] view
+        per video."""
+        vids = [self._frames(v) for v in videos]
+        dts = {dt for _, dt in vids}
+        if len(dts) != 1:
+            raise ValueError("all videos of a batch must share one frame dtype")
+        dt = dts.pop()
+        counts = [v.shape[0] for v, _ in vids]
+        total = sum(counts)
+        feats = torch.empty((total, self.cfg.vision_patches, self.cfg.vision_hidden_size), dtype=torch.bfloat16, device=self.device)
+        F = self.vit_batch_frames
+        pos, chunk, chunk_n = 0, [], 0          # gather frames into chunks of F (a copy only when a chunk spans videos)
+        def flush():
+            nonlocal chunk, chunk_n, pos
+            if not chunk_n:
+                return
+            x = chunk[0] if len(chunk) == 1 else torch.cat(chunk, dim=0)
+            _lib.check(self.lib.trace_vit_forward(self.h, _ptr(x.contiguous()), dt, chunk_n, _ptr(feats[pos:pos + chunk_n]), _stream()))
+            pos += chunk_n
+            chunk, chunk_n = [], 0
+        for v, _ in vids:
+            o = 0
+            while o < v.shape[0]:
+                n = min(F - chunk_n, v.shape[0] - o)
+                chunk.append(v[o:o + n])
+                chunk_n += n
+                o += n
+                if chunk_n == F:
+                    flush()
+        flush()
+        out, o = [], 0
+        for n in counts:
+            out.append(feats[o:o + n])
+            o += n
+        return out
+
     def splice(self, input_ids: Sequence[int], time_rows: Sequence[int] = (), score_rows: Sequence[int] = (),
                want_output: bool = False):
         ids = _i32(input_ids)
@@ -242,8 +304,27 @@ class TraceEngine:
             raise ValueError(f"batch {B} exceeds engine max_batch {self.max_batch}")
         # prefill: neighbours whose spliced prompts have the same length share one pass (M = 2L fills the GEMM tile grid)
         held = None                                   # (slot, spliced embeds) waiting for a partner
+        feats = None
+        if B > 1 and self.vit_batch_frames > self.max_frames and self.cfg.mm_projector_type != "stc_connector":
+            feats = []                                # the tower runs over groups of videos (whole GEMM rounds); 12 GB of features at a time
+            per_frame = self.cfg.vision_patches * self.cfg.vision_hidden_size * 2
+            g0 = 0
+            while g0 < B:
+                g1, nbytes = g0, 0
+                while g1 < B and (g1 == g0 or nbytes + videos[g1].shape[0] * per_frame <= 12 << 30):
+                    nbytes += videos[g1].shape[0] * per_frame
+                    g1 += 1
+                feats.append((g0, g1))
+                g0 = g1
+            groups, feats = feats, {}
         for b in range(B):
-            self.encode_video(videos[b], timestamps[b])
+            if feats is not None:
+                if b not in feats:
+                    g = next(g for g in groups if g[0] <= b < g[1])
+                    feats = dict(zip(range(g[0], g[1]), self.vit_forward_many(videos[g[0]:g[1]])))
+                self.encode_features(feats.pop(b), timestamps[b])
+            else:
+                self.encode_video(videos[b], timestamps[b])
             if b + 1 < B or held is not None:
                 L, emb = self.splice(input_ids[b], want_output=True)
                 if held is not None and held[1].shape[0] == L and held[0] + 1 == b:

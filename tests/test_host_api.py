@@ -266,3 +266,18 @@ def test_create_photo_grid(G):
     for c in G["create_photo_grid"]:
         arr = np.arange(c["t"] * 2 * 3 * 3, dtype=np.uint8).reshape(c["t"], 2, 3, 3)
         assert mm_utils.create_photo_grid(arr, c["rows"], c["cols"]).tolist() == c["out"], (c["t"], c["rows"], c["cols"])
+
+
+def test_tower_call_size_fills_whole_gemm_rounds():
+    """Host logic of the frame-stream tower: the default frames-per-call makes the token rows an (almost) exact multiple of
+    64 row tiles, so the 4 / 12 / 16-column-tile ViT GEMMs run in whole rounds of the 256 CUs, and keeps the fc1 input panel
+    inside the 256 MB Infinity Cache."""
+    from trace_amd import config as tcfg
+    from trace_amd.engine import TraceEngine
+    cfg = tcfg.trace_7b(128)
+    F = TraceEngine.full_round_frames(cfg)
+    assert F == 170
+    tiles = -(-F * cfg.vision_tokens // 256)
+    assert tiles == 384 and all((tiles * n) % 256 == 0 for n in (4, 12, 16))
+    assert F * cfg.vision_tokens * cfg.vision_hidden_size * 2 < 256 << 20
+    assert TraceEngine.full_round_frames(tcfg.tiny()) == 256          # capped

@@ -1,6 +1,5 @@
-"""(needs the hooks described in experiments/README.md)  gemm_pipe.hip (variant 4: persistent tiles, epilogue hidden under the next tile's K loop) against gemm.hip's 256x256
-kernel (variant 3) on the ViT / prefill shapes: results (bit-identical for EPI_NONE / EPI_RESIDUAL, one extra bf16 rounding
-before QuickGELU) and time per launch."""
+"""gemm_ldr.hip (variant 4 = the default for 256x256 tiles: 8 MFMA + 4 loader waves) against gemm.hip's own 256x256 kernel
+(variant 3) on the ViT / prefill shapes: results must be bit-identical; time per launch and TFLOP/s of both."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trace_amd import engine as E

@@ -1025,7 +1025,7 @@ extern int g_skinny_debug;
 extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 100 && variant < 104) { g_attn_debug = variant - 100; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }   // microbench: attention phase cut-offs
-    if (variant < 0 || variant > 3) return fail(TRACE_ERR_ARG, "variant must be 0..3");
+    if (variant < 0 || variant > 4) return fail(TRACE_ERR_ARG, "variant must be 0..4");
     g_gemm_variant = variant;
     return TRACE_OK;
 }

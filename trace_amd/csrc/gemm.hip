@@ -5,8 +5,8 @@
 // Operands are fed swapped (D^T = W.A^T) so each lane ends up with 4 consecutive output columns of one row; the
 // tile is then staged through LDS and leaves as full 16-byte row-contiguous stores (bias / QuickGELU / SwiGLU are
 // applied in fp32 registers first, the residual is added at the coalesced stage).
-// Two tile shapes: 256x256 (8 waves, 1 workgroup/CU) for the big ViT / gate|up GEMMs, 128x128 (4 waves) when a
-// 256-tiling would leave CUs idle (LLM prefill M ~ 2k with N = 4096).
+// Two tile shapes: 256x256 (1 workgroup/CU) for the big ViT / gate|up GEMMs — run by gemm_ldr.hip's loader-wave version of this
+// file's kernel since the end of round 1 — and 128x128 (4 waves) when a 256-tiling would leave CUs idle (LLM prefill M ~ 2k with N = 4096).
 #include "common.h"
 #include "kernels.h"
 
@@ -287,7 +287,7 @@ int launch_glds(const GemmArgs& p, int epi, hipStream_t s) {
 
 }  // namespace
 
-int g_gemm_variant = 0;   // 0 = auto, 2 = 128^2 tiles, 3 = 256^2 tiles (tests / microbench)
+int g_gemm_variant = 0;   // 0 = auto, 2 = 128^2 tiles, 3 = this file's 256^2 kernel, 4 = the loader-wave 256^2 kernel (tests / microbench)
 
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
     if (p.M <= 0 || p.N % BN || p.K % BK || p.K < BK) return TRACE_ERR_ARG;
@@ -302,6 +302,9 @@ int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
             const long rounds = (blocks256 + 255) / 256;
             v = (p.N % 256 == 0 && p.M >= 1024 && blocks256 >= 200 && blocks256 * 5 >= rounds * 256 * 4) ? 3 : 2;
         }
+        // 256^2 tiles chosen automatically run on the loader-wave kernel (gemm_ldr.hip: same results bit for bit, +20-24 % on the
+        // K = 1024 ViT shapes); variant 3 forces this file's kernel for A/B runs
+        if (p.N % 256 == 0 && (g_gemm_variant == 4 || (g_gemm_variant == 0 && v == 3))) return launch_gemm_ldr(p, epi, s);
         if (v == 3 && p.N % 256 == 0) return launch_glds<256, 256, 2, 4>(p, epi, s);
     }
     return launch_glds<128, 128, 2, 2>(p, epi, s);

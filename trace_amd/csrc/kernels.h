@@ -18,6 +18,7 @@ struct GemmArgs {
     unsigned long long* trace;      // profiling only (tools/gemm_trace.py): 8 x u64 per workgroup, or null
 };
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s);
+int launch_gemm_ldr(const GemmArgs& p, int epi, hipStream_t s);    // gemm_ldr.hip: 256x256 tiles, 8 MFMA + 4 loader waves (N % 256 == 0)
 
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_SIGMOID = 2, ACT_GELU = 3 };
 

@@ -296,11 +296,13 @@ int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
     {
         int v = g_gemm_variant;
         if (v == 0) {
-            // 256^2 tiles (one workgroup per CU) when they fill whole rounds of the 256 CUs reasonably well; otherwise the
-            // 128^2 kernel (two workgroups per CU) — e.g. the paired-prefill qkv GEMM, 384 tiles = 1.5 rounds: 233 vs 193 us
+            // 256^2 tiles (one workgroup per CU, loader-wave kernel) when they fill at least 70 % of their rounds of the 256 CUs;
+            // otherwise the 128^2 kernel (two workgroups per CU).  Measured (us, 128^2 vs loader-wave 256^2; tools/gemm_variant_check.py):
+            // 192 tiles = 0.75 round (single-prompt qkv) 101 vs 84; 384 = 1.5 rounds (paired qkv) 182 vs 176; 128 = half a round
+            // (single-prompt o / down) 64 vs 79 and 211 vs 250.  All three kernels give the same bits (same K order).
             const long blocks256 = (long)((p.M + 255) / 256) * (p.N / 256);
             const long rounds = (blocks256 + 255) / 256;
-            v = (p.N % 256 == 0 && p.M >= 1024 && blocks256 >= 200 && blocks256 * 5 >= rounds * 256 * 4) ? 3 : 2;
+            v = (p.N % 256 == 0 && p.M >= 1024 && blocks256 * 10 >= rounds * 256 * 7) ? 3 : 2;
         }
         // 256^2 tiles chosen automatically run on the loader-wave kernel (gemm_ldr.hip: same results bit for bit, +20-24 % on the
         // K = 1024 ViT shapes); variant 3 forces this file's kernel for A/B runs

@@ -44,6 +44,9 @@ __device__ __forceinline__ int swz(int row, int kc) { return row * 128 + ((kc ^ 
 // (6) operand panels read K-tile-contiguously (what a tiled producer layout would give; timing experiment on the same
 // bytes): +2-4 % only — unlike the decode GEMV, these panels come from L2 / infinity cache, not DRAM pages.
 // Per-tile cost after the epilogue fixes (tools/gemm_trace.py): ~8 us fixed + ~1.7 us per K-tile.
+// (7) What did work: LOADER WAVES — gemm_ldr.hip is this kernel with the LDS-DMA issue moved to four extra waves (+20-24 % on
+// the K = 1024 shapes, bit-identical); the reason (1)-(5) changed nothing is that in all of them the waves that wait on the
+// address path are the waves that should be issuing MFMAs.
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     constexpr int NW = WM * WN, NTHR = NW * 64;

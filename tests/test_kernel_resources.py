@@ -1,0 +1,72 @@
+"""Compile-time guard on the register budget of the hot kernels (no GPU needed: hipcc cross-compiles gfx950 and reports
+per-kernel resources with -Rpass-analysis=kernel-resource-usage).
+
+The designs depend on exact budgets — the loader-wave GEMM is 12 waves per CU = 3 per SIMD, i.e. at most 168 registers per wave
+with the 128 accumulators + fragments of an MFMA wave just fitting; the decode attention needs 3 workgroups per CU — and a spill
+to scratch inside those loops is a silent 10-30 % loss, not a failure.  This test fails when an edit pushes a kernel over."""
+import concurrent.futures as cf
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "trace_amd", "csrc")
+
+
+def _resources(name, tmp):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c", os.path.join(CSRC, name + ".hip"),
+           "-I", CSRC, "-o", os.path.join(tmp, name + ".o"), "-Rpass-analysis=kernel-resource-usage"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" ")[0]] = int(m.group(2))
+    return out
+
+
+@pytest.fixture(scope="module")
+def res(tmp_path_factory):
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    tmp = str(tmp_path_factory.mktemp("kres"))
+    names = ["gemm_ldr", "gemm", "attn", "decode"]
+    with cf.ThreadPoolExecutor(max_workers=4) as ex:
+        return dict(zip(names, ex.map(lambda n: _resources(n, tmp), names)))
+
+
+def _pick(d, sub):
+    ks = {k: v for k, v in d.items() if sub in k}
+    assert ks, (sub, list(d)[:5])
+    return ks
+
+
+def test_loader_wave_gemm_fits_three_waves_per_simd(res):
+    for k, v in _pick(res["gemm_ldr"], "gemm_ldr_kernel").items():
+        assert v["VGPRs"] + v.get("AGPRs", 0) <= 168 and v["Occupancy"] >= 3, (k, v)
+        assert v["ScratchSize"] <= 16, (k, v)           # a couple of address registers at most; nothing in the K loop
+
+
+def test_plain_gemm_kernels_do_not_spill(res):
+    for k, v in _pick(res["gemm"], "gemm_glds_kernel").items():
+        assert v["ScratchSize"] == 0 and v["VGPRs"] <= 256, (k, v)
+
+
+def test_attention_kernels_keep_their_occupancy(res):
+    for k, v in _pick(res["attn"], "attn_kernel").items():
+        assert v["ScratchSize"] == 0 and v["Occupancy"] >= 2, (k, v)
+    for k, v in _pick(res["decode"], "attn_decode_kernel").items():
+        assert v["ScratchSize"] == 0 and v["Occupancy"] >= 3, (k, v)
+
+
+def test_decode_gemv_does_not_spill(res):
+    for k, v in _pick(res["decode"], "skinny_lds_kernel").items():
+        assert v["ScratchSize"] == 0, (k, v)

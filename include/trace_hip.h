@@ -105,11 +105,17 @@ int trace_llm_prefill(trace_ctx* ctx, int slot, const void* embeds, int L, void*
  * trace_llm_prefill calls. */
 int trace_llm_prefill_pair(trace_ctx* ctx, int slot0, const void* embeds0, const void* embeds1, int L, void* stream);
 
+/* The head stage of forward() for EVERY position (trace_mistral.py:190-252: lm_head | sync_head | time_head | score_head, fp32,
+ * everything outside head `head`'s id range set to -inf): hidden [R, hidden] bf16 device = the hidden_out of trace_llm_prefill ->
+ * logits_out [R, V+1+Tv+Sv] fp32 device.  The decode loop needs the last row only and gets it from trace_decode_begin / _steps. */
+int trace_llm_head_logits(trace_ctx* ctx, const void* hidden, int R, int head, float* logits_out, void* stream);
+
 /* generate() = greedy loop with head switching (trace_mistral.py:268-347 + HF greedy search).
  * begin: sequences = the given KV slots (each prefilled); heads[b] in {0 text,1 time,2 score} (callers pass [1]);
  *        computes token 0 from the prefill hidden state.  forced: HOST [B, max_new] teacher-forcing ids or NULL.
  *        eos < 0 disables the stop.  logits_out (device fp32 [B, V+1+Tv+Sv], may be NULL) = masked logits of step 0.
- * steps: runs n more decode steps entirely on device (use_graph: hipGraph replay; logits_out only with n == 1).
+ * steps: runs n more decode steps entirely on device (use_graph: hipGraph replay; logits_out only with n == 1).  At most
+ *        max_new - 1 steps in total after one begin (every step appends a KV row; TRACE_ERR_STATE beyond).
  * read : synchronises and copies ids [B, max_new] / lengths [B] / current heads [B] to HOST buffers. */
 int trace_decode_begin(trace_ctx* ctx, const int32_t* slots, int B, const int32_t* heads, int max_new, int eos,
                        const int32_t* forced, float* logits_out, void* stream);

@@ -454,6 +454,144 @@ def deep_llm_goldens(tmp):
     print("deep_llm: L=%d steps=%d logit std %.3f" % (L, len(tf_argmax), tf_logits[torch.isfinite(tf_logits)].std().item()))
 
 
+def mr_forced_ids(cfg, n=31):
+    """The moment-retrieval answer shape (trace/eval/evaluate.py:298-357 with prompts/mr.txt: one event): 14 time-head tokens
+    ('dddd.d<sep>dddd.d' + time <sync>), 4 score-head tokens ('d.d' + score <sync>), then caption text and the text <sync>."""
+    V, Tv = cfg.vocab_size, cfg.time_vocab_size
+    t0, s0 = V + 1, V + Tv + 1
+    dig = lambda base, s: [base + {"<sync>": 0, "<sep>": 1, ".": 12, **{str(i): i + 2 for i in range(10)}}[c] for c in s]
+    seq = dig(t0, "0003.7") + [t0 + 1] + dig(t0, "0011.2") + [t0]            # 14 on the time head
+    seq += dig(s0, "4.0") + [s0]                                              # 4 on the score head
+    seq += [(17 * k + 5) % (V - 3) + 3 for k in range(n - 19)] + [V]          # text, then the text <sync>
+    return seq[:n]
+
+
+def charades_goldens(tmp):
+    """BASELINE config 4 (Charades-STA moment retrieval): 64 (tiny-ViT) frames -> 896 visual rows, a 191-id prompt (the llama_2
+    template + prompts/mr.txt + a query is ~190 sentencepiece ids) -> prefill L = 1086 through one decoder layer at the real
+    Mistral-7B widths, then the 32-token timestamp-heavy answer teacher-forced (18 of 32 steps on the time / score heads)."""
+    import dataclasses
+    from trace_amd import config as tcfg, synth
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=64), intermediate_size=14336, num_hidden_layers=1)
+    model = build_reference_model(cfg, os.path.join(tmp, "charades"))
+    load_synth(model, cfg)
+    frames = synth.synth_frames(cfg, 3).to(torch.bfloat16).float()
+    ts = [[float(i) * 0.5] for i in range(cfg.num_frames)]
+    input_ids = synth.synth_prompt_ids(cfg, n_text=191, video_pos=150, seed=11)
+    forced = mr_forced_ids(cfg, 31)
+    tf_logits, tf_argmax, L = run_reference(model, cfg, input_ids, frames, ts, forced=forced)
+    assert L == 1086 and len(tf_argmax) == 32, (L, len(tf_argmax))
+    np.savez_compressed(os.path.join(OUT, "charades_ctx.npz"), input_ids=input_ids.numpy(), timestamps=np.array(ts, dtype=np.float64),
+                        forced_ids=np.array(forced), tf_logits=tf_logits.numpy().astype(np.float32), tf_argmax=np.array(tf_argmax),
+                        prefill_len=np.array(L), video_idx=np.array(3))
+    print("charades_ctx: L=%d steps=%d" % (L, len(tf_argmax)))
+
+
+def videomme_goldens(tmp):
+    """The BASELINE config 5 SHAPE in the reference's own precision: 256 (tiny-ViT) frames (trace/eval/videomme/evaluate.py:215-258
+    samples past constants.MAX_FRAMES = 128) -> 3584 visual rows, a 251-id prompt -> prefill L = 3834 through one real-width decoder
+    layer, then 16 teacher-forced tokens at contexts 3835...  The fp8 weight path of config 5 has no reference counterpart
+    (SURVEY section 5); its parity anchor is this bf16 result."""
+    import dataclasses
+    from trace_amd import config as tcfg, synth
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=256), intermediate_size=14336, num_hidden_layers=1)
+    model = build_reference_model(cfg, os.path.join(tmp, "videomme"))
+    load_synth(model, cfg)
+    frames = synth.synth_frames(cfg, 5).to(torch.bfloat16).float()
+    ts = [[float(i) * 2.0] for i in range(cfg.num_frames)]
+    input_ids = synth.synth_prompt_ids(cfg, n_text=251, video_pos=200, seed=13)
+    forced = scripted_ids(cfg)[:15]
+    tf_logits, tf_argmax, L = run_reference(model, cfg, input_ids, frames, ts, forced=forced)
+    assert L == 3834 and len(tf_argmax) == 16, (L, len(tf_argmax))
+    np.savez_compressed(os.path.join(OUT, "videomme_ctx.npz"), input_ids=input_ids.numpy(), timestamps=np.array(ts, dtype=np.float64),
+                        forced_ids=np.array(forced), tf_logits=tf_logits.numpy().astype(np.float32), tf_argmax=np.array(tf_argmax),
+                        prefill_len=np.array(L), video_idx=np.array(5))
+    print("videomme_ctx: L=%d steps=%d" % (L, len(tf_argmax)))
+
+
+@torch.no_grad()
+def run_reference_layer_streamed(cfg_full, tmp, input_ids, frames, ts, forced):
+    """Teacher-forced logits of the FULL-depth stack without holding it in RAM: the reference model is built with ONE decoder
+    layer; its own modules do the embedding splice (prepare_inputs_labels_for_multimodal, both branches), the layer
+    (`model.model.layers[0]`, the transformers MistralDecoderLayer the reference delegates to), the final norm and the four
+    heads with the head mask; only the loop over layers is restated here — layer l's synthetic weights are loaded into that one
+    module, applied to the whole teacher-forced sequence (prefill rows + the fed tokens: with every fed token known in advance
+    one causal pass over L + n rows gives, in fp32, what L-row prefill + n cached single-token steps give), and discarded.
+    Checked against the 8-layer fixture made by the unmodified reference forward() (deep_llm.npz) in `full_depth_goldens`."""
+    import dataclasses
+    from trace_amd import synth
+    cfg1 = dataclasses.replace(cfg_full, num_hidden_layers=1)
+    model = build_reference_model(cfg1, tmp)
+    load_synth(model, cfg1)                                    # embeddings, towers, ViT, slot pool, norm, heads (+ layer 0)
+    ids = input_ids.view(1, -1)
+    (_, _, _, embeds, _, _, _) = model.prepare_inputs_labels_for_multimodal(
+        ids, torch.ones_like(ids), None, None, [[frames], ["video"]], [[]], [[]], video_timestamps=[ts])
+    L = embeds.shape[1]
+    rows = [embeds[0]]
+    heads_at = [1]                                             # head that masks the logits at position L-1+i
+    h = 1
+    for t in forced:                                           # decode branch of the splice (trace_arch.py:345-375) per fed token
+        h = model.swap_tokens.get(int(t), h)
+        heads_at.append(h)
+        (_, _, _, e1, _, _, _) = model.prepare_inputs_labels_for_multimodal(
+            torch.tensor([[int(t)]]), torch.ones(1, L + len(rows), dtype=torch.long), [(torch.zeros(1, 1, L, 1),) * 2], None,
+            None, None, None, video_timestamps=None)
+        rows.append(e1[0])
+    x = torch.cat(rows, 0)[None]                               # [1, L+n, H]
+    N = x.shape[1]
+    pos = torch.arange(N)[None]
+    layer, mm = model.model.layers[0], model.model
+    pe = mm.rotary_emb(x, pos)
+    mask = torch.full((N, N), float("-inf")).triu(1)[None, None]
+    keys = [k for k in layer.state_dict().keys()]
+    specs = {sp[0]: sp for sp in synth.weight_specs(cfg_full)}
+    for l in range(cfg_full.num_hidden_layers):
+        sd = {}
+        for k in keys:
+            spec = specs[f"model.layers.{l}.{k}"]
+            sd[k] = synth.synth_tensor(spec[0], spec[1], spec[2], torch.bfloat16).float()
+        layer.load_state_dict(sd, strict=True)
+        out = layer(x, attention_mask=mask, position_ids=pos, position_embeddings=pe, use_cache=False)
+        x = out[0] if isinstance(out, tuple) else out
+        if x.dim() == 2:
+            x = x[None]
+    hs = mm.norm(x)[0, L - 1:]                                  # positions L-1 .. L-1+n
+    lg = torch.cat([model.lm_head(hs), model.sync_head(hs), model.time_head(hs), model.score_head(hs)], -1).float()
+    V, Tv, Sv = cfg_full.vocab_size, cfg_full.time_vocab_size, cfg_full.score_vocab_size
+    rng = [(0, V + 1), (V + 1, V + 1 + Tv), (V + 1 + Tv, V + 1 + Tv + Sv)]
+    for i, hh in enumerate(heads_at):                          # the head mask of trace_mistral.py:244-252
+        lo, hi = rng[hh]
+        lg[i, :lo] = float("-inf"); lg[i, hi:] = float("-inf")
+    return lg, L
+
+
+def full_depth_goldens(tmp):
+    """Depth: ALL 32 decoder layers at the real Mistral-7B widths (6.98 B decoder parameters) behind the tiny ViT, teacher-forced,
+    by the layer-streamed reference run above.  The harness is first run at 8 layers and must reproduce deep_llm.npz (made by the
+    unmodified reference forward()) to fp32 round-off."""
+    import dataclasses
+    from trace_amd import config as tcfg, synth
+    base = dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336)
+    frames = synth.synth_frames(base, 0).to(torch.bfloat16).float()
+    ts = [[float(i) * 2.5] for i in range(base.num_frames)]
+    input_ids = synth.synth_prompt_ids(base, n_text=24, video_pos=10)
+    forced = scripted_ids(base)
+    D = np.load(os.path.join(OUT, "deep_llm.npz"))
+    lg8, L8 = run_reference_layer_streamed(dataclasses.replace(base, num_hidden_layers=8), os.path.join(tmp, "fd8"), input_ids, frames, ts, forced)
+    ref8 = torch.from_numpy(D["tf_logits"])
+    fin = torch.isfinite(ref8)
+    assert torch.equal(fin, torch.isfinite(lg8)), "head mask pattern differs from the reference forward()"
+    err8 = (lg8[fin] - ref8[fin]).abs().max().item()
+    print("layer-streamed harness vs reference forward() at 8 layers: max |dlogit| = %.3e" % err8)
+    assert err8 < 2e-4, err8
+    lg, L = run_reference_layer_streamed(dataclasses.replace(base, num_hidden_layers=32), os.path.join(tmp, "fd32"), input_ids, frames, ts, forced)
+    masked = torch.where(torch.isfinite(lg), lg, torch.full_like(lg, -1e30))
+    np.savez_compressed(os.path.join(OUT, "full_depth_llm.npz"), input_ids=input_ids.numpy(), timestamps=np.array(ts, dtype=np.float64),
+                        forced_ids=np.array(forced), tf_logits=lg.numpy().astype(np.float32), tf_argmax=masked.argmax(-1).numpy(),
+                        prefill_len=np.array(L), harness_err_8_layers=np.array(err8))
+    print("full_depth_llm: L=%d steps=%d logit std %.3f" % (L, lg.shape[0], lg[torch.isfinite(lg)].std().item()))
+
+
 def preprocess_goldens():
     """Frame preprocessing of process_video (mm_utils.py:456-462): the reference's own expand2square + the HF
     CLIPImageProcessor it delegates to (PIL backend), on small synthetic frames, 'pad' and plain modes.  The processor is
@@ -505,6 +643,15 @@ if __name__ == "__main__":
     if "--deep-llm-only" in sys.argv:
         deep_llm_goldens(tmp)
         sys.exit(0)
+    if "--charades-only" in sys.argv:
+        charades_goldens(tmp)
+        sys.exit(0)
+    if "--videomme-only" in sys.argv:
+        videomme_goldens(tmp)
+        sys.exit(0)
+    if "--full-depth-only" in sys.argv:
+        full_depth_goldens(tmp)
+        sys.exit(0)
     int_goldens()
     fp_goldens(tmp)
     medium_goldens(tmp)
@@ -512,4 +659,7 @@ if __name__ == "__main__":
     long_ctx_goldens(tmp)
     real_vocab_goldens(tmp)
     deep_llm_goldens(tmp)
+    charades_goldens(tmp)
+    videomme_goldens(tmp)
+    full_depth_goldens(tmp)
     preprocess_goldens()

@@ -235,3 +235,48 @@ def test_real_vocab_matches_reference_fixture(golden_dir):
     _cmp_logits(lg[:, torch.from_numpy(M["cols"])].numpy(), M["sampled"])
     top = torch.topk(torch.where(torch.isfinite(lg), lg, torch.full_like(lg, -1e30)), 2, dim=-1)
     np.testing.assert_allclose(top.values.numpy(), M["top_val"], rtol=2e-4, atol=2e-4)
+
+
+def _ctx_case(golden_dir, name, frames, vid):
+    import dataclasses
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=frames), intermediate_size=14336, num_hidden_layers=1)
+    M = np.load(os.path.join(golden_dir, name))
+    assert int(M["video_idx"]) == vid
+    sd = {k: v.float() for k, v in synth.state_dict(cfg).items()}
+    ora = O.Oracle(cfg, sd, emulate_bf16=False)
+    fr = synth.synth_frames(cfg, vid).to(torch.bfloat16).float()
+    forced = M["forced_ids"].tolist()
+    ids, lg = ora.generate(torch.from_numpy(M["input_ids"]), fr, M["timestamps"].tolist(), head=1,
+                           max_new_tokens=len(forced) + 1, forced_ids=forced, return_logits=True)
+    assert ids == M["tf_argmax"].tolist()
+    _cmp_logits(lg.numpy(), M["tf_logits"])
+    return cfg, M, forced
+
+
+def test_charades_config_matches_reference_fixture(golden_dir):
+    """BASELINE config 4 (moment retrieval: 64 frames, prefill L = 1086, 32 new tokens of which 18 on the time / score heads),
+    one real-width decoder layer: oracle teacher-forced logits vs the reference's (trace/eval/evaluate.py:298-357 + prompts/mr.txt)."""
+    cfg, M, forced = _ctx_case(golden_dir, "charades_ctx.npz", 64, 3)
+    assert int(M["prefill_len"]) == 1086 and len(forced) + 1 == 32
+    V, Tv = cfg.vocab_size, cfg.time_vocab_size
+    heads = [1]
+    for t in forced:
+        heads.append({V: 1, V + 1: 2, V + Tv + 1: 0}.get(t, heads[-1]))
+    assert sum(h != 0 for h in heads[:31]) == 18 and heads[31] == 1      # 14 time-head + 4 score-head steps; the text <sync> re-opens the time head
+
+
+def test_videomme_shape_matches_reference_fixture(golden_dir):
+    """BASELINE config 5's shape in the reference's precision: 256 frames -> prefill L = 3834 + 16 tokens, one real-width layer."""
+    cfg, M, forced = _ctx_case(golden_dir, "videomme_ctx.npz", 256, 5)
+    assert int(M["prefill_len"]) == 3834 and len(forced) + 1 == 16
+
+
+def test_full_depth_fixture_is_self_consistent(golden_dir):
+    """full_depth_llm.npz (32 real-width layers, layer-streamed reference run): its generator reproduced the unmodified reference
+    forward() at 8 layers to fp32 round-off (recorded in the file), and the first steps' head-mask pattern / forced stream equal
+    the 8-layer fixture's.  (The 28 GB fp32 stack itself is out of reach of a CPU-suite oracle run; the 8-layer oracle pin is above.)"""
+    F, D = np.load(os.path.join(golden_dir, "full_depth_llm.npz")), np.load(os.path.join(golden_dir, "deep_llm.npz"))
+    assert float(F["harness_err_8_layers"]) < 2e-4
+    assert F["forced_ids"].tolist() == D["forced_ids"].tolist() and F["input_ids"].tolist() == D["input_ids"].tolist()
+    assert (np.isfinite(F["tf_logits"]) == np.isfinite(D["tf_logits"])).all()
+    assert int(F["prefill_len"]) == int(D["prefill_len"])

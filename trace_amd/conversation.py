@@ -1,10 +1,13 @@
 """Prompt assembly with the reference's interface (trace/conversation.py): `conv_templates[name].copy()`,
 `.append_message(role, msg)`, `.get_prompt()`, `.roles`, `.sep`, `.sep2`, `.sep_style`.
 
-The inference drivers use only the 'llama_2' template (trace/eval/evaluate.py:226,327-337; scripts/inference/
-inference.py:31); its output is pinned string-for-string by tests/golden/host_functions.json for the reference's five
-task prompts.  The other separator styles are implemented for completeness of the interface; templates that the
-inference path never selects are not reproduced."""
+SUPPORTED TEMPLATES: 'llama_2' only is verified — every inference driver selects it (trace/eval/evaluate.py:226,327-337;
+scripts/inference/inference.py:31) and its output is pinned string-for-string by tests/golden/host_functions.json for the
+reference's five task prompts.  'plain' carries the reference's values (conversation.py:420-428) but is not pinned.  The
+reference's other 15 chat templates (vicuna, mistral_instruct, mpt, qwen, llava_*; conversation.py:329-498) belong to
+training / chat front ends outside the accelerated path: `conv_templates[name]` raises a KeyError that says so, and
+`default_conversation` is llama_2 here (the reference's default, vicuna_v1, is never used by the inference drivers).
+The SeparatorStyle members exist because drivers compare against them (evaluate.py:337)."""
 from __future__ import annotations
 
 import dataclasses
@@ -70,27 +73,6 @@ class Conversation:
                 else:
                     out += " " + message + " " + self.sep2
             return out.lstrip(self.sep)
-        if st == SeparatorStyle.SINGLE:
-            out = self.system + self.sep
-            for role, message in msgs:
-                out += (role + ": " + _text(message) + self.sep) if message else (role + ":")
-            return out
-        if st == SeparatorStyle.TWO:
-            seps = [self.sep, self.sep2]
-            out = self.system + seps[0]
-            for i, (role, message) in enumerate(msgs):
-                out += (role + ": " + _text(message) + seps[i % 2]) if message else (role + ":")
-            return out
-        if st == SeparatorStyle.MPT:
-            out = self.system + self.sep
-            for role, message in msgs:
-                out += (role + _text(message) + self.sep) if message else role
-            return out
-        if st == SeparatorStyle.QWEN:
-            out = self.system + self.sep + "\n"
-            for role, message in msgs:
-                out += (role + _text(message) + self.sep + "\n") if message else role
-            return out
         if st == SeparatorStyle.PLAIN:
             seps = [self.sep, self.sep2]
             out = self.system
@@ -112,8 +94,14 @@ _LLAMA2_SYSTEM = (
 
 conv_llama_2 = Conversation(system=_LLAMA2_SYSTEM, roles=("USER", "ASSISTANT"), version="llama_v2", messages=[], offset=0,
                             sep_style=SeparatorStyle.LLAMA_2, sep="<s>", sep2="</s>")
-conv_plain = Conversation(system="", roles=("", ""), messages=[], offset=0, sep_style=SeparatorStyle.PLAIN, sep="", sep2="\n",
-                          version="plain")
+conv_plain = Conversation(system="", roles=("", ""), messages=[], offset=0, sep_style=SeparatorStyle.PLAIN, sep="\n", sep2=None)
 
-conv_templates = {"llama_2": conv_llama_2, "plain": conv_plain}
+
+class _Templates(dict):
+    def __missing__(self, name):
+        raise KeyError(f"conversation template {name!r} is not provided by trace_amd (supported: {sorted(self)}); the TRACE inference "
+                       "drivers use 'llama_2' — see the module docstring")
+
+
+conv_templates = _Templates({"llama_2": conv_llama_2, "plain": conv_plain})
 default_conversation = conv_llama_2

@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) void select_next_kernel(const float* __restric
         for (int w = 1; w < 4; ++w)
             if (sv[w] > v || (sv[w] == v && si[w] < idx)) { v = sv[w]; idx = si[w]; }
         int tok = idx;
-        if (advance) st.pos[b] += 1;
+        if (advance && step < max_new) st.pos[b] += 1;     // (the host bounds the step count too: engine.hip trace_decode_steps)
         int feed = tok;
         if (step < max_new) {
             const int f = st.forced[(size_t)b * max_new + step];

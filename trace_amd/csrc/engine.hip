@@ -74,9 +74,11 @@ struct trace_ctx {
     float* sk_ws = nullptr; unsigned int* sk_tickets = nullptr; size_t sk_ws_floats = 0; int sk_ntickets = 0;   // decode GEMV K-chunk partials
     float* part_val; int32_t* part_idx;
     int32_t *d_slots, *d_pos, *d_heads, *d_done, *d_out_ids, *d_out_len, *d_step, *d_forced, *d_params;
+    int32_t* d_heads_tmp;                // head id per row for trace_llm_head_logits
     int B = 0, max_new = 0, eos = -1, has_forced = 0, ntiles = 0, nsplit = 32;
     int slot_len[64] = {0};
     int host_mode = 0, fed = 0;        // host-driven token selection (sampling): head logits only, ids fed back by the host
+    int steps_done = 0;                // decode steps taken since trace_decode_begin (bounded by max_new - 1: the KV slot and the RoPE tables end at max_ctx)
     hipGraphExec_t graphs[SK_ROWS + 1] = {nullptr};   // one captured decode step per batch size
     hipStream_t cap_stream = nullptr;
     // profiling
@@ -222,7 +224,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     }
     c->ntiles = c->NVpad / 16;
     A(c->part_val, (size_t)SK_ROWS * c->ntiles); A(c->part_idx, (size_t)SK_ROWS * c->ntiles);
-    A(c->d_slots, SK_ROWS); A(c->d_pos, SK_ROWS); A(c->d_heads, SK_ROWS); A(c->d_done, SK_ROWS); A(c->d_out_len, SK_ROWS); A(c->d_step, 4); A(c->d_params, 4);
+    A(c->d_heads_tmp, SK_ROWS); A(c->d_slots, SK_ROWS); A(c->d_pos, SK_ROWS); A(c->d_heads, SK_ROWS); A(c->d_done, SK_ROWS); A(c->d_out_len, SK_ROWS); A(c->d_step, 4); A(c->d_params, 4);
     A(c->d_out_ids, (size_t)SK_ROWS * cfg->max_new_tokens); A(c->d_forced, (size_t)SK_ROWS * cfg->max_new_tokens);
 #undef A
     if (rc == TRACE_OK && hipHostMalloc((void**)&c->h_kind, Lm * 8) != hipSuccess) rc = fail(TRACE_ERR_HIP, "hipHostMalloc");
@@ -588,6 +590,7 @@ extern "C" int trace_stc_connector(trace_ctx* c, const void* feats, int T, void*
 
 // slot pool on `feats` (nullptr = the tower's internal buffer) + the per-frame time-token rows -> c->video
 static int encode_tail(trace_ctx* c, const void* feats, int T, const int32_t* time_ids, void* video_out, void* stream) {
+    if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
     hipStream_t s = (hipStream_t)stream;
     TRY(trace_slot_pool(c, feats, T, nullptr, stream));
     const int rows = T * c->TPF;
@@ -645,9 +648,11 @@ extern "C" int trace_splice_embeds(trace_ctx* c, const int32_t* ids, int n_ids, 
         } else if (id == -205) { c->h_kind[r] = 4; c->h_row[r] = 0; ++r; }
         else if (id == -203) {
             if (ti >= n_time || !time_rows) return fail(TRACE_ERR_ARG, "more <time> placeholders than time tokens");
+            if (time_rows[ti] < 0 || time_rows[ti] >= c->Tv) return fail(TRACE_ERR_ARG, "time token id out of range");     // nn.Embedding raises
             c->h_kind[r] = 2; c->h_row[r] = time_rows[ti++]; ++r;
         } else if (id == -204) {
             if (si >= n_score || !score_rows) return fail(TRACE_ERR_ARG, "more <score> placeholders than score tokens");
+            if (score_rows[si] < 0 || score_rows[si] >= c->Sv) return fail(TRACE_ERR_ARG, "score token id out of range");
             c->h_kind[r] = 3; c->h_row[r] = score_rows[si++]; ++r;
         } else {
             const int t = id < 0 ? 0 : id;      // torch.clamp(ids, min=0) (trace_arch.py:417)
@@ -655,6 +660,8 @@ extern "C" int trace_splice_embeds(trace_ctx* c, const int32_t* ids, int n_ids, 
             c->h_kind[r] = 0; c->h_row[r] = t; ++r;
         }
     }
+    // the masked assignment of trace_arch.py:426-427 fails with a shape mismatch unless every supplied token has its placeholder
+    if (ti != n_time || si != n_score) return fail(TRACE_ERR_ARG, "fewer <time>/<score> placeholders than supplied tokens");
     HIPCHK(hipMemcpyAsync(c->d_kind, c->h_kind, L * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_row, c->h_row, L * 4, hipMemcpyHostToDevice, s));
     GatherTabs tabs{};
@@ -822,6 +829,24 @@ extern "C" int trace_llm_prefill_pair(trace_ctx* c, int slot0, const void* embed
     return prefill_impl(c, slot0, 2, L, nullptr, s);
 }
 
+// masked logits of R final-norm hidden rows under ONE head: what forward() returns for every position of a sequence
+// (trace_mistral.py:190-252) — the decode loop itself only ever needs the last row (trace_decode_begin / _steps)
+extern "C" int trace_llm_head_logits(trace_ctx* c, const void* hidden, int R, int head, float* logits_out, void* stream) {
+    if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
+    if (!hidden || !logits_out || R < 1) return fail(TRACE_ERR_ARG, "bad hidden / logits_out / R");
+    if (head < 0 || head > 2) return fail(TRACE_ERR_ARG, "head must be 0, 1 or 2");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t h[SK_ROWS];
+    for (int i = 0; i < SK_ROWS; ++i) h[i] = head;
+    HIPCHK(hipMemcpyAsync(c->d_heads_tmp, h, sizeof(h), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const bf16_t* x = (const bf16_t*)hidden;
+    for (int r0 = 0; r0 < R; r0 += SK_ROWS)
+        LCHK(launch_head_logits(x + (size_t)r0 * c->H, c->H, c->wheads, c->H, c->d_heads_tmp, c->V, c->Tv, c->Sv, c->part_val, c->part_idx,
+                                logits_out + (size_t)r0 * c->NV, std::min(SK_ROWS, R - r0), s));
+    return TRACE_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ decode
 static StepState step_state(trace_ctx* c) {
     StepState st{};
@@ -913,7 +938,7 @@ extern "C" int trace_decode_begin(trace_ctx* c, const int32_t* slots, int B, con
     HIPCHK(hipMemsetAsync(c->d_out_ids, 0, (size_t)B * max_new * 4, s));
     const int32_t prm[3] = {max_new, eos, c->host_mode};
     HIPCHK(hipMemcpyAsync(c->d_params, prm, 12, hipMemcpyHostToDevice, s));
-    c->fed = 0;
+    c->fed = 0; c->steps_done = 0;
     if (forced) HIPCHK(hipMemcpyAsync(c->d_forced, forced, (size_t)B * max_new * 4, hipMemcpyHostToDevice, s));
     else HIPCHK(hipMemsetAsync(c->d_forced, 0xff, (size_t)B * max_new * 4, s));      // -1 = not forced
     // gather the prefill hidden rows of the chosen slots into dH, then head + select (no position advance)
@@ -928,6 +953,11 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
     if (n < 0) return fail(TRACE_ERR_ARG, "bad n");
     if (logits_out && (n != 1 || use_graph)) return fail(TRACE_ERR_ARG, "logits_out needs n == 1 and eager mode");
     if (c->host_mode && (n != 1 || use_graph)) return fail(TRACE_ERR_ARG, "host-select mode runs one eager step at a time");
+    // every step appends one KV row at pos[b]++; decode_begin checked pos + max_new <= max_ctx once, so the total is bounded here
+    if (c->steps_done + n > c->max_new - 1)
+        return fail(TRACE_ERR_STATE, "decode steps exceed max_new - 1 since trace_decode_begin (" + std::to_string(c->steps_done) + " taken, " +
+                                     std::to_string(n) + " requested, max_new " + std::to_string(c->max_new) + ")");
+    c->steps_done += n;
     hipStream_t s = (hipStream_t)stream;
     if (c->profile) hipEventRecord(c->ev0, s);
     if (!use_graph) {

@@ -241,6 +241,13 @@ class TraceEngine:
         _lib.check(self.lib.trace_llm_prefill(self.h, slot, _ptr(embeds), L, _ptr(hid), _stream()))
         return hid
 
+    def head_logits(self, hidden: torch.Tensor, head: int) -> torch.Tensor:
+        """masked fp32 logits [R, total_vocab] of final-norm hidden rows under one head (forward()'s logits at every position)"""
+        assert hidden.dtype == torch.bfloat16 and hidden.is_cuda and hidden.is_contiguous()
+        out = torch.empty((hidden.shape[0], self.cfg.total_vocab), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.trace_llm_head_logits(self.h, _ptr(hidden), hidden.shape[0], int(head), _ptr(out), _stream()))
+        return out
+
     def prefill_pair(self, slot0: int, embeds0: torch.Tensor, embeds1: torch.Tensor):
         """two spliced prompts of equal length -> KV slots slot0, slot0 + 1 in one pass (trace_llm_prefill_pair)"""
         assert embeds0.shape == embeds1.shape and embeds0.dtype == torch.bfloat16 and embeds0.is_cuda

@@ -101,6 +101,8 @@ class TraceMistralForCausalLM:
         if images_or_videos is None:
             raise NotImplementedError("text-only generation is outside the accelerated path")
         cfg, eng = self.config, self.engine
+        eng.host_mode(False)                    # a previous forward() leaves the engine armed for its decode form
+        self._live_kv = None
         ids = inputs if isinstance(inputs, torch.Tensor) else torch.tensor(inputs)
         if ids.dim() == 1:
             ids = ids.unsqueeze(0)
@@ -173,30 +175,101 @@ class TraceMistralForCausalLM:
                 if all(done) or step == max_new - 1:
                     break
                 if stopping:
+                    # HF StoppingCriteriaList: a row stops when ANY criterion fires for it; generate(inputs_embeds=...) hands the
+                    # criteria the generated ids only (the reference calls super().generate with inputs_embeds, trace_mistral.py:301-312)
                     cur, _ = eng.decode_read()
                     n = max(len(x) for x in cur)
-                    full = torch.cat([prompt_ids.cpu(), torch.tensor([x + [0] * (n - len(x)) for x in cur])], dim=1)
-                    if all(sc(full, None) for sc in stopping):
+                    gen = torch.tensor([x + [0] * (n - len(x)) for x in cur], dtype=torch.long)
+                    fired = torch.zeros(B, dtype=torch.bool)
+                    for sc in stopping:
+                        r = sc(gen, None)
+                        fired |= (r.view(-1).bool().cpu() if isinstance(r, torch.Tensor) else torch.full((B,), bool(r)))
+                    for b in range(B):
+                        done[b] = done[b] or bool(fired[b])
+                    if all(done):
                         break
                 lg = eng.decode_steps(1, use_graph=False, want_logits=True)
             return eng.decode_read()
         finally:
             eng.host_mode(False)
 
-    # ---- forward (trace_mistral.py:114-264), prefill form: last-position masked logits ----
+    # ---- forward (trace_mistral.py:114-264) ----
     @torch.no_grad()
-    def forward(self, input_ids=None, images=None, video_timestamps=None, heads=None, **kwargs):
-        if images is None or input_ids is None:
-            raise NotImplementedError("forward() is provided for the multimodal prefill form only")
-        vids, modals = images
-        eng = self.engine
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                labels=None, use_cache=None, images=None, times=None, scores=None, video_timestamps=None, heads=None, **kwargs):
+        """Both forms of the reference's forward():
+          * prefill form (`images=(videos, modal_list)`, `input_ids` with the modal placeholders): logits `[B, L, V']` fp32 for
+            EVERY position of the spliced sequence (`heads` given: V' = V+1+Tv+Sv with everything outside the row's head at
+            -inf; `heads=None`: the text|sync logits `[B, L, V+1]`, trace_mistral.py:190-193) and `past_key_values` = a handle
+            on the KV slots the rows were prefilled into;
+          * decode form (`input_ids [B, 1]` + that handle): the next-token embedding by id range (trace_arch.py:345-375), one
+            decoder step, logits `[B, 1, V']`.
+        Deviations, by design: `past_key_values` is an opaque handle (the cache lives in the engine, never in torch tensors);
+        rows of a batch must splice to one length (the reference pads); `labels` / `inputs_embeds` are training / internal
+        inputs and raise; in the decode form the active head is tracked on the device by the swap-token rule the reference's
+        `prepare_inputs_for_generation` applies (trace_mistral.py:336-344), so a `heads` argument that disagrees with it raises."""
+        if labels is not None or inputs_embeds is not None:
+            raise NotImplementedError("forward(labels= / inputs_embeds=) belongs to training; outside the accelerated path")
+        if input_ids is None:
+            raise ValueError("input_ids is required")
+        eng, cfg = self.engine, self.config
         ids = input_ids if input_ids.dim() == 2 else input_ids.unsqueeze(0)
         B = ids.shape[0]
+        if past_key_values is not None:
+            if not isinstance(past_key_values, _KVHandle) or past_key_values is not getattr(self, "_live_kv", None):
+                raise ValueError("past_key_values must be the handle returned by the previous forward() of this model")
+            if ids.shape[1] != 1 or B != past_key_values.B:
+                raise ValueError("decode form takes input_ids [B, 1]")
+            eng.feed([int(x) for x in ids[:, 0].tolist()])
+            lg = eng.decode_steps(1, use_graph=False, want_logits=True)
+            _, cur = eng.decode_read()
+            if heads is not None and [int(h) for h in heads] != [int(h) for h in cur]:
+                raise ValueError(f"heads={list(heads)} disagrees with the head state the fed tokens imply ({cur})")
+            if heads is None:
+                if any(cur):
+                    raise ValueError("heads=None asks for text logits but the fed tokens switched a row to the time/score head")
+                lg = lg[:, : cfg.vocab_size + 1]
+            return SimpleNamespace(logits=lg.unsqueeze(1), past_key_values=past_key_values, loss=None, hidden_states=None,
+                                   attentions=None)
+        if images is None:
+            raise NotImplementedError("text-only forward is outside the accelerated path")
+        vids, modals = images
+        hd = [0] * B if heads is None else [int(h) for h in heads]
+        assert len(hd) == B                                                       # trace_mistral.py:245
+        if B > eng.max_batch:
+            raise ValueError(f"batch {B} exceeds the engine's max_batch {eng.max_batch}")
+        rows = []
         for b in range(B):
-            eng.encode_video(vids[b], video_timestamps[b])
-            eng.prefill(b, eng.splice(ids[b].tolist()))
-        hd = list(heads) if heads is not None else [0] * B
-        lg = eng.decode_begin(list(range(B)), hd, 1, eos=-1, want_logits=True)
-        return SimpleNamespace(logits=lg.unsqueeze(1), past_key_values=None, loss=None)
+            x = vids[b]
+            if (modals[b] if modals else "video") == "image":
+                nf = cfg.num_frames if hasattr(cfg, "num_frames") else NUM_FRAMES
+                x = x.unsqueeze(0).expand(nf, -1, -1, -1) if x.dim() == 3 else x.expand(nf, -1, -1, -1)
+            eng.encode_video(x, video_timestamps[b])
+            trow = [int(i) for ev in (times[b] if times is not None else []) for i in self.model.time_tower.encode(ev)]
+            srow = [int(i) for ev in (scores[b] if scores is not None else []) for i in self.model.score_tower.encode(ev)]
+            L = eng.splice(ids[b].tolist(), trow, srow)
+            hid = eng.prefill(b, L, want_hidden=True)
+            rows.append(eng.head_logits(hid, hd[b]))
+        if any(r.shape != rows[0].shape for r in rows):
+            raise NotImplementedError("rows of one forward() batch must splice to the same length (no padding path in the engine)")
+        logits = torch.stack(rows, 0)
+        if heads is None:
+            logits = logits[..., : cfg.vocab_size + 1]
+        # arm the decode form: token selection stays with the caller (host mode), the cache stays in the engine
+        eng.host_mode(True)
+        eng.decode_begin(list(range(B)), hd, eng.max_new_tokens, eos=-1)
+        self._live_kv = _KVHandle(B)
+        return SimpleNamespace(logits=logits, past_key_values=self._live_kv, loss=None, hidden_states=None, attentions=None)
 
     __call__ = forward
+
+
+class _KVHandle:
+    """`past_key_values` of this build: the KV cache stays inside the engine (slots 0..B-1); the handle only proves that the
+    decode-form call follows the prefill-form call that filled them."""
+
+    def __init__(self, B: int):
+        self.B = B
+
+    def get_seq_length(self, *a, **k):
+        raise NotImplementedError("the KV cache is engine-resident")

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Headline benchmark: end-to-end TRACE-7B video-grounding inference on synthetic 128-frame x 336^2 clips.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5]
+        N > 1 without WORLD_SIZE in the environment: bench.py launches its own ranks (python -m torch.distributed.run
+        --nproc-per-node N, rendezvous on 127.0.0.1) and fails if fewer than N GPUs are visible; under an external
+        torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE and requires WORLD_SIZE == N.
 
 A "step" = one pass of the hot path over one batch of `--videos-per-step` (default 64) videos per GPU, inputs already
 resident in HBM: CLIP-ViT-L/14-336 over 128 frames -> SpatialSlotPool -> splice -> Mistral-7B prefill (L = 1968) -> 256 greedy
@@ -81,14 +84,77 @@ def dvc_schedule(cfg, n_new, seed):
     return out[:n_new]
 
 
+def mr_schedule(cfg, n_new, seed):
+    """Forced feed for the moment-retrieval answer shape of BASELINE config 4 (trace/eval/evaluate.py:298-357 with prompts/mr.txt):
+    one event = 14 time-head steps, 4 score-head steps, then caption text and the text <sync> (18 of 32 steps on the 13-way heads)."""
+    rng = np.random.RandomState(2000 + seed)
+    V, Tv = cfg.vocab_size, cfg.time_vocab_size
+    digits = lambda n, base: [base + 3 + int(d) for d in rng.randint(0, 10, size=n)]
+    sb = V + Tv
+    out = []
+    while len(out) < n_new:
+        out += digits(4, V) + [V + 13] + digits(1, V) + [V + 2] + digits(4, V) + [V + 13] + digits(1, V) + [V + 1]
+        out += digits(1, sb) + [sb + 13] + digits(1, sb) + [sb + 1]
+        out += [int(x) for x in rng.randint(3, V, size=13)] + [V]
+    return out[:n_new]
+
+
+# BASELINE.json configs with a GPU workload (C1 is the reference's CPU plumbing case, C3 = C2 under --gpus 8)
+CONFIGS = {
+    "c2": dict(frames=128, max_new=256, n_text=176, video_pos=150, schedule="dvc", videos_per_step=64,
+               name="C2: TRACE-7B bf16 (CLIP-ViT-L/14-336 23 layers + SpatialSlotPool + Mistral-7B)"),
+    "c4": dict(frames=64, max_new=32, n_text=191, video_pos=150, schedule="mr", videos_per_step=64,
+               name="C4: Charades-STA moment retrieval shape, TRACE-7B bf16"),
+    "c5": dict(frames=256, max_new=16, n_text=251, video_pos=200, schedule="dvc", videos_per_step=32,
+               name="C5 shape: VideoMME long video (256 frames, past MAX_FRAMES), TRACE-7B"),
+}
+
+
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` with no launcher around it: start one rank per GPU ourselves (the driver's own N > 1 invocation,
+    `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, sets WORLD_SIZE and never gets here)."""
+    import socket
+    import subprocess
+    if not args.plumbing_check:
+        n_vis = torch.cuda.device_count()
+        if n_vis < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_vis} GPU(s) visible on this node — refusing to report a "
+                             f"{args.gpus}-GPU number from fewer devices")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def plumbing_check(args, rank, world) -> None:
+    """Launcher / rendezvous / gather path with no kernels (runs on CPU over gloo: tests/test_bench_launcher.py): every rank fabricates
+    its videos' ids, the packed all-gather runs, rank 0 prints a line whose n_gpus / rccl_ranks prove every rank took part."""
+    B, n_new = 3, 8
+    local = [[(1000 * rank + 10 * b + i) % 32027 for i in range(1 + (b + rank) % n_new)] for b in range(B)]
+    tdist.barrier()
+    g = tdist.gather_outputs(local, n_new, B, None if torch.cuda.is_available() else torch.device("cpu"))
+    tdist.barrier()
+    ok = all(g[r][b] == [(1000 * r + 10 * b + i) % 32027 for i in range(1 + (b + r) % n_new)] for r in range(world) for b in range(B))
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing check (no kernels)", "value": 0.0, "unit": "videos/s", "n_gpus": world, "rccl_ranks": len(g),
+                          "gather_ok": ok, "data": "none", "config": {"workload": "launcher + rendezvous + packed-id all-gather only"}}), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--videos-per-step", type=int, default=int(os.environ.get("TRACE_BENCH_BATCH", "64")))
-    ap.add_argument("--frames", type=int, default=128)
-    ap.add_argument("--max-new", type=int, default=256)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE.json configuration (c3 = c2 with --gpus 8)")
+    ap.add_argument("--videos-per-step", type=int, default=None)
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--max-new", type=int, default=None)
+    ap.add_argument("--plumbing-check", action="store_true", help="launcher / rendezvous / gather only, no kernels (CPU-testable)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the captured hipGraph for decode steps (default: eager launches, which run at the same speed "
                          "— the step is GPU-bound — and allow the per-launch HIP-event roofline probe in the timed region)")
@@ -96,18 +162,33 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="tiny geometry (plumbing check)")
     ap.add_argument("--vit-batch", type=int, default=None, help="frames per ViT call (default: TraceEngine.full_round_frames)")
     args = ap.parse_args()
+    preset = CONFIGS[args.config]
+    if args.frames is None:
+        args.frames = preset["frames"]
+    if args.max_new is None:
+        args.max_new = preset["max_new"]
+    if args.videos_per_step is None:
+        args.videos_per_step = int(os.environ.get("TRACE_BENCH_BATCH", preset["videos_per_step"]))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                       # never returns
 
-    rank, local, world = tdist.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rank, local, world = tdist.init_from_env(None if torch.cuda.is_available() else "gloo")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would report the wrong device count")
+    if args.plumbing_check:
+        return plumbing_check(args, rank, world)
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"{world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from trace_amd.engine import TraceEngine
 
     cfg = tcfg.tiny(args.frames) if args.tiny else tcfg.trace_7b(args.frames)
     B, n_new = args.videos_per_step, args.max_new
-    n_text = 24 if args.tiny else 176
-    ids = synth.synth_prompt_ids(cfg, n_text=n_text, video_pos=10 if args.tiny else 150).tolist()
+    n_text = 24 if args.tiny else preset["n_text"]
+    ids = synth.synth_prompt_ids(cfg, n_text=n_text, video_pos=10 if args.tiny else preset["video_pos"]).tolist()
     L = n_text - 1 + args.frames * cfg.tokens_per_frame
     eng = TraceEngine(cfg, device=local, max_batch=B, max_ctx=(L + n_new + 63) // 64 * 64, max_frames=args.frames,
                       max_new_tokens=n_new, vit_batch_frames=args.vit_batch)
@@ -120,12 +201,17 @@ def main():
     ts = [[[float(i)] for i in range(args.frames)] for _ in range(B)]
     prompt = [ids] * B
     heads = [1] * B
-    forced = [dvc_schedule(cfg, n_new, seed=rank * B + b) for b in range(B)]
+    sched = mr_schedule if preset["schedule"] == "mr" else dvc_schedule
+    forced = [sched(cfg, n_new, seed=rank * B + b) for b in range(B)]
+    ranks_seen = [1]
 
     def step():
         out, _ = eng.generate(videos, ts, prompt, heads, n_new, eos=-1, use_graph=args.graph, forced=forced)
         if world > 1 or torch.distributed.is_initialized():
-            tdist.gather_outputs(out, n_new, B, dev)
+            g = tdist.gather_outputs(out, n_new, B, dev)
+            ranks_seen[0] = len(g)
+            if len(g) != world or any(len(x) != B for x in g):
+                raise SystemExit(f"bench: the all-gather returned {len(g)} ranks, expected {world}")
         return out
 
     for _ in range(args.warmup):
@@ -195,13 +281,13 @@ def main():
         g_tf = (g_gf / g_ms) if g_ms > 0 else None             # GFLOP / ms = TFLOP/s
         line = {
             "metric": "videos/sec + decode tok/s, TRACE-7B 128-frame, 1/2/4/8 MI355X",
-            "value": vps, "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": vps, "unit": "videos/s", "n_gpus": world, "rccl_ranks": ranks_seen[0], "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("tiny plumbing check" if args.tiny else
-                                    "C2: TRACE-7B bf16 (CLIP-ViT-L/14-336 23 layers + SpatialSlotPool + Mistral-7B), "
-                                    f"{args.frames}x336^2 frames, prefill L={Ls}, {n_new} greedy tokens, heads=[1]"),
-                       "videos_per_step_per_gpu": B, "frames": args.frames, "prefill_len": Ls, "new_tokens": n_new, "head_schedule": "forced DVC pattern per event: 14 time + 4 score + 33 text steps (argmax still computed every step)",
+                                    f"{preset['name']}, {args.frames}x336^2 frames, prefill L={Ls}, {n_new} greedy tokens, heads=[1]"),
+                       "baseline_config": args.config,
+                       "videos_per_step_per_gpu": B, "frames": args.frames, "prefill_len": Ls, "new_tokens": n_new, "head_schedule": ("forced MR pattern: 14 time + 4 score + 14 text steps per 32 tokens" if preset["schedule"] == "mr" else "forced DVC pattern per event: 14 time + 4 score + 33 text steps") + " (argmax still computed every step)",
                        "decode_launch": "hipGraph" if args.graph else "eager", "parallelism": f"dp{world} (replica per GPU)",
                        "weights": "random-init (device RNG), reference architecture"},
             "decode_tok_s": world * B * (n_new - 1) / (t_dec * 1e-3),

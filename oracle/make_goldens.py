@@ -592,6 +592,51 @@ def full_depth_goldens(tmp):
     print("full_depth_llm: L=%d steps=%d logit std %.3f" % (L, lg.shape[0], lg[torch.isfinite(lg)].std().item()))
 
 
+def tokenizer_goldens():
+    """SURVEY 8f.2, tokenizer hookup: a tiny sentencepiece LlamaTokenizer (trained here on this repo's own SURVEY.md + DESIGN.md text,
+    vocabulary 512 — the GPU test widens the tiny config's embedding table to match; the trained model file is committed as data) loaded the way the reference loads its tokenizer
+    (AutoTokenizer.from_pretrained(path, use_fast=False), trace/model/builder.py:113), then the REFERENCE's tokenizer_MMODAL_token_all /
+    tokenizer_MMODAL_token (trace/mm_utils.py:493-554) on the llama_2 prompts of every task file and on multi-placeholder strings."""
+    import sentencepiece as spm
+    from transformers import AutoTokenizer
+    from Trace.trace import mm_utils as ref_mm
+    from Trace.trace import conversation as conv_mod
+    d = os.path.join(OUT, "sp_tiny")
+    os.makedirs(d, exist_ok=True)
+    corpus = os.path.join(tempfile.mkdtemp(), "corpus.txt")
+    with open(corpus, "w") as f:
+        f.write(open(os.path.join(REPO, "SURVEY.md")).read())
+    spm.SentencePieceTrainer.train(input=corpus, model_prefix=os.path.join(d, "tokenizer"), vocab_size=512, model_type="bpe", pad_id=-1,
+                                   unk_id=0, bos_id=1, eos_id=2, byte_fallback=True, character_coverage=1.0,
+                                   normalization_rule_name="identity", add_dummy_prefix=True, minloglevel=2)
+    os.remove(os.path.join(d, "tokenizer.vocab"))
+    with open(os.path.join(d, "tokenizer_config.json"), "w") as f:
+        json.dump({"tokenizer_class": "LlamaTokenizer", "bos_token": "<s>", "eos_token": "</s>", "unk_token": "<unk>", "add_bos_token": True,
+                   "add_eos_token": False, "legacy": True, "model_max_length": 4096}, f, indent=1)
+    tok = AutoTokenizer.from_pretrained(d, use_fast=False)
+    cases = []
+    pdir = os.path.join(REF, "trace", "prompts")
+    for fn in sorted(os.listdir(pdir)):
+        q = open(os.path.join(pdir, fn)).read()
+        if "{}" in q:
+            q = q.format("a person opens the door")
+        conv = conv_mod.conv_templates["llama_2"].copy()
+        conv.append_message(conv.roles[0], "<video>\n" + q)
+        conv.append_message(conv.roles[1], None)
+        cases.append(conv.get_prompt() + "<sync>")
+    cases += ["a bb <video>\nccc dd [/INST]<sync>", "<video>\nxx", "no modal here", "x <time> y <score> z <sync>", "<image> a <video> b <audio> c",
+              "<sync>", "lead <sync><sync> tail", "Ünïcödé <video> 你好 [/INST]<sync>"]
+    G = {"vocab_size": len(tok), "bos": tok.bos_token_id, "eos": tok.eos_token_id,
+         "all": [{"in": c, "out": ref_mm.tokenizer_MMODAL_token_all(c, tok, return_tensors="pt").tolist()} for c in cases],
+         "video": [{"in": c, "out": ref_mm.tokenizer_MMODAL_token(c, tok, -201, return_tensors="pt").tolist()} for c in cases[:7]],
+         "decode": [{"in": ids, "out": tok.batch_decode([ids], skip_special_tokens=True)[0]}
+                    for ids in ([1, 40, 41, 300, 2], [5, 6, 7], [400, 401, 402, 403, 2, 2])],
+         "stop_ids": tok("</s>").input_ids}
+    with open(os.path.join(OUT, "tokenizer_sp.json"), "w") as f:
+        json.dump(G, f, indent=0)
+    print("tokenizer_sp.json:", len(cases), "cases; lens", [len(c["out"]) for c in G["all"]][:6])
+
+
 def preprocess_goldens():
     """Frame preprocessing of process_video (mm_utils.py:456-462): the reference's own expand2square + the HF
     CLIPImageProcessor it delegates to (PIL backend), on small synthetic frames, 'pad' and plain modes.  The processor is
@@ -643,6 +688,9 @@ if __name__ == "__main__":
     if "--deep-llm-only" in sys.argv:
         deep_llm_goldens(tmp)
         sys.exit(0)
+    if "--tokenizer-only" in sys.argv:
+        tokenizer_goldens()
+        sys.exit(0)
     if "--charades-only" in sys.argv:
         charades_goldens(tmp)
         sys.exit(0)
@@ -662,4 +710,5 @@ if __name__ == "__main__":
     charades_goldens(tmp)
     videomme_goldens(tmp)
     full_depth_goldens(tmp)
+    tokenizer_goldens()
     preprocess_goldens()

@@ -41,6 +41,21 @@ def test_config_struct_matches_header():
     assert names == [f[0] for f in TraceConfigC._fields_]
 
 
+def test_integration_doc_struct_matches_header():
+    """The ctypes stub a maintainer copies out of INTEGRATION.md must describe the same struct as the header (round 1 shipped a
+    stub one field short: 100 bytes passed to a function that reads 104)."""
+    import ctypes as C
+    from trace_amd._lib import TraceConfigC
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index("class Cfg(C.Structure):"):]
+    block = block[:block.index("def chk(rc)")]
+    ns = {"C": C}
+    exec(block, ns)                                  # the document's own class statement, executed as written
+    Cfg = ns["Cfg"]
+    assert [(n, t) for n, t in Cfg._fields_] == [(n, t) for n, t in TraceConfigC._fields_]
+    assert C.sizeof(Cfg) == C.sizeof(TraceConfigC)
+
+
 def test_engine_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -168,3 +168,94 @@ def test_evaluate_videos_equals_the_driver_loop(loaded):
             assert "error" in r
             continue
         assert (r["timestamps"], r["scores"], r["captions"]) == (ref["timestamps"], ref["scores"], ref["captions"])
+
+
+def test_driver_loop_through_sentencepiece_tokenizer(tmp_path_factory, golden_dir):
+    """a checkpoint directory as the reference ships one — config.json, safetensors shards under the reference's
+    state-dict names, sentencepiece tokenizer.model + tokenizer_config.json — loads through AutoTokenizer (builder.py:113) and the
+    drivers' loop (conversation -> tokenizer_MMODAL_token_all -> generate -> batch_decode / KeywordsStoppingCriteria) runs on it."""
+    import dataclasses
+    import shutil
+    from safetensors.torch import save_file
+    from trace_amd.mm_utils import KeywordsStoppingCriteria
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), vocab_size=512)          # the committed sentencepiece model has 512 pieces
+    path = str(tmp_path_factory.mktemp("ckpt_sp") / "trace-tiny-sp")
+    os.makedirs(path)
+    cfg.save_pretrained(path)
+    save_file({k: v.contiguous() for k, v in synth.state_dict(cfg).items()}, os.path.join(path, "model.safetensors"))
+    for f in ("tokenizer.model", "tokenizer_config.json"):
+        shutil.copy(os.path.join(golden_dir, "sp_tiny", f), path)
+    tok, model, proc, _ = load_pretrained_model(path, None, get_model_name_from_path(path), max_batch=1, max_new_tokens=32)
+    assert type(tok).__name__.startswith("Llama") and len(tok) == cfg.vocab_size
+    raw = np.random.RandomState(4).randint(0, 255, size=(40, 48, 64, 3), dtype=np.uint8)
+    tensor, ts = process_video(raw, proc, "pad", 4, fps=8.0)
+    conv = conv_templates["llama_2"].copy()
+    conv.append_message(conv.roles[0], DEFAULT_MMODAL_TOKEN["VIDEO"] + "\nfind events")
+    conv.append_message(conv.roles[1], None)
+    ids = tokenizer_MMODAL_token_all(conv.get_prompt() + "<sync>", tok, return_tensors="pt")
+    assert (ids == -201).sum() == 1 and ids[-1] == -205 and ids[0] == tok.bos_token_id and int(ids.max()) < cfg.vocab_size
+    heads = [1]
+    out = model.generate(ids.unsqueeze(0).to("cuda"), images_or_videos=[tensor.to("cuda")], modal_list=["video"], do_sample=False,
+                         max_new_tokens=12, use_cache=True, pad_token_id=tok.eos_token_id, video_timestamps=[ts], heads=heads)
+    ora = O.Oracle(cfg, synth.state_dict(cfg), emulate_bf16=True)
+    ref, lg = ora.generate(ids, tensor.to(torch.bfloat16).float(), ts, head=1, max_new_tokens=12, eos_token_id=cfg.eos_token_id,
+                           return_logits=True)
+    srt = torch.sort(torch.where(torch.isfinite(lg), lg, torch.full_like(lg, -1e30)), dim=-1, descending=True).values
+    for i, (a, b) in enumerate(zip(out[0].tolist(), ref)):
+        if (srt[i, 0] - srt[i, 1]) < 0.1:
+            break
+        assert a == b, f"step {i}"
+    text_ids = [t for t in out[0].tolist() if t < cfg.vocab_size]
+    assert isinstance(tok.batch_decode([text_ids], skip_special_tokens=True)[0], str)
+    sc = KeywordsStoppingCriteria(["</s>"], tok, ids.unsqueeze(0))
+    out2 = model.generate(ids.unsqueeze(0), images_or_videos=[tensor], modal_list=["video"], do_sample=False, max_new_tokens=12,
+                          stopping_criteria=[sc], video_timestamps=[ts], heads=[1])
+    n = out2.shape[1]
+    assert out2[0].tolist() == out[0, :n].tolist()              # the stepwise (stopping-criteria) path emits the same greedy ids
+    model.engine.close()
+
+
+def test_forward_contract_prefill_and_decode_forms(loaded):
+    """forward() as the reference defines it (trace_mistral.py:114-264): prefill form -> logits for EVERY position [B, L, V'] with the
+    head mask, decode form (input_ids [B,1] + past_key_values) -> [B, 1, V']; both against the bf16-emulating oracle, and the
+    last prefill position / the decode steps equal what generate()'s own loop computes."""
+    cfg, tok, model, proc, _ = loaded
+    tensor, ts, ids = _driver_inputs(cfg, tok, proc, seed=3)
+    ora = O.Oracle(cfg, synth.state_dict(cfg), emulate_bf16=True)
+    fr = tensor.to(torch.bfloat16)
+    out = model.forward(input_ids=ids.unsqueeze(0), images=[[fr], ["video"]], video_timestamps=[ts], heads=[1], use_cache=True)
+    NV = cfg.total_vocab
+    vid = ora.encode_video(fr.float(), ts)
+    emb = ora.splice(ids, vid)
+    hid, kv = ora.llm_forward(emb)
+    ref = ora.logits(hid, 1)
+    L = emb.shape[0]
+    assert out.logits.shape == (1, L, NV) and out.logits.dtype == torch.float32
+    got = out.logits[0].cpu()
+    assert torch.equal(torch.isfinite(got), torch.isfinite(ref))
+    fin = torch.isfinite(ref)
+    assert (got[fin] - ref[fin]).abs().max().item() < 0.08
+    # heads=None: text | sync logits only, unmasked
+    out0 = model.forward(input_ids=ids.unsqueeze(0), images=[[fr], ["video"]], video_timestamps=[ts])
+    assert out0.logits.shape == (1, L, cfg.vocab_size + 1) and torch.isfinite(out0.logits).all()
+    # decode form: feed the arg-max of the last position, twice; heads follow the swap rule
+    out = model.forward(input_ids=ids.unsqueeze(0), images=[[fr], ["video"]], video_timestamps=[ts], heads=[1], use_cache=True)
+    heads, lg = [1], out.logits[0, -1]
+    pkv = out.past_key_values
+    for _ in range(3):
+        t = int(torch.argmax(lg))
+        heads[0] = model.swap_tokens.get(t, heads[0])
+        o = model.forward(input_ids=torch.tensor([[t]]), past_key_values=pkv, heads=heads, use_cache=True)
+        assert o.logits.shape == (1, 1, NV)
+        hid, kv = ora.llm_forward(ora.decode_embed(t)[None], kv)
+        r = ora.logits(hid, heads[0])[0]
+        lg = o.logits[0, 0].cpu()
+        f = torch.isfinite(r)
+        assert torch.equal(torch.isfinite(lg), f) and (lg[f] - r[f]).abs().max().item() < 0.08
+        pkv = o.past_key_values
+    with pytest.raises(ValueError, match="disagrees"):
+        model.forward(input_ids=torch.tensor([[5]]), past_key_values=pkv, heads=[(heads[0] + 1) % 3])
+    # generate() after forward() works (host mode is reset)
+    g = model.generate(ids.unsqueeze(0), images_or_videos=[tensor], modal_list=["video"], do_sample=False, max_new_tokens=4,
+                       video_timestamps=[ts], heads=[1])
+    assert g.shape[0] == 1

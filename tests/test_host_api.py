@@ -281,3 +281,29 @@ def test_tower_call_size_fills_whole_gemm_rounds():
     assert tiles == 384 and all((tiles * n) % 256 == 0 for n in (4, 12, 16))
     assert F * cfg.vision_tokens * cfg.vision_hidden_size * 2 < 256 << 20
     assert TraceEngine.full_round_frames(tcfg.tiny()) == 256          # capped
+
+
+def test_sentencepiece_tokenizer_hookup(golden_dir):
+    """a model directory with sentencepiece files goes through AutoTokenizer (trace/model/builder.py:113) and
+    tokenizer_MMODAL_token_all / tokenizer_MMODAL_token on it give what the REFERENCE's functions gave with the same tokenizer
+    (tests/golden/tokenizer_sp.json, captured by oracle/make_goldens.py from the imported reference)."""
+    import json
+    import os
+    import torch
+    from trace_amd import config as tcfg, mm_utils
+    from trace_amd.model import builder
+    G = json.load(open(os.path.join(golden_dir, "tokenizer_sp.json")))
+    tok = builder.load_tokenizer(os.path.join(golden_dir, "sp_tiny"), tcfg.tiny())
+    assert type(tok).__name__.startswith("Llama") and len(tok) == G["vocab_size"] == 512
+    assert (tok.bos_token_id, tok.eos_token_id) == (G["bos"], G["eos"])
+    for c in G["all"]:
+        assert mm_utils.tokenizer_MMODAL_token_all(c["in"], tok, return_tensors="pt").tolist() == c["out"], c["in"][:40]
+    for c in G["video"]:
+        assert mm_utils.tokenizer_MMODAL_token(c["in"], tok, -201, return_tensors="pt").tolist() == c["out"], c["in"][:40]
+    for c in G["decode"]:
+        assert tok.batch_decode([c["in"]], skip_special_tokens=True)[0] == c["out"]
+    # the drivers' stopping criterion on the real tokenizer: fires on the template's sep2 (evaluate.py:337-341)
+    ids = torch.tensor([G["all"][0]["out"][:8]])
+    sc = mm_utils.KeywordsStoppingCriteria(["</s>"], tok, ids)
+    assert sc(torch.cat([ids, torch.tensor([[40, 41, tok.eos_token_id]])], 1), None) is True
+    assert sc(torch.cat([ids, torch.tensor([[40, 41, 42]])], 1), None) is False

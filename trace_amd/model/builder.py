@@ -122,6 +122,18 @@ def _image_processor(cfg: TraceConfig, model_path: str):
     return CLIPImageProcessor(size={"shortest_edge": s}, crop_size={"height": s, "width": s})
 
 
+def load_tokenizer(model_path: str, cfg: TraceConfig, **kwargs):
+    """The reference's `AutoTokenizer.from_pretrained(model_path, use_fast=False)` (trace/model/builder.py:113,135) when the directory
+    carries tokenizer files (sentencepiece `tokenizer.model` / `tokenizer.json`); the byte-level stand-in otherwise."""
+    has_tok = any(os.path.exists(os.path.join(model_path, f)) for f in ("tokenizer.model", "tokenizer.json"))
+    if has_tok:
+        from transformers import AutoTokenizer
+        return AutoTokenizer.from_pretrained(model_path, use_fast=False, token=kwargs.get("token"))
+    import warnings
+    warnings.warn(f"no tokenizer files under {model_path}: falling back to the byte-level stand-in tokenizer")
+    return ByteTokenizer(cfg.vocab_size)
+
+
 def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto",
                           device="cuda", use_flash_attn=False, max_batch: int = 1, max_new_tokens: int = 1024, **kwargs):
     if load_8bit or load_4bit:
@@ -148,17 +160,11 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
         from .. import synth
         small = cfg.hidden_size * cfg.num_hidden_layers < 4096 * 8
         eng.load_weights(synth.iter_weights(cfg, device="cpu" if small else f"cuda:{dev_index}"))
-        tokenizer = ByteTokenizer(cfg.vocab_size)
+        has_tok = any(os.path.exists(os.path.join(model_path, f)) for f in ("tokenizer.model", "tokenizer.json"))
+        tokenizer = load_tokenizer(model_path, cfg, **kwargs) if has_tok else ByteTokenizer(cfg.vocab_size)
     else:
         eng.load_weights(_iter_checkpoint(model_path, cfg))
-        has_tok = any(os.path.exists(os.path.join(model_path, f)) for f in ("tokenizer.model", "tokenizer.json", "tokenizer_config.json"))
-        if has_tok:
-            from transformers import AutoTokenizer
-            tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=False, token=kwargs.get("token"))
-        else:
-            import warnings
-            warnings.warn(f"no tokenizer files under {model_path}: falling back to the byte-level stand-in tokenizer")
-            tokenizer = ByteTokenizer(cfg.vocab_size)
+        tokenizer = load_tokenizer(model_path, cfg, **kwargs)
     processor = _image_processor(cfg, model_path)
     model = TraceMistralForCausalLM(cfg, eng, processor)
     # builder.py:135-149: optional extra tokens must not change the embedding table the engine already holds

@@ -56,6 +56,10 @@ def _check(lgs, ids, M, rows, tol, tag):
             if m > 2 * tol:
                 assert a == r, (tag, b, i, a, r, m)
     print(f"{tag}: max |dlogit| = {worst:.4f} (budget {tol})")
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):                                   # measured values travel back from the GPU box with gpurun_out/
+        with open(os.path.join(out_dir, "parity_measured.txt"), "a") as f:
+            f.write(f"{tag}: max |dlogit| = {worst:.4f} (budget {tol})\n")
     return worst
 
 
@@ -81,9 +85,19 @@ def test_c4_charades_moment_retrieval_vs_reference_fixture(golden_dir):
         _check(lgs, out, M, (0, nb - 1), LOGIT_TOL, f"C4 batch {nb}")
         assert all(len(o) == 32 for o in out)
         assert all(h == 1 for h in heads)                       # the stream ends on the text <sync>: back to the time head
-    # the drivers' one-call path (hipGraph decode, batch of 3 videos through generate()) emits the same ids as the stepwise run
+    # the drivers' one-call path (hipGraph decode, batch of 3 videos through generate()): the reference's ids wherever its margin
+    # allows (another batch size sums the GEMV partial rows in another grouping, so near-ties may fall either way)
     out_g, _ = eng.generate([frames] * 3, [ts] * 3, [ids] * 3, [1] * 3, n, eos=-1, use_graph=True, forced=[forced] * 3)
-    assert out_g[0] == out[0] and out_g[2] == out[0]
+    ref_lg, ref_ids = torch.from_numpy(M["tf_logits"]), M["tf_argmax"].tolist()
+    srt = torch.sort(torch.where(torch.isfinite(ref_lg), ref_lg, torch.full_like(ref_lg, -1e30)), dim=-1, descending=True).values
+    checked = 0
+    for b in (0, 2):
+        assert len(out_g[b]) == 32
+        for i, (a, r) in enumerate(zip(out_g[b], ref_ids)):
+            if float(srt[i, 0] - srt[i, 1]) > 2 * LOGIT_TOL:
+                assert a == r, (b, i, a, r)
+                checked += 1
+    assert checked >= 20
     eng.close()
 
 

@@ -137,7 +137,13 @@ def test_batch_40_equals_singles():
         assert torch.equal(torch.isfinite(lgb[b]), fin)
         if b != 0:           # slot 0 was just overwritten by this video's prefill; the batch logits of slot 0 were read before
             assert (lgb[b][fin] - lg1[fin]).abs().max().item() < LOGIT_TOL
-        single, _ = eng.generate([vids[b]], [ts], [ids], [1], n_new, eos=-1)
-        first_diff = next((i for i, (x, y) in enumerate(zip(out[b], single[0])) if x != y), n_new)
-        assert first_diff >= 6, (b, first_diff, out[b], single[0])
+        # free-running ids: equal until the single run's own top-2 margin drops inside the logit budget (after a near-tie the two
+        # runs may legitimately follow different tokens)
+        lgs = [lg1] + [eng.decode_steps(1, use_graph=False, want_logits=True).float().cpu()[0] for _ in range(n_new - 1)]
+        single, _ = eng.decode_read()
+        for i in range(n_new):
+            top = torch.topk(torch.where(torch.isfinite(lgs[i]), lgs[i], torch.full_like(lgs[i], -1e30)), 2).values
+            if float(top[0] - top[1]) < 2 * LOGIT_TOL:
+                break
+            assert out[b][i] == single[0][i], (b, i, out[b], single[0])
     eng.close()

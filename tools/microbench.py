@@ -36,6 +36,7 @@ res = []
 quick = "--quick" in sys.argv
 variants = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--variant=")] or [0]
 only_gemm = "--gemm-only" in sys.argv
+only_attn = "--attn-only" in sys.argv
 # --- prefill-shaped GEMMs (ViT M = 128*577, LLM M = 1968)
 for name, M, N, K, epi in [
     ("vit_qkv", 73856, 3072, 1024, E.EPI_NONE), ("vit_out", 73856, 1024, 1024, E.EPI_RESIDUAL),
@@ -43,6 +44,8 @@ for name, M, N, K, epi in [
     ("llm_qkv", 1968, 6144, 4096, E.EPI_NONE), ("llm_gateup", 1968, 28672, 4096, E.EPI_SWIGLU),
     ("llm_down", 1968, 4096, 14336, E.EPI_RESIDUAL), ("sq4096", 4096, 4096, 4096, E.EPI_NONE),
 ]:
+    if only_attn:
+        break
     if quick and M > 8192:
         M = 8192
     A, W = rnd(M, K), rnd(N, K, scale=0.02)
@@ -60,12 +63,15 @@ for name, M, N, K, epi in [
 if only_gemm:
     sys.exit(0)
 # --- attention
-for name, Bn, n, heads, kvh, hd, causal in [("attn_vit", 32 if quick else 128, 577, 16, 16, 64, False), ("attn_prefill", 1, 1968, 32, 8, 128, True)]:
+for name, Bn, n, heads, kvh, hd, causal in [("attn_vit", 32 if quick else 170, 577, 16, 16, 64, False), ("attn_prefill", 2, 1967, 32, 8, 128, True),
+                                            ("attn_prefill_c5", 1, 3834, 32, 8, 128, True)]:
     q, k, v = rnd(Bn, n, heads, hd), rnd(Bn, n, kvh, hd), rnd(Bn, n, kvh, hd)
-    ms = timeit(lambda: ops.attention(q, k, v, causal, 1 / math.sqrt(hd)), iters=5)
+    ms = timeit(lambda: ops.attention(q, k, v, causal, 1 / math.sqrt(hd)), iters=5)      # includes the V transpose kernel
     fl = 4.0 * Bn * heads * n * n * hd * (0.5 if causal else 1.0)
     res.append({"kernel": name, "ms": ms, "TFLOPs": fl / ms / 1e9})
     print(res[-1], flush=True)
+if only_attn:
+    sys.exit(0)
 # --- decode weight streaming
 for name, N, K, epi in [("dec_qkv", 6144, 4096, E.EPI_NONE), ("dec_o", 4096, 4096, E.EPI_RESIDUAL),
                         ("dec_gateup", 28672, 4096, E.EPI_SWIGLU), ("dec_down", 4096, 14336, E.EPI_RESIDUAL),

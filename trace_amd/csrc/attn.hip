@@ -14,17 +14,91 @@
 // K rows XOR-swizzled (conflict-free ds_read_b128), V^T rows padded to 136 B (conflict-free ds_read_b64).
 // K/V^T tiles are double-buffered in LDS; the next tile's global loads are issued before the MFMAs of the
 // current one and written to LDS after them (one barrier per tile).
+// Round 2 (ISA read with tools/isa_mix.py): the per-element validity test of partial / diagonal tiles had been if-converted
+// by the compiler into ~330 compare/select instructions executed on EVERY key tile (of ~490 VALU per tile against 16 MFMAs:
+// the kernel was VALU-issue bound at 0.21 of the MFMA peak).  The test now sits behind a wave-uniform branch (readfirstlane)
+// and only edge tiles run the masked instantiation of the tile body; a short tail of keys (577 = 9 x 64 + 1 in the ViT) never
+// becomes a tile at all: those keys initialise the online-softmax state on the VALU (dot product, exp2, one scaled V row)
+// before the tile loop.  V^T rows are stored with the two 4-key groups a lane needs side by side, so each PV operand is one
+// ds_read_b128 instead of two ds_read_b64.
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
 constexpr int BKV = 64;
-constexpr int VROW = 136;   // bytes per V^T row in LDS: 64 kv * 2 + 8 pad
+constexpr int VROW = 144;   // bytes per V^T row in LDS: 64 kv * 2 + 16 pad (odd multiple of 16: conflict-free ds_read_b128)
+constexpr int TAILV = 8;    // at most this many trailing keys (nkv % 64) are folded in on the VALU instead of a masked tile
 
 template <int HD>
 __device__ __forceinline__ int kswz(int row, int kc) {
     return row * (HD * 2) + ((kc ^ (HD == 64 ? ((row >> 1) & 7) : (row & 15))) << 4);
+}
+
+// one key tile: S^T = K.Q^T, online softmax (MASK: per-element validity, edge tiles only), O^T += V^T.P
+// (a function template with explicit references, not a by-reference lambda: with those hipcc kept the captured arrays in scratch)
+template <int HD, bool MASK>
+__device__ __forceinline__ void attn_tile(const char* kb, const char* vb, int kv0, const bf16x8_t (&qf)[HD / 16], f32x16_t (&oacc)[HD / 32],
+                                          float& m, float& l, float sc, int c32, int h, int nkv_main, int causal, int qabs, int off) {
+    f32x16_t S[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[st][r] = 0.f;
+        const int row = st * 32 + c32;
+#pragma unroll
+        for (int s_ = 0; s_ < HD / 16; ++s_) {
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + kswz<HD>(row, s_ * 2 + h));
+            S[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s_], S[st], 0, 0, 0);
+        }
+    }
+    if (MASK) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kv0 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const bool ok = kv < nkv_main && (!causal || kv <= qabs + off);
+                S[st][r] = ok ? S[st][r] : -1e30f;
+            }
+    }
+    // ---- online softmax (base 2; the score scale is folded into the exp2 argument: p = 2^(s*sc - m)) ----
+    float mloc = -1e30f;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, S[st][r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mnew = fmaxf(m, mloc * sc);           // running max in the scaled (base-2) domain
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+    m = mnew;
+    float lsum = 0.f;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(S[st][r], sc, -mnew));   // raw v_exp_f32 (exp2f() adds a denormal-range fix-up: 5 ops)
+            lsum += p;
+            S[st][r] = p;
+        }
+    l = l * alpha + lsum;
+#pragma unroll
+    for (int i = 0; i < HD / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    // ---- O^T += V^T . P ----
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int st = ks >> 1, rb = (ks & 1) * 8;
+        union { bf16x8_t v; uint32_t u[4]; } pf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pf.u[i] = pack2bf(S[st][rb + 2 * i], S[st][rb + 2 * i + 1]);
+#pragma unroll
+        for (int ht = 0; ht < HD / 32; ++ht) {
+            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vb + (ht * 32 + c32) * VROW + ks * 32 + h * 16);
+            oacc[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, oacc[ht], 0, 0, 0);
+        }
+    }
 }
 
 template <int HD, bool GQA>
@@ -38,18 +112,38 @@ __device__ __forceinline__ void attn_body(AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c32 = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, kvh = blockIdx.y;
+    // 1-D grid, XCD-aware: the dispatcher places block i on XCD i % 8 and the 8 XCDs do not share an L2, so the blocks that read
+    // the same K/V (the 5 query blocks of one ViT (frame, head); every query tile of one prefill kv head) must be NEIGHBOURS IN THE
+    // SAME XCD'S SEQUENCE — as (x, y, z) grid they were spread over 5-8 XCDs and each L2 fetched its own copy from HBM (the ViT
+    // launch read its 400 MB of K/V five times: 4.4 TB/s, i.e. it ran at the HBM roofline, not the MFMA one).
+    const int nqt = (a.nq_rows + 31) / 32;
+    const int nqb = GQA ? nqt : (nqt + 3) / 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int b, kvh, qblk;
+    if (GQA) {          // [kv head][batch][query tile], heaviest (last) causal tiles first: with 8 kv heads, XCD x = kv head x
+        qblk = nqb - 1 - lid % nqb;
+        b = (lid / nqb) % a.batch;
+        kvh = lid / (nqb * a.batch);
+    } else {            // [batch][head][query block]
+        qblk = lid % nqb;
+        kvh = (lid / nqb) % a.kv_heads;
+        b = lid / (nqb * a.kv_heads);
+    }
     const int qh = GQA ? kvh * (a.heads / a.kv_heads) + wid : kvh;
-    const int qt = GQA ? blockIdx.x : blockIdx.x * 4 + wid;
+    const int qt = GQA ? qblk : qblk * 4 + wid;
     const int q0 = qt * 32;
     const bool active = q0 < a.nq_rows;
     const int off = a.nkv_rows - a.nq_rows;
     const int qabs = q0 + c32;
 
+    // trailing keys (nkv % 64 of them, when few) are folded in on the VALU: the tile loop covers whole tiles only
+    const int rem = a.nkv_rows % BKV;
+    const bool vtail = !GQA && a.Vrow != nullptr && !a.causal && rem > 0 && rem <= TAILV && a.nkv_rows > BKV;
+    const int nkv_main = vtail ? a.nkv_rows - rem : a.nkv_rows;
     // block-level kv extent
-    int kv_limit = a.nkv_rows;
+    int kv_limit = nkv_main;
     if (a.causal) {
-        const int qmax = (GQA ? q0 : blockIdx.x * 128 + 96) + 31 + off;   // last query row of the block
+        const int qmax = (GQA ? q0 : qblk * 128 + 96) + 31 + off;   // last query row of the block
         kv_limit = min(kv_limit, qmax + 1);
     }
     const int nt = (kv_limit + BKV - 1) / BKV;
@@ -92,9 +186,9 @@ __device__ __forceinline__ void attn_body(AttnArgs a) {
         char* vb_ = kb_ + KT_BYTES;                                                                            \
         _Pragma("unroll") for (int i = 0; i < NCH; ++i) {                                                      \
             *reinterpret_cast<u32x4*>(kb_ + kswz<HD>(krow[i], kkc[i])) = rk[i];                                \
-            char* vp_ = vb_ + vrow[i] * VROW + vkc[i] * 16;                                                    \
+            char* vp_ = vb_ + vrow[i] * VROW + (vkc[i] >> 1) * 32 + (vkc[i] & 1) * 8;                          \
             *reinterpret_cast<u32x2*>(vp_) = u32x2{rv[i][0], rv[i][1]};                                     \
-            *reinterpret_cast<u32x2*>(vp_ + 8) = u32x2{rv[i][2], rv[i][3]};                                 \
+            *reinterpret_cast<u32x2*>(vp_ + 16) = u32x2{rv[i][2], rv[i][3]};                                \
         }                                                                                                      \
     }
 
@@ -106,84 +200,68 @@ __device__ __forceinline__ void attn_body(AttnArgs a) {
     float m = -1e30f, l = 0.f;
     const float sc = a.scale * 1.4426950408889634f;
 
-    ATTN_GLOAD(0)
-    ATTN_LSTORE(0)
+    // ---- trailing keys on the VALU (non-causal only): state after them = softmax over those keys alone ----
+    if (vtail && active) {
+        for (int j = 0; j < rem; ++j) {
+            const int kv = nkv_main + j;
+            const bf16_t* kp = kbase + (size_t)kv * a.k_rs + h * 8;
+            float dot = 0.f;
+#pragma unroll
+            for (int s_ = 0; s_ < HD / 16; ++s_) {
+                const uint4 kk = *reinterpret_cast<const uint4*>(kp + s_ * 16);
+                union { bf16x8_t v; uint32_t u[4]; } qq;
+                qq.v = qf[s_];
+                const uint32_t ku[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dot = fmaf(bflo(qq.u[e]), bflo(ku[e]), dot);
+                    dot = fmaf(bfhi(qq.u[e]), bfhi(ku[e]), dot);
+                }
+            }
+            dot += __shfl_xor(dot, 32, 64);
+            const float mnew = fmaxf(m, dot * sc);
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+            const float p = __builtin_amdgcn_exp2f(fmaf(dot, sc, -mnew));
+            m = mnew;
+            l = l * alpha + (h == 0 ? p : 0.f);            // the epilogue adds the two halves' sums
+            const bf16_t* vp = a.Vrow + (size_t)b * a.vr_bs + (size_t)kvh * a.vr_hs + (size_t)kv * a.vr_rs + 4 * h;
+#pragma unroll
+            for (int ht = 0; ht < HD / 32; ++ht)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const uint2 vv = *reinterpret_cast<const uint2*>(vp + ht * 32 + 8 * rg);
+                    oacc[ht][rg * 4 + 0] = fmaf(p, bflo(vv.x), oacc[ht][rg * 4 + 0] * alpha);
+                    oacc[ht][rg * 4 + 1] = fmaf(p, bfhi(vv.x), oacc[ht][rg * 4 + 1] * alpha);
+                    oacc[ht][rg * 4 + 2] = fmaf(p, bflo(vv.y), oacc[ht][rg * 4 + 2] * alpha);
+                    oacc[ht][rg * 4 + 3] = fmaf(p, bfhi(vv.y), oacc[ht][rg * 4 + 3] * alpha);
+                }
+        }
+    }
+
+    if (nt > 0) {
+        ATTN_GLOAD(0)
+        ATTN_LSTORE(0)
+    }
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
-        const bool more = t + 1 < nt;
-        if (more) ATTN_GLOAD(t + 1)
-        const char* kb = smem + (t & 1) * BUF;
-        const char* vb = kb + KT_BYTES;
-        const int kv0 = t * BKV;
-        if (active) {
-            f32x16_t S[2];
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) S[st][r] = 0.f;
-                const int row = st * 32 + c32;
-#pragma unroll
-                for (int s = 0; s < HD / 16; ++s) {
-                    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + kswz<HD>(row, s * 2 + h));
-                    S[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], S[st], 0, 0, 0);
-                }
-            }
-            // ---- online softmax (base 2; the score scale is folded into the exp2 argument: p = 2^(s*sc - m)) ----
-            const bool edge = (kv0 + BKV > a.nkv_rows) || (a.causal && (kv0 + BKV - 1 > q0 + off));
-            float mloc = -1e30f;
-            if (edge) {
-#pragma unroll
-                for (int st = 0; st < 2; ++st)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int kv = kv0 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const bool ok = kv < a.nkv_rows && (!a.causal || kv <= qabs + off);
-                        S[st][r] = ok ? S[st][r] : -1e30f;
-                    }
-            }
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, S[st][r]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float mnew = fmaxf(m, mloc * sc);           // running max in the scaled (base-2) domain
-            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-            m = mnew;
-            float lsum = 0.f;
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(S[st][r], sc, -mnew));   // raw v_exp_f32 (exp2f() adds a denormal-range fix-up: 5 ops)
-                    lsum += p;
-                    S[st][r] = p;
-                }
-            l = l * alpha + lsum;
-#pragma unroll
-            for (int i = 0; i < HD / 32; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-            // ---- O^T += V^T . P ----
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int st = ks >> 1, rb = (ks & 1) * 8;
-                union { bf16x8_t v; uint32_t u[4]; } pf;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pf.u[i] = pack2bf(S[st][rb + 2 * i], S[st][rb + 2 * i + 1]);
-#pragma unroll
-                for (int ht = 0; ht < HD / 32; ++ht) {
-                    const char* vp = vb + (ht * 32 + c32) * VROW + (ks * 16 + 4 * h) * 2;
-                    union { bf16x8_t v; uint2 u[2]; } vf;
-                    vf.u[0] = *reinterpret_cast<const uint2*>(vp);
-                    vf.u[1] = *reinterpret_cast<const uint2*>(vp + 16);
-                    oacc[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, oacc[ht], 0, 0, 0);
-                }
-            }
-        }
-        if (more) ATTN_LSTORE((t + 1) & 1)
-        __syncthreads();
+    // tiles [0, nt_plain) need no per-element test (all 64 keys exist and, when causal, are visible to every row of the block);
+    // the few edge tiles run the masked body in a loop of their own — one body per loop keeps both free of spills, and the
+    // split is block-uniform so every wave passes the same barriers
+    int nt_plain = nkv_main / BKV;
+    if (a.causal) nt_plain = min(nt_plain, max(0, ((GQA ? q0 : qblk * 128) + off + 1) / BKV));
+    nt_plain = min(nt_plain, nt);
+#define ATTN_LOOP(T0_, T1_, MASK_)                                                                             \
+    for (int t = (T0_); t < (T1_); ++t) {                                                                      \
+        const bool more = t + 1 < nt && a.dbg != 1;                                                            \
+        if (more) ATTN_GLOAD(t + 1)                                                                            \
+        const char* kb = smem + (t & 1) * BUF;                                                                 \
+        if (active && a.dbg != 2) attn_tile<HD, MASK_>(kb, kb + KT_BYTES, t * BKV, qf, oacc, m, l, sc, c32, h, nkv_main, a.causal, qabs, off); \
+        if (more) ATTN_LSTORE((t + 1) & 1)                                                                     \
+        __syncthreads();                                                                                       \
     }
+    ATTN_LOOP(0, nt_plain, false)
+    ATTN_LOOP(nt_plain, nt, true)
+#undef ATTN_LOOP
 
     if (active && qabs < a.nq_rows) {
         const float lt = l + __shfl_xor(l, 32, 64);
@@ -202,12 +280,239 @@ __device__ __forceinline__ void attn_body(AttnArgs a) {
     }
 }
 
+// =====================================================================================================================
+// ViT attention, round 2: head_dim 64, non-causal, one launch = frames x heads x 577 tokens.
+// Knock-out runs of the kernel above (tools/attn_vit_probe.py, 170 frames): tile math alone 387 us, K/V staging alone (global
+// loads -> registers -> LDS stores -> barrier) 261 us, together 466-510 us, i.e. 0.2 of the MFMA peak with the matrix pipe 27 % busy:
+// the loop was bound by VALU issue (135 plain + 33 transcendental instructions per 16 MFMAs) and by the staging instructions.
+// This kernel removes most of both:
+//  * K and V^T tiles arrive by LDS-DMA (global_load_lds, 16 B per lane, no registers, no ds_write) into a 3-stage ring, two
+//    tiles ahead, behind a counted vmcnt + one raw s_barrier per tile.  K rows are XOR-swizzled on the SOURCE address; V^T comes
+//    from transpose_v's PERMUTED layout (within every 16 keys the two 4-key groups a lane needs are adjacent) so each PV operand
+//    is one swizzled ds_read_b128.
+//  * softmax per score element is exp2 + (1/2) max3 + (1/2) cvt_pk + (1/2) pk_add: the score scale and log2(e) are folded into
+//    the Q fragments once per block, and the running maximum is folded into the QK^T MFMA itself — its accumulator starts at
+//    -m instead of 0 — so the MFMA result is already the exp2 argument.  The maximum moves lazily: O, l and m are rescaled only
+//    when some row's tile maximum exceeds the current reference by more than RESCALE_THR (exact arithmetic either way: p is
+//    exponentiated after the decision, so nothing is ever rescaled twice or not at all); p <= 2^RESCALE_THR fits bf16's exponent range.
+//  * the 577th key (nkv % 64 of them) initialises the state on the VALU as in the kernel above.
+constexpr int DSTAGE = 16384, DSTAGES = 3;
+constexpr float RESCALE_THR = 6.f;
+
+__device__ __forceinline__ void glds16(const bf16_t* g, char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_vit_dma_kernel(AttnArgs a) {
+    constexpr int HD = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c32 = lane & 31, h = lane >> 5;
+    const int nqt = (a.nq_rows + 31) / 32, nqb = (nqt + 3) / 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qblk = lid % nqb, kvh = (lid / nqb) % a.kv_heads, b = lid / (nqb * a.kv_heads);
+    const int q0 = (qblk * 4 + wid) * 32;
+    const bool active = q0 < a.nq_rows;
+    const int qabs = q0 + c32;
+    const int rem = a.nkv_rows % BKV, nkv_main = a.nkv_rows - rem, nt = nkv_main / BKV;
+    const bf16_t* kbase = a.K + (size_t)b * a.k_bs + (size_t)kvh * a.k_hs;
+    const bf16_t* vbase = a.V + (size_t)b * a.v_bs + (size_t)kvh * a.v_hs;
+
+    // ---- LDS-DMA: per tile the block moves 8 K pieces + 8 V^T pieces of 1 KB (8 rows x 128 B); wave w issues pieces 2w, 2w+1 of each
+    const bf16_t* ksrc[2];
+    const bf16_t* vsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (2 * wid + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        ksrc[j] = kbase + (size_t)r * a.k_rs + c * 8;
+        vsrc[j] = vbase + (size_t)r * a.v_rs + c * 8;
+    }
+    const long kstep = (long)BKV * a.k_rs;
+    auto issue = [&](int t, int stage) {
+        char* st = smem + stage * DSTAGE + (2 * wid) * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            glds16(ksrc[j] + (size_t)t * kstep, st + j * 1024);
+            glds16(vsrc[j] + t * BKV, st + 8192 + j * 1024);
+        }
+    };
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+
+    // ---- Q fragments, scaled once: q' = bf16(q * scale * log2 e), so that K.q' is the exp2 argument
+    const float sc = a.scale * 1.4426950408889634f;
+    bf16x8_t qf[HD / 16];
+    {
+        const int qr = min(qabs, a.nq_rows - 1);
+        const bf16_t* qp = a.Q + (size_t)b * a.q_bs + (size_t)kvh * a.q_hs + (size_t)qr * a.q_rs + h * 8;
+#pragma unroll
+        for (int s_ = 0; s_ < HD / 16; ++s_) {
+            const uint4 q4 = *reinterpret_cast<const uint4*>(qp + s_ * 16);
+            union { bf16x8_t v; uint32_t u[4]; } o;
+            o.u[0] = pack2bf(bflo(q4.x) * sc, bfhi(q4.x) * sc);
+            o.u[1] = pack2bf(bflo(q4.y) * sc, bfhi(q4.y) * sc);
+            o.u[2] = pack2bf(bflo(q4.z) * sc, bfhi(q4.z) * sc);
+            o.u[3] = pack2bf(bflo(q4.w) * sc, bfhi(q4.w) * sc);
+            qf[s_] = o.v;
+        }
+    }
+
+    f32x16_t oacc[HD / 32];
+#pragma unroll
+    for (int i = 0; i < HD / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m = 0.f, l = 0.f;        // m: the reference every exponent is taken against (exp2 domain); meaningless while `first`
+    bool first = true;
+
+    // ---- trailing keys on the VALU
+    if (active) {
+        for (int j = 0; j < rem; ++j) {
+            const int kv = nkv_main + j;
+            const bf16_t* kp = kbase + (size_t)kv * a.k_rs + h * 8;
+            float dot = 0.f;
+#pragma unroll
+            for (int s_ = 0; s_ < HD / 16; ++s_) {
+                const uint4 kk = *reinterpret_cast<const uint4*>(kp + s_ * 16);
+                union { bf16x8_t v; uint32_t u[4]; } qq;
+                qq.v = qf[s_];
+                const uint32_t ku[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dot = fmaf(bflo(qq.u[e]), bflo(ku[e]), dot);
+                    dot = fmaf(bfhi(qq.u[e]), bfhi(ku[e]), dot);
+                }
+            }
+            dot += __shfl_xor(dot, 32, 64);
+            const float mnew = first ? dot : fmaxf(m, dot);
+            const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(m - mnew);
+            const float p = __builtin_amdgcn_exp2f(dot - mnew);
+            m = mnew; first = false;
+            l = l * alpha + (h == 0 ? p : 0.f);
+            const bf16_t* vp = a.Vrow + (size_t)b * a.vr_bs + (size_t)kvh * a.vr_hs + (size_t)kv * a.vr_rs + 4 * h;
+#pragma unroll
+            for (int ht = 0; ht < HD / 32; ++ht)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const uint2 vv = *reinterpret_cast<const uint2*>(vp + ht * 32 + 8 * rg);
+                    oacc[ht][rg * 4 + 0] = fmaf(p, bflo(vv.x), oacc[ht][rg * 4 + 0] * alpha);
+                    oacc[ht][rg * 4 + 1] = fmaf(p, bfhi(vv.x), oacc[ht][rg * 4 + 1] * alpha);
+                    oacc[ht][rg * 4 + 2] = fmaf(p, bflo(vv.y), oacc[ht][rg * 4 + 2] * alpha);
+                    oacc[ht][rg * 4 + 3] = fmaf(p, bfhi(vv.y), oacc[ht][rg * 4 + 3] * alpha);
+                }
+        }
+    }
+    f32x16_t cinit;                                  // accumulator start of the QK^T MFMAs: -m in every slot (0 while `first`)
+    {
+        const float ci = first ? 0.f : -m;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cinit[r] = ci;
+    }
+
+    int stage = 0, stage2 = 2 % DSTAGES;
+    for (int t = 0; t < nt; ++t) {
+        // tile t landed: this wave's pieces by its own counted vmcnt (the 4 pieces of tile t+1 may stay in flight), everybody's by the
+        // barrier; the barrier also says every wave is done reading tile t-1, whose stage the DMA issued next overwrites
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < nt && a.dbg != 1) issue(t + 2, stage2);
+        if (active && a.dbg != 2) {
+            const char* kb = smem + stage * DSTAGE;
+            const char* vb = kb + 8192;
+            f32x16_t S[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int row = st * 32 + c32;
+#pragma unroll
+                for (int s_ = 0; s_ < HD / 16; ++s_) {
+                    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + kswz<HD>(row, s_ * 2 + h));
+                    if (s_ == 0) {
+                        // D != C: the builtin ties the result to its accumulator operand, which made the compiler copy cinit into S
+                        // first (27 v_mov per tile); the instruction itself takes separate registers (early-clobber: D must not
+                        // overlap the sources).  The s_nop covers the VALU-write -> MFMA-read wait states hipcc does not pad inside asm.
+                        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(S[st]) : "v"(kf), "v"(qf[0]), "v"(cinit));
+                    } else {
+                        S[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s_], S[st], 0, 0, 0);
+                    }
+                }
+            }
+            // tile maximum relative to m (S already is s - m)
+            float mt = fmaxf(S[0][0], S[1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mt = fmaxf(fmaxf(mt, S[0][r]), S[1][r]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const bool need = first || mt > RESCALE_THR;
+            if (__any(need)) {                                   // rare after the first tile: move the reference up for the rows that need it
+                const float d = need ? mt : 0.f;
+                const float f = first ? 0.f : __builtin_amdgcn_exp2f(-d);       // (first tile: O = l = 0, and 2^-d may overflow)
+                m += d;
+                l *= f;
+#pragma unroll
+                for (int i = 0; i < HD / 32; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[i][r] *= f;
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) S[st][r] -= d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cinit[r] = -m;
+                first = false;
+            }
+            float ls0 = 0.f, ls1 = 0.f;
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(S[st][r]), p1 = __builtin_amdgcn_exp2f(S[st][r + 1]);
+                    ls0 += p0; ls1 += p1;
+                    S[st][r] = p0; S[st][r + 1] = p1;
+                }
+            l += ls0 + ls1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int st = ks >> 1, rb = (ks & 1) * 8;
+                union { bf16x8_t v; uint32_t u[4]; } pf;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pf.u[i] = pack2bf(S[st][rb + 2 * i], S[st][rb + 2 * i + 1]);
+#pragma unroll
+                for (int ht = 0; ht < HD / 32; ++ht) {
+                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vb + kswz<HD>(ht * 32 + c32, ks * 2 + h));
+                    oacc[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, oacc[ht], 0, 0, 0);
+                }
+            }
+        }
+        stage = stage + 1 == DSTAGES ? 0 : stage + 1;
+        stage2 = stage2 + 1 == DSTAGES ? 0 : stage2 + 1;
+    }
+
+    if (active && qabs < a.nq_rows) {
+        const float lt = l + __shfl_xor(l, 32, 64);
+        const float inv = 1.f / lt;
+        bf16_t* op = a.O + (size_t)b * a.o_bs + (size_t)kvh * a.o_hs + (size_t)qabs * a.o_rs;
+#pragma unroll
+        for (int ht = 0; ht < HD / 32; ++ht)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d = ht * 32 + 8 * rg + 4 * h;
+                uint2 o;
+                o.x = pack2bf(oacc[ht][rg * 4 + 0] * inv, oacc[ht][rg * 4 + 1] * inv);
+                o.y = pack2bf(oacc[ht][rg * 4 + 2] * inv, oacc[ht][rg * 4 + 3] * inv);
+                *reinterpret_cast<uint2*>(op + d) = o;
+            }
+    }
+}
+
 // V [rows, HD] (row stride src_rs) -> V^T [HD, rows_pad] (row stride dst_rs), zero-filled for rows >= n.
 // One block per 64-row tile: 16-byte loads -> LDS -> 16-byte stores along the token axis.
+// perm = 1: within every 16 keys the destination order is [0-3, 8-11, 4-7, 12-15] (attn_vit_dma_kernel's PV operand layout).
 template <int HD>
 __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ src, long src_bs, long src_hs, int src_rs,
                                                           bf16_t* __restrict__ dst, long dst_bs, long dst_hs, int dst_rs,
-                                                          int n) {
+                                                          int n, int perm) {
     constexpr int LROW = HD + 2;   // elements; odd dword stride -> column reads spread over banks
     __shared__ bf16_t tile[64 * LROW];
     const int t0 = blockIdx.x * 64, hh = blockIdx.y, b = blockIdx.z;
@@ -227,7 +532,9 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
         uint32_t o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint32_t lo = tile[(tc * 8 + 2 * e) * LROW + dd], hi = tile[(tc * 8 + 2 * e + 1) * LROW + dd];
+            // source rows of destination positions 2e, 2e+1 of this 8-key chunk
+            const int r0 = perm ? 16 * (tc >> 1) + 4 * (tc & 1) + ((2 * e) & 3) + 8 * ((2 * e) >> 2) : tc * 8 + 2 * e;
+            const uint32_t lo = tile[r0 * LROW + dd], hi = tile[(r0 + 1) * LROW + dd];
             o[e] = lo | (hi << 16);
         }
         *reinterpret_cast<uint4*>(d + (size_t)dd * dst_rs + t0 + tc * 8) = make_uint4(o[0], o[1], o[2], o[3]);
@@ -251,14 +558,38 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
         done = true;
     }
     const int nqt = (a.nq_rows + 31) / 32;
-    dim3 grid(GQA ? nqt : (nqt + 3) / 4, a.kv_heads, a.batch);
-    hipLaunchKernelGGL((attn_kernel<HD, GQA>), grid, dim3(256), lds, s, a);
+    const long nblk = (long)(GQA ? nqt : (nqt + 3) / 4) * a.kv_heads * a.batch;
+    if (nblk > 0x7fffffffL) return TRACE_ERR_ARG;
+    hipLaunchKernelGGL((attn_kernel<HD, GQA>), dim3((unsigned)nblk), dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 }  // namespace
 
-int launch_attn_vit(const AttnArgs& a, hipStream_t s) {
+int g_attn_pf_debug = 0;   // microbenchmark-only knock-outs of the prefill-shaped kernels: 1 = no K/V loads after tile 0, 2 = no tile math
+
+// The LDS-DMA kernel takes V^T in transpose_v's permuted layout and needs whole key tiles plus at most TAILV trailing keys
+bool attn_vit_wants_perm(int nkv_rows, bool has_vrow) {
+    const int rem = nkv_rows % BKV;
+    return g_attn_pf_debug < 5 && nkv_rows >= 2 * BKV && (rem == 0 || (has_vrow && rem <= TAILV));
+}
+
+int launch_attn_vit(const AttnArgs& a_, hipStream_t s) {
+    AttnArgs a = a_;
+    a.dbg = g_attn_pf_debug;
     if (a.heads != a.kv_heads || a.nq_rows <= 0 || a.nkv_rows <= 0 || (a.v_rs % 64)) return TRACE_ERR_ARG;
+    if (a.v_perm) {
+        if (a.causal || !attn_vit_wants_perm(a.nkv_rows, a.Vrow != nullptr)) return TRACE_ERR_ARG;
+        static bool done = false;
+        if (!done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_vit_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DSTAGES * DSTAGE);
+            done = true;
+        }
+        const int nqt = (a.nq_rows + 31) / 32;
+        const long nblk = (long)((nqt + 3) / 4) * a.kv_heads * a.batch;
+        if (nblk > 0x7fffffffL) return TRACE_ERR_ARG;
+        hipLaunchKernelGGL(attn_vit_dma_kernel, dim3((unsigned)nblk), dim3(256), DSTAGES * DSTAGE, s, a);
+        return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+    }
     return launch_attn<64, false>(a, s);
 }
 
@@ -268,10 +599,10 @@ int launch_attn_prefill(const AttnArgs& a, hipStream_t s) {
 }
 
 int launch_transpose_v(const bf16_t* src, long src_bs, long src_hs, int src_rs, bf16_t* dst, long dst_bs, long dst_hs,
-                       int dst_rs, int n, int hd, int heads, int batch, hipStream_t s) {
+                       int dst_rs, int n, int hd, int heads, int batch, hipStream_t s, int perm) {
     if (dst_rs % 64 || dst_rs < n || (hd != 64 && hd != 128)) return TRACE_ERR_ARG;
     dim3 grid((n + 63) / 64, heads, batch);
-    if (hd == 64) hipLaunchKernelGGL(transpose_v_kernel<64>, grid, dim3(256), 0, s, src, src_bs, src_hs, src_rs, dst, dst_bs, dst_hs, dst_rs, n);
-    else hipLaunchKernelGGL(transpose_v_kernel<128>, grid, dim3(256), 0, s, src, src_bs, src_hs, src_rs, dst, dst_bs, dst_hs, dst_rs, n);
+    if (hd == 64) hipLaunchKernelGGL(transpose_v_kernel<64>, grid, dim3(256), 0, s, src, src_bs, src_hs, src_rs, dst, dst_bs, dst_hs, dst_rs, n, perm);
+    else hipLaunchKernelGGL(transpose_v_kernel<128>, grid, dim3(256), 0, s, src, src_bs, src_hs, src_rs, dst, dst_bs, dst_hs, dst_rs, n, perm);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }

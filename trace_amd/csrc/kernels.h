@@ -49,13 +49,20 @@ struct AttnArgs {
     int batch, heads, kv_heads;
     float scale;
     int causal;                     // 1: query row i attends kv rows <= i + (nkv_rows - nq_rows)
+    // optional row-major view of V ([kv, hd] per (batch, kv head)): lets the head_dim-64 non-causal kernel fold a short tail of
+    // keys (nkv % 64 <= 8) in on the VALU instead of running a mostly-masked tile; null = masked tile
+    const bf16_t* Vrow; long vr_bs, vr_hs; int vr_rs;
+    int dbg;                        // microbenchmark knock-outs (0 = full kernel)
+    int v_perm;                     // V^T was written by launch_transpose_v(..., perm = 1): selects the LDS-DMA ViT kernel
 };
 // NB: V is passed PRE-TRANSPOSED: V^T[d, kv] with row stride v_rs (multiple of 64, >= nkv_rows, zero padded)
 int launch_attn_vit(const AttnArgs& a, hipStream_t s);       // head_dim 64, non-causal, heads == kv_heads
 int launch_attn_prefill(const AttnArgs& a, hipStream_t s);   // head_dim 128, causal, GQA 4:1
 // V [n, hd] (row stride src_rs) -> V^T [hd, dst_rs] per (batch, head); zero fill beyond n
 int launch_transpose_v(const bf16_t* src, long src_bs, long src_hs, int src_rs, bf16_t* dst, long dst_bs, long dst_hs,
-                       int dst_rs, int n, int hd, int heads, int batch, hipStream_t s);
+                       int dst_rs, int n, int hd, int heads, int batch, hipStream_t s, int perm = 0);
+// true: launch_attn_vit can run its LDS-DMA kernel for this key count -> transpose V with perm = 1 and set AttnArgs::v_perm
+bool attn_vit_wants_perm(int nkv_rows, bool has_vrow);
 
 // ---- SpatialSlotPool (slot_pool.hip) ----
 // feats rows: frame t patch p at feats + (t*frame_stride + p*row_stride); out RES [T*S, D] bf16 (pre-readout)

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define TRACE_ABI_VERSION 1
+#define TRACE_ABI_VERSION 2
 
 typedef struct trace_ctx trace_ctx;
 
@@ -40,6 +40,9 @@ typedef struct trace_config {
     int32_t vit_batch_frames; /* frames one trace_vit_forward call may take (ViT workspaces); 0 = max_frames.  Larger than
                                * max_frames lets a caller push the frames of several videos through the tower together (the
                                * tower is per-frame: results do not depend on the grouping) */
+    int32_t llm_weights_fp8;  /* 1 = the four decoder projections per layer run on the fp8 path (BASELINE config 5): e4m3 weights with a
+                               * scale per output row made at load from the bf16 tensors, activations quantised per token row on the
+                               * fly, fp8 MFMA with fp32 accumulation.  No reference counterpart; parity anchor = the bf16 path */
 } trace_config;
 
 const char* trace_last_error(void);
@@ -150,6 +153,12 @@ int trace_op_skinny_gemm(const void* X, const void* W, void* out, const void* R,
                          int w_tiled, void* stream);
 int trace_op_skinny_ks(int N, int K, int epilogue, int B);
 int trace_op_tile_pack(const void* W, void* Wt, int N, int K, void* stream);
+/* fp8 path pieces: row quantiser (X bf16 [rows,K] -> e4m3 bytes + scale[row] = amax/448), the W8A8 GEMM
+   C = (A8 . W8^T) * sa[m] * sw[n] (+ residual / SwiGLU epilogue as trace_op_gemm), and the decode GEMV (fp32 out [B,N]) */
+int trace_op_quant_rows_fp8(const void* X, void* X8, float* sx, int rows, int K, void* stream);
+int trace_op_gemm_fp8(const void* A8, const float* sa, const void* W8, const float* sw, void* C, const void* R, int M, int N, int K,
+                      int epilogue, void* stream);
+int trace_op_skinny_fp8(const void* X8, const float* sx, const void* W8, const float* sw, float* out, int B, int N, int K, void* stream);
 /* out[b][j] = bf16(silu(sum_ks gate) * sum_ks up) from partial rows [KS][64][N2] of the 16-row interleaved gate|up GEMV */
 int trace_op_swiglu_combine(const float* part, int KS, int N2, void* out, int B, void* stream);
 /* x = bf16(sum_ks part[ks][b][:]) + R[b][:] -> xout;  y = RMSNorm(x) * w   (decode residual add + norm, N <= 4096) */

@@ -23,6 +23,7 @@ class TraceConfigC(C.Structure):
         ("max_frames", C.c_int32), ("max_ctx", C.c_int32), ("max_batch", C.c_int32), ("max_new_tokens", C.c_int32),
         ("projector_type", C.c_int32),
         ("vit_batch_frames", C.c_int32),
+        ("llm_weights_fp8", C.c_int32),
     ]
 
 
@@ -62,6 +63,9 @@ SIGNATURES = {
     "trace_op_set_gemm_trace": (I, [P]),
     "trace_op_skinny_ks": (I, [I, I, I, I]),
     "trace_op_tile_pack": (I, [P, P, I, I, P]),
+    "trace_op_quant_rows_fp8": (I, [P, P, P, I, I, P]),
+    "trace_op_gemm_fp8": (I, [P, P, P, P, P, P, I, I, I, I, P]),
+    "trace_op_skinny_fp8": (I, [P, P, P, P, P, I, I, I, P]),
     "trace_op_swiglu_combine": (I, [P, I, I, P, I, P]),
     "trace_op_add_rmsnorm": (I, [P, I, P, P, P, P, I, I, F, P]),
     "trace_op_attn_decode": (I, [P, P, P, P, P, P, I, I, I, I, I, F, P]),
@@ -90,7 +94,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.trace_abi_version() != 1:
+    if lib.trace_abi_version() != 2:
         raise TraceHipError("libtrace_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -27,6 +27,10 @@ struct VitLayer { bf16_t *ln1w, *ln1b, *wqkv, *bqkv, *wo, *bo, *ln2w, *ln2b, *w1
 struct LlmLayer {
     bf16_t *rms1, *wqkv, *wo, *rms2, *wgu, *wd;
     bf16_t *wqkv_d, *wo_d, *wgu_d, *wd_d;      // decode copies in the GEMV tile layout (decode.hip: launch_tile_pack)
+    // fp8 weight path (trace_config::llm_weights_fp8; fp8.hip): e4m3 row-major copies for the prefill GEMMs, tile-layout copies for the
+    // decode GEMVs, one fp32 scale per output row
+    uint8_t *wqkv8, *wo8, *wgu8, *wd8, *wqkv8_d, *wo8_d, *wgu8_d, *wd8_d;
+    float *sqkv, *so, *sgu, *sd;
 };
 struct StcBlock { bf16_t *w1, *n1w, *n1b, *wdw, *n2w, *n2b, *fc1w, *fc1b, *fc2w, *fc2b, *w3, *n3w, *n3b, *wd, *ndw, *ndb; int cin, rd; };
 
@@ -77,6 +81,9 @@ struct trace_ctx {
     int32_t* d_heads_tmp;                // head id per row for trace_llm_head_logits
     int B = 0, max_new = 0, eos = -1, has_forced = 0, ntiles = 0, nsplit = 32;
     int slot_len[64] = {0};
+    int fp8 = 0;                       // decoder projections on the fp8 path
+    uint8_t *pA8 = nullptr, *dA8 = nullptr;      // quantised activations: prefill [2 max_ctx][max(H, I)], decode [64][I]
+    float *psa = nullptr, *dsa = nullptr;        // their per-row scales
     int host_mode = 0, fed = 0;        // host-driven token selection (sampling): head logits only, ids fed back by the host
     int steps_done = 0;                // decode steps taken since trace_decode_begin (bounded by max_new - 1: the KV slot and the RoPE tables end at max_ctx)
     hipGraphExec_t graphs[SK_ROWS + 1] = {nullptr};   // one captured decode step per batch size
@@ -135,6 +142,8 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     if (c->H % 128 || c->I % 128 || c->vh % 128 || c->vi % 128 || c->QKV % 128) return bad("dims must be multiples of 128");
     if (c->H > 4096) return bad("hidden_size > 4096: the decode row kernels (norms, residual add) hold one 4096-wide row per workgroup");
     c->stc = cfg->projector_type == 1;
+    c->fp8 = cfg->llm_weights_fp8 != 0;
+    if (c->fp8 && (c->H % 128 || c->I % 128 || c->I > 16384)) return bad("fp8 weight path needs hidden / intermediate sizes that are multiples of 128 (intermediate <= 16384)");
     if (!c->stc && (c->S != 8 || c->vh > 1024)) return bad("slot pool kernel needs 8 slots and mm_hidden <= 1024");
     if (c->max_B < 1 || c->max_B > 64) return bad("max_batch (KV slots) must be in [1,64]");
     c->nsplit = 32;                                           // upper bound (workspace size); per-batch value below
@@ -180,6 +189,11 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     for (auto& l : c->llm) {
         A(l.rms1, H); A(l.wqkv, (size_t)c->QKV * H); A(l.wo, H * H); A(l.rms2, H); A(l.wgu, 2 * I * H); A(l.wd, H * I);
         A(l.wqkv_d, (size_t)c->QKV * H); A(l.wo_d, H * H); A(l.wgu_d, 2 * I * H); A(l.wd_d, H * I);
+        if (c->fp8) {
+            A(l.wqkv8, (size_t)c->QKV * H); A(l.wo8, H * H); A(l.wgu8, 2 * I * H); A(l.wd8, H * I);
+            A(l.wqkv8_d, (size_t)c->QKV * H); A(l.wo8_d, H * H); A(l.wgu8_d, 2 * I * H); A(l.wd8_d, H * I);
+            A(l.sqkv, (size_t)c->QKV); A(l.so, H); A(l.sgu, 2 * I); A(l.sd, H);
+        }
     }
     A(c->slot_cos, (size_t)c->GG * vh / 2); A(c->slot_sin, (size_t)c->GG * vh / 2);
     A(c->rope_cos, (size_t)c->max_ctx * c->HD / 2); A(c->rope_sin, (size_t)c->max_ctx * c->HD / 2);
@@ -207,6 +221,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     A(c->pX, 2 * Lm * H); A(c->pH, 2 * Lm * H); A(c->pQKV, 2 * Lm * c->QKV);
     A(c->pO, 2 * Lm * H); A(c->pACT, 2 * Lm * I);
     A(c->d_kind, Lm); A(c->d_row, Lm);
+    if (c->fp8) { A(c->pA8, 2 * Lm * std::max(H, I)); A(c->psa, 2 * Lm); A(c->dA8, (size_t)SK_ROWS * std::max(H, I)); A(c->dsa, SK_ROWS); }
     // --- decode ---
     A(c->dX, SK_ROWS * H); A(c->dH, SK_ROWS * H); A(c->dQKV, SK_ROWS * (size_t)c->QKV); A(c->dO, SK_ROWS * H); A(c->dACT, SK_ROWS * I);
     A(c->xlast, 64 * H);
@@ -450,6 +465,16 @@ extern "C" int trace_ctx_finalize(trace_ctx* c) {
         LCHK(launch_tile_pack(l.wo, c->H, l.wo_d, c->H, c->H, 0));
         LCHK(launch_tile_pack(l.wgu, c->H, l.wgu_d, 2 * c->I, c->H, 0));
         LCHK(launch_tile_pack(l.wd, c->I, l.wd_d, c->H, c->I, 0));
+        if (c->fp8) {      // per-output-row e4m3 quantisation of the four projections (from the bf16 copies), then the decode tile layout
+            LCHK(launch_quant_rows_fp8(l.wqkv, c->H, l.wqkv8, c->H, l.sqkv, c->QKV, c->H, 0));
+            LCHK(launch_quant_rows_fp8(l.wo, c->H, l.wo8, c->H, l.so, c->H, c->H, 0));
+            LCHK(launch_quant_rows_fp8(l.wgu, c->H, l.wgu8, c->H, l.sgu, 2 * c->I, c->H, 0));
+            LCHK(launch_quant_rows_fp8(l.wd, c->I, l.wd8, c->I, l.sd, c->H, c->I, 0));
+            LCHK(launch_tile_pack_fp8(l.wqkv8, c->H, l.wqkv8_d, c->QKV, c->H, 0));
+            LCHK(launch_tile_pack_fp8(l.wo8, c->H, l.wo8_d, c->H, c->H, 0));
+            LCHK(launch_tile_pack_fp8(l.wgu8, c->H, l.wgu8_d, 2 * c->I, c->H, 0));
+            LCHK(launch_tile_pack_fp8(l.wd8, c->I, l.wd8_d, c->H, c->I, 0));
+        }
     }
     HIPCHK(hipDeviceSynchronize());
     c->finalized = true;
@@ -461,9 +486,19 @@ static unsigned long long* g_gemm_trace = nullptr;      // tools/gemm_trace.py
 extern "C" int trace_op_set_gemm_trace(void* buf) { g_gemm_trace = (unsigned long long*)buf; return TRACE_OK; }
 static int gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* C, int ldc, const bf16_t* bias, const bf16_t* R,
                 int ldr, int M, int N, int K, int epi, hipStream_t s) {
-    GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, g_gemm_trace};
+    GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, g_gemm_trace, 0, nullptr, nullptr};
     const int rc = launch_gemm_bf16(g, epi, s);
     if (rc != TRACE_OK) return fail(rc, "gemm launch failed (M=" + std::to_string(M) + " N=" + std::to_string(N) + " K=" + std::to_string(K) + ")");
+    return TRACE_OK;
+}
+
+// C = (quantise_rows(A) . W8^T) * scales (+ epilogue): A [M,K] bf16 is quantised row-wise into c->pA8 / c->psa first
+static int gemm_fp8(trace_ctx* c, const bf16_t* A, int lda, const uint8_t* W8, const float* sw, bf16_t* C, int ldc, const bf16_t* R, int ldr,
+                    int M, int N, int K, int epi, hipStream_t s) {
+    LCHK(launch_quant_rows_fp8(A, lda, c->pA8, K, c->psa, M, K, s));
+    GemmArgs g{reinterpret_cast<const bf16_t*>(c->pA8), K, reinterpret_cast<const bf16_t*>(W8), K, C, ldc, nullptr, R, ldr, M, N, K, nullptr, 1, c->psa, sw};
+    const int rc = launch_gemm_bf16(g, epi, s);
+    if (rc != TRACE_OK) return fail(rc, "fp8 gemm launch failed (M=" + std::to_string(M) + " N=" + std::to_string(N) + " K=" + std::to_string(K) + ")");
     return TRACE_OK;
 }
 
@@ -791,7 +826,8 @@ static int prefill_impl(trace_ctx* c, int slot0, int nb, int L, void* hidden_out
         bf16_t* kc = c->kcache + (size_t)l * c->layer_stride;
         bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
         LCHK(launch_rmsnorm(c->pX, H, c->pH, H, W.rms1, M, H, c->c.rms_eps, s));
-        TRY(gemm(c->pH, H, W.wqkv, H, c->pQKV, QKV, nullptr, nullptr, 0, M, QKV, H, EPI_NONE, s));
+        if (c->fp8) { TRY(gemm_fp8(c, c->pH, H, W.wqkv8, W.sqkv, c->pQKV, QKV, nullptr, 0, M, QKV, H, EPI_NONE, s)); }
+        else TRY(gemm(c->pH, H, W.wqkv, H, c->pQKV, QKV, nullptr, nullptr, 0, M, QKV, H, EPI_NONE, s));
         LCHK(launch_rope_kv(c->pQKV, QKV, kc, nullptr, (long)c->slot_stride, (long)c->kv_head_stride, nullptr, nullptr, slot0, 0, M,
                             c->NQ, c->NKV, HD, c->rope_cos, c->rope_sin, L, s));
         // V goes into the cache transposed ([kvh][hd][ctx_pad]; positions L..Lpad-1 are zero-filled, later overwritten)
@@ -800,6 +836,13 @@ static int prefill_impl(trace_ctx* c, int slot0, int nb, int L, void* hidden_out
         a.K = kc + (size_t)slot0 * c->slot_stride;
         a.V = vc + (size_t)slot0 * c->slot_stride;
         LCHK(launch_attn_prefill(a, s));
+        if (c->fp8) {
+            TRY(gemm_fp8(c, c->pO, H, W.wo8, W.so, c->pX, H, c->pX, H, M, H, H, EPI_RESIDUAL, s));
+            LCHK(launch_rmsnorm(c->pX, H, c->pH, H, W.rms2, M, H, c->c.rms_eps, s));
+            TRY(gemm_fp8(c, c->pH, H, W.wgu8, W.sgu, c->pACT, I, nullptr, 0, M, 2 * I, H, EPI_SWIGLU, s));
+            TRY(gemm_fp8(c, c->pACT, I, W.wd8, W.sd, c->pX, H, c->pX, H, M, H, I, EPI_RESIDUAL, s));
+            continue;
+        }
         TRY(gemm(c->pO, H, W.wo, H, c->pX, H, nullptr, c->pX, H, M, H, H, EPI_RESIDUAL, s));
         LCHK(launch_rmsnorm(c->pX, H, c->pH, H, W.rms2, M, H, c->c.rms_eps, s));
         TRY(gemm(c->pH, H, W.wgu, H, c->pACT, I, nullptr, nullptr, 0, M, 2 * I, H, EPI_SWIGLU, s));
@@ -884,8 +927,14 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
     // Every GEMV leaves fp32 k-chunk partial rows in sk_ws and its consumer sums them on load (an in-kernel merge costs
     // 5-8 us of dependent round trips per GEMV): qkv -> attention (RoPE + cache append + attention) -> o -> [sum + residual
     // -> new residual, RMSNorm] -> gate|up -> [sum, SwiGLU] -> down -> [sum + residual, next layer's / the final RMSNorm].
-    const int ks_q = skinny_ks(QKV, H, EPI_PARTIAL, B), ks_o = skinny_ks(H, H, EPI_PARTIAL, B);
-    const int ks_g = skinny_ks(2 * I, H, EPI_PARTIAL, B), ks_d = skinny_ks(H, I, EPI_PARTIAL, B);
+    const bool f8 = c->fp8;
+    const int ks_q = f8 ? skinny_fp8_ks(QKV, H, B) : skinny_ks(QKV, H, EPI_PARTIAL, B), ks_o = f8 ? skinny_fp8_ks(H, H, B) : skinny_ks(H, H, EPI_PARTIAL, B);
+    const int ks_g = f8 ? skinny_fp8_ks(2 * I, H, B) : skinny_ks(2 * I, H, EPI_PARTIAL, B), ks_d = f8 ? skinny_fp8_ks(H, I, B) : skinny_ks(H, I, EPI_PARTIAL, B);
+    // fp8: the GEMV's activations are quantised row-wise first (quant_rows_fp8: [B, K] bf16 -> e4m3 + per-row scale), the weights come
+    // from the e4m3 tile copy; partial rows, their consumers and the attention are the bf16 path's
+#define GEMV8(X_, W8D_, SW_, N_, K_)                                                                           \
+    LCHK(launch_quant_rows_fp8((X_), (K_), c->dA8, (K_), c->dsa, B, (K_), s));                                  \
+    LCHK(launch_skinny_fp8(c->dA8, (K_), c->dsa, (W8D_), (SW_), B, (N_), (K_), c->sk_ws, c->sk_ws_floats, s));
     LCHK(launch_rmsnorm(c->dX, H, c->dH, H, c->llm[0].rms1, B, H, c->c.rms_eps, s));
     for (int l = 0; l < c->NL; ++l) {
         const LlmLayer& W = c->llm[l];
@@ -893,11 +942,13 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
         bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
         // (fusing the RMSNorm into the GEMV itself was tried: re-scaling the same activations in every workgroup cost
         //  more than a row kernel — 65 us vs 52 + 6 us for the gate|up GEMV)
-        LCHK(launch_skinny_gemm(c->dH, H, W.wqkv_d, H, nullptr, QKV, nullptr, 0, B, QKV, H, EPI_PARTIAL, 1, SKWS(c), s));
+        if (f8) { GEMV8(c->dH, W.wqkv8_d, W.sqkv, QKV, H) }
+        else LCHK(launch_skinny_gemm(c->dH, H, W.wqkv_d, H, nullptr, QKV, nullptr, 0, B, QKV, H, EPI_PARTIAL, 1, SKWS(c), s));
         LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots, c->d_pos, c->dO,
                                 H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, decode_nsplit(B), 1.0f / sqrtf((float)HD), 1,
                                 c->rope_cos, c->rope_sin, c->sk_ws, ks_q, s));
-        LCHK(launch_skinny_gemm(c->dO, H, W.wo_d, H, nullptr, H, nullptr, 0, B, H, H, EPI_PARTIAL, 1, SKWS(c), s));
+        if (f8) { GEMV8(c->dO, W.wo8_d, W.so, H, H) }
+        else LCHK(launch_skinny_gemm(c->dO, H, W.wo_d, H, nullptr, H, nullptr, 0, B, H, H, EPI_PARTIAL, 1, SKWS(c), s));
         LCHK(launch_add_rmsnorm(c->sk_ws, ks_o, c->dX, H, c->dX, H, W.rms2, c->dH, H, B, H, c->c.rms_eps, s));
         // roofline probe: HIP events around ONE launch of the dominant kernel (layer 0 gate|up GEMV) per step
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -906,13 +957,16 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
             if (s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) { e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2; }
         }
         if (e0) hipEventRecord(e0, s);
-        LCHK(launch_skinny_gemm(c->dH, H, W.wgu_d, H, nullptr, 2 * I, nullptr, 0, B, 2 * I, H, EPI_PARTIAL, 1, SKWS(c), s));
+        if (f8) { GEMV8(c->dH, W.wgu8_d, W.sgu, 2 * I, H) }
+        else LCHK(launch_skinny_gemm(c->dH, H, W.wgu_d, H, nullptr, 2 * I, nullptr, 0, B, 2 * I, H, EPI_PARTIAL, 1, SKWS(c), s));
         if (e1) hipEventRecord(e1, s);
         LCHK(launch_swiglu_combine(c->sk_ws, ks_g, 2 * I, c->dACT, I, B, s));
-        LCHK(launch_skinny_gemm(c->dACT, I, W.wd_d, I, nullptr, H, nullptr, 0, B, H, I, EPI_PARTIAL, 1, SKWS(c), s));
+        if (f8) { GEMV8(c->dACT, W.wd8_d, W.sd, H, I) }
+        else LCHK(launch_skinny_gemm(c->dACT, I, W.wd_d, I, nullptr, H, nullptr, 0, B, H, I, EPI_PARTIAL, 1, SKWS(c), s));
         const bf16_t* nw = l + 1 < c->NL ? c->llm[l + 1].rms1 : c->final_norm;
         LCHK(launch_add_rmsnorm(c->sk_ws, ks_d, c->dX, H, c->dX, H, nw, c->dH, H, B, H, c->c.rms_eps, s));
     }
+#undef GEMV8
     return head_and_select(c, c->dH, 1, logits_out, s);
 }
 
@@ -1119,6 +1173,40 @@ extern "C" int trace_op_skinny_gemm(const void* X, const void* W, void* out, con
     return TRACE_OK;
 }
 extern "C" int trace_op_skinny_ks(int N, int K, int epilogue, int B) { return skinny_ks(N, K, epilogue, B); }
+// ---- fp8 path hooks (tests/test_gpu_fp8.py) ----
+extern "C" int trace_op_quant_rows_fp8(const void* X, void* X8, float* sx, int rows, int K, void* stream) {
+    LCHK(launch_quant_rows_fp8((const bf16_t*)X, K, (uint8_t*)X8, K, sx, rows, K, (hipStream_t)stream));
+    return TRACE_OK;
+}
+extern "C" int trace_op_gemm_fp8(const void* A8, const float* sa, const void* W8, const float* sw, void* C, const void* R, int M, int N, int K,
+                                 int epilogue, void* stream) {
+    const int No = epilogue == EPI_SWIGLU ? N / 2 : N;
+    GemmArgs g{(const bf16_t*)A8, K, (const bf16_t*)W8, K, (bf16_t*)C, No, nullptr, (const bf16_t*)R, No, M, N, K, nullptr, 1, sa, sw};
+    const int rc = launch_gemm_bf16(g, epilogue, (hipStream_t)stream);
+    if (rc != TRACE_OK) return fail(rc, "fp8 gemm launch failed");
+    return TRACE_OK;
+}
+// X8 [B,K] e4m3 + sx, W8 [N,K] e4m3 row-major + sw -> out fp32 [B,N] (the k-chunk partial rows summed here, in chunk order)
+extern "C" int trace_op_skinny_fp8(const void* X8, const float* sx, const void* W8, const float* sw, float* out, int B, int N, int K, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    static uint8_t* wt = nullptr; static size_t wt_bytes = 0;
+    static float* ws = nullptr; static size_t ws_floats = 0;
+    const size_t need_w = (size_t)N * K, need_ws = (size_t)skinny_fp8_ks(N, K, B) * SK_ROWS * N;
+    if (need_w > wt_bytes) { HIPCHK(hipDeviceSynchronize()); if (wt) hipFree(wt); HIPCHK(hipMalloc((void**)&wt, need_w)); wt_bytes = need_w; }
+    if (need_ws > ws_floats) { HIPCHK(hipDeviceSynchronize()); if (ws) hipFree(ws); HIPCHK(hipMalloc((void**)&ws, need_ws * 4)); ws_floats = need_ws; }
+    LCHK(launch_tile_pack_fp8((const uint8_t*)W8, K, wt, N, K, s));
+    LCHK(launch_skinny_fp8((const uint8_t*)X8, K, sx, wt, sw, B, N, K, ws, ws_floats, s));
+    const int KS = skinny_fp8_ks(N, K, B);
+    std::vector<float> h((size_t)KS * SK_ROWS * N), o((size_t)B * N, 0.f);
+    HIPCHK(hipMemcpyAsync(h.data(), ws, h.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int ks = 0; ks < KS; ++ks)
+        for (int b = 0; b < B; ++b)
+            for (int n = 0; n < N; ++n) o[(size_t)b * N + n] += h[((size_t)ks * SK_ROWS + b) * N + n];
+    HIPCHK(hipMemcpy(out, o.data(), o.size() * 4, hipMemcpyHostToDevice));
+    return TRACE_OK;
+}
+
 extern "C" int trace_op_tile_pack(const void* W, void* Wt, int N, int K, void* stream) {
     LCHK(launch_tile_pack((const bf16_t*)W, K, (bf16_t*)Wt, N, K, (hipStream_t)stream));
     return TRACE_OK;

@@ -47,8 +47,24 @@ __device__ __forceinline__ int swz(int row, int kc) { return row * 128 + ((kc ^ 
 // (7) What did work: LOADER WAVES — gemm_ldr.hip is this kernel with the LDS-DMA issue moved to four extra waves (+20-24 % on
 // the K = 1024 shapes, bit-identical); the reason (1)-(5) changed nothing is that in all of them the waves that wait on the
 // address path are the waves that should be issuing MFMAs.
-template <int BM, int BN, int WM, int WN, int EPI>
+// FP8 = true (fp8.hip's W8A8 path): A and W are e4m3 bytes — the same 128-byte LDS rows then hold 128 k instead of 64, a lane's
+// 16-byte fragment read is TWO fp8 MFMA operands (v_mfma_f32_16x16x32_fp8_fp8; which k a slot means only has to agree between the two
+// operands), and the epilogue multiplies the accumulators by the row scale of A and the row scale of W.
+typedef long long2_t __attribute__((ext_vector_type(2)));
+template <bool FP8>
+__device__ __forceinline__ f32x4_t mma_step(const bf16x8_t& w, const bf16x8_t& a, f32x4_t acc) {
+    if constexpr (FP8) {
+        const long2_t w2 = __builtin_bit_cast(long2_t, w), a2 = __builtin_bit_cast(long2_t, a);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[0], a2[0], acc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[1], a2[1], acc, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, acc, 0, 0, 0);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, bool FP8>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
+    constexpr int ESZ = FP8 ? 1 : 2, CE = 16 / ESZ;       // element bytes, elements per 16-byte chunk
     constexpr int NW = WM * WN, NTHR = NW * 64;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
@@ -76,18 +92,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     unsigned long long* tr = p.trace ? p.trace + (size_t)blockIdx.x * 8 : nullptr;
     if (tr && threadIdx.x == 0) { tr[0] = __builtin_amdgcn_s_memrealtime(); tr[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); tr[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); }
 
-    const bf16_t* asrc[A_IT];
-    const bf16_t* wsrc[W_IT];
+    const char* asrc[A_IT];
+    const char* wsrc[W_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int slot = i * NTHR + tid, row = slot >> 3, kc = (slot & 7) ^ ((row >> 1) & 7);
         const int am = min(m0 + row, p.M - 1);
-        asrc[i] = p.A + (size_t)am * p.lda + kc * 8;
+        asrc[i] = reinterpret_cast<const char*>(p.A) + ((size_t)am * p.lda + kc * CE) * ESZ;
     }
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
         const int slot = i * NTHR + tid, row = slot >> 3, kc = (slot & 7) ^ ((row >> 1) & 7);
-        wsrc[i] = p.W + (size_t)(n0 + row) * p.ldw + kc * 8;
+        wsrc[i] = reinterpret_cast<const char*>(p.W) + ((size_t)(n0 + row) * p.ldw + kc * CE) * ESZ;
     }
     // SPREAD: issue the next tile's LDS-DMA pieces between the MFMA groups (pays on the 8-wave 256^2 tile: +3..5 %;
     // on the 4-wave 128^2 tile with 2-3 workgroups per CU it measured -19 %, so that one issues them up front)
@@ -96,7 +112,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     auto w_stage = [&](int i) -> char* { return smem + i * STAGE + A_BYTES; };
     auto issue_a = [&](int kt) {
         char* sa = a_stage(kt & 1);
-        const int ko = kt * BK;
+        const int ko = kt * 128;                       // bytes: one K-tile = 128-byte rows
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + ko),
@@ -105,7 +121,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     // one 1-KiB-per-wave piece of tile kt (pieces 0..A_IT-1 = A, A_IT.. = W); issued BETWEEN MFMA groups so the
     // ~100-cycle issue cost of each LDS-DMA hides under the matrix pipe instead of delaying the first MFMA of the tile
     auto issue_piece = [&](int kt, int piece) {
-        const int ko = kt * BK;
+        const int ko = kt * 128;                       // bytes: one K-tile = 128-byte rows
         if (piece < A_IT) {
             char* sa = a_stage(kt & 1);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[piece] + ko),
@@ -119,7 +135,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     };
     auto issue_w = [&](int kt) {
         char* sw = w_stage(kt & 1);
-        const int ko = kt * BK;
+        const int ko = kt * 128;                       // bytes: one K-tile = 128-byte rows
 #pragma unroll
         for (int i = 0; i < W_IT; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + ko),
@@ -137,7 +153,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) woff[j] = swz(wn * (BN / WN) + j * 16 + r, g);
 
-    const int nk = p.K / BK;
+    const int nk = p.K * ESZ / 128;
     issue_a(0); issue_w(0);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                                   // tile kt landed (vmcnt(0) + barrier); everyone is done with tile kt-1
@@ -167,8 +183,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
                 for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[2 * ip + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], ac[ii], acc[2 * ip + ii][j], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);
+                        acc[2 * ip + ii][j] = mma_step<FP8>(wf[j], ac[ii], acc[2 * ip + ii][j]);
+                __builtin_amdgcn_sched_group_barrier(0x008, (FP8 ? 4 : 2) * TN, 0);
                 if (more) {
                     constexpr int PPG = (A_IT + W_IT) / TM;            // pieces per MFMA group
 #pragma unroll
@@ -202,8 +218,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         uint2 b2 = make_uint2(0u, 0u);
-        if (!GLU && p.bias) b2 = *reinterpret_cast<const uint2*>(p.bias + n0 + wn * (BN / WN) + j * 16 + g * 4);
+        if (!FP8 && !GLU && p.bias) b2 = *reinterpret_cast<const uint2*>(p.bias + n0 + wn * (BN / WN) + j * 16 + g * 4);   // (the fp8 path is the bias-free LLM)
         bv[j][0] = bflo(b2.x); bv[j][1] = bfhi(b2.x); bv[j][2] = bflo(b2.y); bv[j][3] = bfhi(b2.y);
+    }
+    // fp8: scale of the lane's TM rows (A rows) and of its 4 columns per column tile (W rows)
+    float sar[FP8 ? TM : 1], swc[FP8 ? TN : 1][4];
+    if constexpr (FP8) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) sar[i] = p.sa[min(m0 + wm * (BM / WM) + i * 16 + r, p.M - 1)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(p.sw + n0 + wn * (BN / WN) + j * 16 + g * 4);
+            swc[j][0] = t4[0]; swc[j][1] = t4[1]; swc[j][2] = t4[2]; swc[j][3] = t4[3];
+        }
     }
     __syncthreads();
     if (tr && threadIdx.x == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
@@ -218,7 +245,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float x = acc[i][j][q] + bv[j][q];
+                    float x = acc[i][j][q];
+                    if constexpr (FP8) x *= sar[i] * swc[j][q];
+                    else x += bv[j][q];
                     if (EPI == EPI_QUICKGELU) x = x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x));   // x*sigmoid(1.702x)
                     v[q] = x;
                 }
@@ -231,7 +260,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float gt = acc[i][2 * jj][q], up = acc[i][2 * jj + 1][q];
+                    float gt = acc[i][2 * jj][q], up = acc[i][2 * jj + 1][q];
+                    if constexpr (FP8) { gt *= sar[i] * swc[2 * jj][q]; up *= sar[i] * swc[2 * jj + 1][q]; }
                     v[q] = gt * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gt)) * up;   // silu(g)*u
                 }
                 *reinterpret_cast<uint2*>(smem + mrow * OSTRIDE + nl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
@@ -262,7 +292,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
 }
 
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool FP8>
 int launch_glds(const GemmArgs& p, int epi, hipStream_t s) {
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int LOOPB = 2 * STAGE;
@@ -272,17 +302,17 @@ int launch_glds(const GemmArgs& p, int epi, hipStream_t s) {
     const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_RESIDUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_QUICKGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_SWIGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_NONE, FP8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_RESIDUAL, FP8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_QUICKGELU, FP8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_SWIGLU, FP8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     switch (epi) {
-        case EPI_NONE: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_NONE>), dim3(nblk), dim3(NTHR), lds, s, p); break;
-        case EPI_RESIDUAL: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_RESIDUAL>), dim3(nblk), dim3(NTHR), lds, s, p); break;
-        case EPI_QUICKGELU: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_QUICKGELU>), dim3(nblk), dim3(NTHR), lds, s, p); break;
-        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_SWIGLU>), dim3(nblk), dim3(NTHR), lds, s, p); break;
+        case EPI_NONE: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_NONE, FP8>), dim3(nblk), dim3(NTHR), lds, s, p); break;
+        case EPI_RESIDUAL: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_RESIDUAL, FP8>), dim3(nblk), dim3(NTHR), lds, s, p); break;
+        case EPI_QUICKGELU: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_QUICKGELU, FP8>), dim3(nblk), dim3(NTHR), lds, s, p); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_SWIGLU, FP8>), dim3(nblk), dim3(NTHR), lds, s, p); break;
         default: return TRACE_ERR_ARG;
     }
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
@@ -294,6 +324,7 @@ int g_gemm_variant = 0;   // 0 = auto, 2 = 128^2 tiles, 3 = this file's 256^2 ke
 
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
     if (p.M <= 0 || p.N % BN || p.K % BK || p.K < BK) return TRACE_ERR_ARG;
+    if (p.fp8 && (p.K % 128 || (p.lda % 16) || (p.ldw % 16) || !p.sa || !p.sw || p.bias || epi == EPI_QUICKGELU)) return TRACE_ERR_ARG;
     if ((p.lda % 8) || (p.ldw % 8) || (p.ldc % 8)) return TRACE_ERR_ARG;
     if (epi == EPI_RESIDUAL && (!p.R || (p.ldr % 8))) return TRACE_ERR_ARG;
     {
@@ -310,7 +341,7 @@ int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
         // 256^2 tiles chosen automatically run on the loader-wave kernel (gemm_ldr.hip: same results bit for bit, +20-24 % on the
         // K = 1024 ViT shapes); variant 3 forces this file's kernel for A/B runs
         if (p.N % 256 == 0 && (g_gemm_variant == 4 || (g_gemm_variant == 0 && v == 3))) return launch_gemm_ldr(p, epi, s);
-        if (v == 3 && p.N % 256 == 0) return launch_glds<256, 256, 2, 4>(p, epi, s);
+        if (v == 3 && p.N % 256 == 0) return p.fp8 ? launch_glds<256, 256, 2, 4, true>(p, epi, s) : launch_glds<256, 256, 2, 4, false>(p, epi, s);
     }
-    return launch_glds<128, 128, 2, 2>(p, epi, s);
+    return p.fp8 ? launch_glds<128, 128, 2, 2, true>(p, epi, s) : launch_glds<128, 128, 2, 2, false>(p, epi, s);
 }

@@ -26,8 +26,21 @@ constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
 
 __device__ __forceinline__ int swz(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
 
-template <int EPI>
+typedef long long2_t __attribute__((ext_vector_type(2)));
+template <bool FP8>
+__device__ __forceinline__ f32x4_t mma_step(const bf16x8_t& w, const bf16x8_t& a, f32x4_t acc) {
+    if constexpr (FP8) {      // fp8.hip's W8A8 path: a 16-byte fragment is two e4m3 MFMA operands (see gemm.hip)
+        const long2_t w2 = __builtin_bit_cast(long2_t, w), a2 = __builtin_bit_cast(long2_t, a);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[0], a2[0], acc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[1], a2[1], acc, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, acc, 0, 0, 0);
+    }
+}
+
+template <int EPI, bool FP8>
 __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
+    constexpr int ESZ = FP8 ? 1 : 2, CE = 16 / ESZ;
     constexpr bool GLU = (EPI == EPI_SWIGLU);
     constexpr int OSTRIDE = BN * 2 + 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -45,24 +58,25 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
         tn = in_g / gsz;
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int nk = p.K / BK;
+    const int nk = p.K * ESZ / 128;                    // K-tiles of 128-byte rows
 
     if (wid >= WM * WN) {
         // ---------------- loader wave lw: pieces of 8 tile rows x 128 bytes; lw 0,1 -> A rows 0..127 / 128..255, lw 2,3 -> W ----------------
         const int lw = wid - WM * WN;
         const bool isA = lw < 2;
         const int half = (lw & 1) * 128;
-        const bf16_t* src[16];
+        const char* src[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int row = half + j * 8 + (lane >> 3);
             const int kc = (lane & 7) ^ ((row >> 1) & 7);
-            src[j] = isA ? p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + kc * 8 : p.W + (size_t)(n0 + row) * p.ldw + kc * 8;
+            src[j] = isA ? reinterpret_cast<const char*>(p.A) + ((size_t)min(m0 + row, p.M - 1) * p.lda + kc * CE) * ESZ
+                         : reinterpret_cast<const char*>(p.W) + ((size_t)(n0 + row) * p.ldw + kc * CE) * ESZ;
         }
         const int region = (isA ? 0 : A_BYTES) + half * 128;
         auto issue = [&](int kt) {
             char* dst = smem + (kt & 1) * STAGE + region;
-            const int ko = kt * BK;
+            const int ko = kt * 128;
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + ko),
@@ -113,8 +127,8 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
                 for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[2 * ip + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], ac[ii], acc[2 * ip + ii][j], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);
+                        acc[2 * ip + ii][j] = mma_step<FP8>(wf[j], ac[ii], acc[2 * ip + ii][j]);
+                __builtin_amdgcn_sched_group_barrier(0x008, (FP8 ? 4 : 2) * TN, 0);
                 if (ip + 1 < TM / 2) { ac[0] = an[0]; ac[1] = an[1]; }
             }
         }
@@ -128,8 +142,18 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         uint2 b2 = make_uint2(0u, 0u);
-        if (!GLU && p.bias) b2 = *reinterpret_cast<const uint2*>(p.bias + n0 + wn * (BN / WN) + j * 16 + g * 4);
+        if (!FP8 && !GLU && p.bias) b2 = *reinterpret_cast<const uint2*>(p.bias + n0 + wn * (BN / WN) + j * 16 + g * 4);   // (the fp8 path is the bias-free LLM)
         bv[j][0] = bflo(b2.x); bv[j][1] = bfhi(b2.x); bv[j][2] = bflo(b2.y); bv[j][3] = bfhi(b2.y);
+    }
+    float sar[FP8 ? TM : 1], swc[FP8 ? TN : 1][4];
+    if constexpr (FP8) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) sar[i] = p.sa[min(m0 + wm * (BM / WM) + i * 16 + r, p.M - 1)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(p.sw + n0 + wn * (BN / WN) + j * 16 + g * 4);
+            swc[j][0] = t4[0]; swc[j][1] = t4[1]; swc[j][2] = t4[2]; swc[j][3] = t4[3];
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -142,7 +166,9 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float x = acc[i][j][q] + bv[j][q];
+                    float x = acc[i][j][q];
+                    if constexpr (FP8) x *= sar[i] * swc[j][q];
+                    else x += bv[j][q];
                     if (EPI == EPI_QUICKGELU) x = x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x));
                     v[q] = x;
                 }
@@ -155,7 +181,8 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float gt = acc[i][2 * jj][q], up = acc[i][2 * jj + 1][q];
+                    float gt = acc[i][2 * jj][q], up = acc[i][2 * jj + 1][q];
+                    if constexpr (FP8) { gt *= sar[i] * swc[2 * jj][q]; up *= sar[i] * swc[2 * jj + 1][q]; }
                     v[q] = gt * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gt)) * up;
                 }
                 *reinterpret_cast<uint2*>(smem + mrow * OSTRIDE + nl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
@@ -193,14 +220,14 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
     }
 }
 
-template <int EPI>
+template <int EPI, bool FP8>
 void launch_one(const GemmArgs& p, int nblk, size_t lds, hipStream_t s) {
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ldr_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ldr_kernel<EPI, FP8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         done = true;
     }
-    hipLaunchKernelGGL(gemm_ldr_kernel<EPI>, dim3(nblk), dim3(NTHR), lds, s, p);
+    hipLaunchKernelGGL((gemm_ldr_kernel<EPI, FP8>), dim3(nblk), dim3(NTHR), lds, s, p);
 }
 
 }  // namespace
@@ -210,11 +237,20 @@ int launch_gemm_ldr(const GemmArgs& p, int epi, hipStream_t s) {
     constexpr size_t LOOPB = 2 * STAGE, OBYTES = (size_t)BM * (BN * 2 + 16);
     const size_t lds = LOOPB > OBYTES ? LOOPB : OBYTES;
     const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
+    if (p.fp8) {
+        switch (epi) {
+            case EPI_NONE: launch_one<EPI_NONE, true>(p, nblk, lds, s); break;
+            case EPI_RESIDUAL: launch_one<EPI_RESIDUAL, true>(p, nblk, lds, s); break;
+            case EPI_SWIGLU: launch_one<EPI_SWIGLU, true>(p, nblk, lds, s); break;
+            default: return TRACE_ERR_ARG;
+        }
+        return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+    }
     switch (epi) {
-        case EPI_NONE: launch_one<EPI_NONE>(p, nblk, lds, s); break;
-        case EPI_RESIDUAL: launch_one<EPI_RESIDUAL>(p, nblk, lds, s); break;
-        case EPI_QUICKGELU: launch_one<EPI_QUICKGELU>(p, nblk, lds, s); break;
-        case EPI_SWIGLU: launch_one<EPI_SWIGLU>(p, nblk, lds, s); break;
+        case EPI_NONE: launch_one<EPI_NONE, false>(p, nblk, lds, s); break;
+        case EPI_RESIDUAL: launch_one<EPI_RESIDUAL, false>(p, nblk, lds, s); break;
+        case EPI_QUICKGELU: launch_one<EPI_QUICKGELU, false>(p, nblk, lds, s); break;
+        case EPI_SWIGLU: launch_one<EPI_SWIGLU, false>(p, nblk, lds, s); break;
         default: return TRACE_ERR_ARG;
     }
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;

@@ -16,6 +16,8 @@ struct GemmArgs {
     const bf16_t* R; int ldr;       // residual [M,N] for EPI_RESIDUAL (may alias C)
     int M, N, K;
     unsigned long long* trace;      // profiling only (tools/gemm_trace.py): 8 x u64 per workgroup, or null
+    // fp8 = 1: A and W point at e4m3 BYTES (lda / ldw in bytes, K % 128 == 0); C = (A8 . W8^T) * sa[m] * sw[n] (+ epilogue)
+    int fp8; const float* sa; const float* sw;
 };
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s);
 int launch_gemm_ldr(const GemmArgs& p, int epi, hipStream_t s);    // gemm_ldr.hip: 256x256 tiles, 8 MFMA + 4 loader waves (N % 256 == 0)
@@ -123,6 +125,16 @@ struct StepState {
 int launch_select_next(const float* part_val, const int32_t* part_idx, const StepState& st, const bf16_t* embed,
                        const bf16_t* time_tab, const bf16_t* score_tab, const bf16_t* sync_row, bf16_t* xnext, int ldx,
                        int B, int H, int V, int Tv, int Sv, int advance, hipStream_t s);
+
+// ---- fp8 (e4m3) weight path of the decoder (fp8.hip; the fp8 GEMM is launch_gemm_bf16 with GemmArgs::fp8 set) ----
+// X bf16 [rows][K] -> X8 e4m3 [rows][K] + sx[row] = amax/448 (per-row dynamic scale).  Also used row-wise on weight matrices at load.
+int launch_quant_rows_fp8(const bf16_t* X, long ldx, uint8_t* X8, long ld8, float* sx, int rows, int K, hipStream_t s);
+// W8 [N][K] bytes -> decode copy [N/16][K/128][64 lanes][32 B]
+int launch_tile_pack_fp8(const uint8_t* src, long ldw, uint8_t* dst, int N, int K, hipStream_t s);
+// decode GEMV on fp8 operands: fp32 partial rows [skinny_fp8_ks(N,K,B)][SK_ROWS][N] = (X8 . W8^T) * sx[m] * sw[n] in ws
+int launch_skinny_fp8(const uint8_t* X8, long ldx, const float* sx, const uint8_t* Wtiled, const float* sw, int B, int N, int K, float* ws,
+                      size_t ws_floats, hipStream_t s);
+int skinny_fp8_ks(int N, int K, int B);
 
 // ---- STC connector support (stc.hip): channels-last [n][h][w][C] row kernels ----
 int launch_dwconv3x3(const bf16_t* x, const bf16_t* w /*[C][9]*/, bf16_t* y, int N, int H, int W, int C, hipStream_t s);

@@ -29,7 +29,8 @@ def _i32(seq) -> "C.Array":
 
 class TraceEngine:
     def __init__(self, cfg: TraceConfig, device: int = 0, max_batch: int = 1, max_ctx: Optional[int] = None,
-                 max_frames: Optional[int] = None, max_new_tokens: int = 1024, vit_batch_frames: Optional[int] = None):
+                 max_frames: Optional[int] = None, max_new_tokens: int = 1024, vit_batch_frames: Optional[int] = None,
+                 llm_fp8: bool = False):
         if not torch.cuda.is_available():
             raise _lib.TraceHipError("no HIP device visible: the TRACE hot path only runs on an MI355X (no CPU fallback)")
         self.lib = _lib.load()
@@ -51,7 +52,8 @@ class TraceEngine:
             cfg.vision_hidden_size, cfg.vision_intermediate_size, cfg.vision_layers_used, cfg.vision_num_heads,
             cfg.vision_image_size, cfg.vision_patch_size, cfg.vision_layer_norm_eps, cfg.num_slots, cfg.slot_ln_eps,
             cfg.slot_rope_base, max_frames, max_ctx, max_batch, max_new_tokens,
-            1 if cfg.mm_projector_type == "stc_connector" else 0, self.vit_batch_frames)
+            1 if cfg.mm_projector_type == "stc_connector" else 0, self.vit_batch_frames, 1 if llm_fp8 else 0)
+        self.llm_fp8 = bool(llm_fp8)
         h = C.c_void_p()
         _lib.check(self.lib.trace_ctx_create(C.byref(c), device, C.byref(h)))
         self.h = h
@@ -465,3 +467,32 @@ class ops:
         _lib.check(lib.trace_op_attn_decode(_ptr(q), _ptr(kcache), _ptr(vcache), _ptr(pos), _ptr(o), _ptr(ws), Bn, nq, nkv,
                                             max_ctx, nsplit, scale, _stream()))
         return o
+
+    # ---- fp8 (e4m3) path pieces ----
+    @staticmethod
+    def quant_rows_fp8(X):
+        """X bf16 [rows, K] -> (uint8 e4m3 bytes [rows, K], fp32 scale [rows])"""
+        lib = _lib.load()
+        q = torch.empty(X.shape, dtype=torch.uint8, device=X.device)
+        sx = torch.empty((X.shape[0],), dtype=torch.float32, device=X.device)
+        _lib.check(lib.trace_op_quant_rows_fp8(_ptr(X), _ptr(q), _ptr(sx), X.shape[0], X.shape[1], _stream()))
+        return q, sx
+
+    @staticmethod
+    def gemm_fp8(A8, sa, W8, sw, R=None, epilogue=EPI_NONE):
+        lib = _lib.load()
+        M, K = A8.shape
+        N = W8.shape[0]
+        No = N // 2 if epilogue == EPI_SWIGLU else N
+        Cc = torch.empty((M, No), dtype=torch.bfloat16, device=A8.device)
+        _lib.check(lib.trace_op_gemm_fp8(_ptr(A8), _ptr(sa), _ptr(W8), _ptr(sw), _ptr(Cc), _ptr(R), M, N, K, epilogue, _stream()))
+        return Cc
+
+    @staticmethod
+    def skinny_fp8(X8, sx, W8, sw):
+        lib = _lib.load()
+        Bn, K = X8.shape
+        N = W8.shape[0]
+        out = torch.empty((Bn, N), dtype=torch.float32, device=X8.device)
+        _lib.check(lib.trace_op_skinny_fp8(_ptr(X8), _ptr(sx), _ptr(W8), _ptr(sw), _ptr(out), Bn, N, K, _stream()))
+        return out

@@ -105,8 +105,8 @@ CONFIGS = {
                name="C2: TRACE-7B bf16 (CLIP-ViT-L/14-336 23 layers + SpatialSlotPool + Mistral-7B)"),
     "c4": dict(frames=64, max_new=32, n_text=191, video_pos=150, schedule="mr", videos_per_step=64,
                name="C4: Charades-STA moment retrieval shape, TRACE-7B bf16"),
-    "c5": dict(frames=256, max_new=16, n_text=251, video_pos=200, schedule="dvc", videos_per_step=32,
-               name="C5 shape: VideoMME long video (256 frames, past MAX_FRAMES), TRACE-7B"),
+    "c5": dict(frames=256, max_new=16, n_text=251, video_pos=200, schedule="dvc", videos_per_step=32, fp8=True,
+               name="C5: VideoMME long video (256 frames, past MAX_FRAMES), TRACE-7B, fp8 (e4m3 W8A8) decoder projections"),
 }
 
 
@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--videos-per-step", type=int, default=None)
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--max-new", type=int, default=None)
+    ap.add_argument("--fp8", dest="fp8", action="store_true", default=None, help="decoder projections on the fp8 (e4m3 W8A8) path (default: on for --config c5)")
+    ap.add_argument("--no-fp8", dest="fp8", action="store_false")
     ap.add_argument("--plumbing-check", action="store_true", help="launcher / rendezvous / gather only, no kernels (CPU-testable)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the captured hipGraph for decode steps (default: eager launches, which run at the same speed "
@@ -169,6 +171,8 @@ def main():
         args.max_new = preset["max_new"]
     if args.videos_per_step is None:
         args.videos_per_step = int(os.environ.get("TRACE_BENCH_BATCH", preset["videos_per_step"]))
+    if args.fp8 is None:
+        args.fp8 = bool(preset.get("fp8", False))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -191,7 +195,7 @@ def main():
     ids = synth.synth_prompt_ids(cfg, n_text=n_text, video_pos=10 if args.tiny else preset["video_pos"]).tolist()
     L = n_text - 1 + args.frames * cfg.tokens_per_frame
     eng = TraceEngine(cfg, device=local, max_batch=B, max_ctx=(L + n_new + 63) // 64 * 64, max_frames=args.frames,
-                      max_new_tokens=n_new, vit_batch_frames=args.vit_batch)
+                      max_new_tokens=n_new, vit_batch_frames=args.vit_batch, llm_fp8=args.fp8)
     t0 = time.perf_counter()
     eng.load_weights(synth.iter_weights(cfg, device=str(dev)))
     torch.cuda.synchronize()
@@ -283,7 +287,8 @@ def main():
             "metric": "videos/sec + decode tok/s, TRACE-7B 128-frame, 1/2/4/8 MI355X",
             "value": vps, "unit": "videos/s", "n_gpus": world, "rccl_ranks": ranks_seen[0], "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": ("fp8 e4m3 (W8A8, fp32 accumulate) in the decoder projections; bf16 elsewhere (ViT, attention, KV cache, norms, heads)"
+                      if args.fp8 else "bf16"), "data": "synthetic",
             "config": {"workload": ("tiny plumbing check" if args.tiny else
                                     f"{preset['name']}, {args.frames}x336^2 frames, prefill L={Ls}, {n_new} greedy tokens, heads=[1]"),
                        "baseline_config": args.config,

@@ -97,6 +97,21 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restric
 
     // ---- park X[:, chunk] in LDS in fragment order: combo c = (unit*2 + half)*NB + nb, lane (r, g) holds
     //      X[16 nb + r][(u_beg + unit)*64 + g*16 + half*8 .. +8]  (zeros for rows >= B) ----
+    if (!parked && dbg != 6) {                          // (dbg == 6: the register-staged parking below, for A/B runs)
+        // parking by LDS-DMA: a combo is one lane-linear 1 KB image whose lanes read arbitrary 16-byte sources — exactly what
+        // global_load_lds does, with no register round trip, no ds_write and no index math in the way of the weight stream
+        // (rows >= B read row B-1 instead of zeros: their accumulator rows are never stored)
+        const int combos = nu * 2 * NB;
+        for (int c = wid; c < combos; c += nwaves) {
+            const int nb = c % NB, uh = c / NB, h = uh & 1, u = uh >> 1;
+            const int m = min(16 * nb + r, B - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (size_t)m * ldx + (size_t)(u_beg + u) * 64 + g * 16 + h * 8),
+                                             (__attribute__((address_space(3))) void*)(smem + (size_t)c * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        parked = true;
+    }
     if (!parked) {
         const int combos = nu * 2 * NB;
         for (int c0 = wid; c0 < combos; c0 += nwaves * 4) {

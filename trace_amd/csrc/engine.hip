@@ -1052,7 +1052,7 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
         c->prof[1] = (float)n;
         c->prof[2] = c->ksamples ? (float)(c->ksum_ms / c->ksamples) : 0.f;
         c->prof[3] = (float)c->ksamples;
-        c->prof[4] = (float)(2.0 * c->I * c->H * 2.0);      // algorithmic bytes of the bracketed launch (gate|up weights)
+        c->prof[4] = (float)(2.0 * c->I * c->H * (c->fp8 ? 1.0 : 2.0));      // algorithmic bytes of the bracketed launch (gate|up weights; fp8: the bracket also spans the activation quantiser)
     }
     return TRACE_OK;
 }

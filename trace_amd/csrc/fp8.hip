@@ -137,25 +137,15 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(const uint8_t* __restri
     const bool work = active && ua < ub;
     if (work) loadw(wa, ua);
     // park X8[:, chunk]: combo c = (unit*2 + half)*NB + nb, lane (r, g) holds X8[16 nb + r][(u_beg + unit)*128 + g*32 + half*16 .. +16]
-    if (!parked) {
+    if (!parked) {                                       // by LDS-DMA, one lane-linear 1 KB image per combo (see decode.hip); rows >= B read row B-1
         const int combos = nu * 2 * NB;
-        for (int c0 = wid; c0 < combos; c0 += nwaves * 4) {
-            u32x4_t v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = c0 + q * nwaves;
-                const int nb = c % NB, uh = c / NB, hh = uh & 1, u = uh >> 1;
-                const int m = 16 * nb + r;
-                v[q] = u32x4_t{0u, 0u, 0u, 0u};
-                if (c < combos && m < B)
-                    v[q] = *reinterpret_cast<const u32x4_t*>(X8 + (size_t)m * ldx + (size_t)(u_beg + u) * 128 + g * 32 + hh * 16);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = c0 + q * nwaves;
-                if (c < combos) xs[c * 64 + lane] = v[q];
-            }
+        for (int c = wid; c < combos; c += nwaves) {
+            const int nb = c % NB, uh = c / NB, hh = uh & 1, u = uh >> 1;
+            const int m = min(16 * nb + r, B - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X8 + (size_t)m * ldx + (size_t)(u_beg + u) * 128 + g * 32 + hh * 16),
+                                             (__attribute__((address_space(3))) void*)(smem + (size_t)c * 1024), 16, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         parked = true;
     }

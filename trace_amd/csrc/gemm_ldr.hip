@@ -87,7 +87,8 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
             __syncthreads();                       // own pieces of tile kt landed (vmcnt(0)); everyone is done with tile kt-1
             if (kt + 1 < nk) issue(kt + 1);
         }
-        __syncthreads();                           // the MFMA waves' two epilogue barriers
+        __syncthreads();                           // the MFMA waves' epilogue barriers (one more on the fp8 path: the scale rows)
+        if (FP8) __syncthreads();
         __syncthreads();
         return;
     }
@@ -118,18 +119,30 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
             __builtin_amdgcn_sched_group_barrier(0x100, TN + 2, 0);
 #pragma unroll
             for (int ip = 0; ip < TM / 2; ++ip) {
-                if (ip + 1 < TM / 2) {
-                    an[0] = *reinterpret_cast<const bf16x8_t*>(fa + (2 * ip + 2) * 2048);
-                    an[1] = *reinterpret_cast<const bf16x8_t*>(fa + (2 * ip + 3) * 2048);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                if constexpr (FP8) {
+                    // fp8: 16 MFMAs per pair of m-tiles instead of 8, and no room for the second fragment pair beside 128 accumulators
+                    // (the prefetch spilled inside the loop): the next pair's first fragment is prefetched under this pair's MFMAs, its
+                    // second one is read behind the first eight
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[2 * ip][j] = mma_step<true>(wf[j], ac[0], acc[2 * ip][j]);
+                    if (ip + 1 < TM / 2) ac[0] = *reinterpret_cast<const bf16x8_t*>(fa + (2 * ip + 2) * 2048);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[2 * ip + 1][j] = mma_step<true>(wf[j], ac[1], acc[2 * ip + 1][j]);
+                    if (ip + 1 < TM / 2) ac[1] = *reinterpret_cast<const bf16x8_t*>(fa + (2 * ip + 3) * 2048);
+                } else {
+                    if (ip + 1 < TM / 2) {
+                        an[0] = *reinterpret_cast<const bf16x8_t*>(fa + (2 * ip + 2) * 2048);
+                        an[1] = *reinterpret_cast<const bf16x8_t*>(fa + (2 * ip + 3) * 2048);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[2 * ip + ii][j] = mma_step<false>(wf[j], ac[ii], acc[2 * ip + ii][j]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);
+                    if (ip + 1 < TM / 2) { ac[0] = an[0]; ac[1] = an[1]; }
                 }
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[2 * ip + ii][j] = mma_step<FP8>(wf[j], ac[ii], acc[2 * ip + ii][j]);
-                __builtin_amdgcn_sched_group_barrier(0x008, (FP8 ? 4 : 2) * TN, 0);
-                if (ip + 1 < TM / 2) { ac[0] = an[0]; ac[1] = an[1]; }
             }
         }
     }
@@ -145,17 +158,16 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
         if (!FP8 && !GLU && p.bias) b2 = *reinterpret_cast<const uint2*>(p.bias + n0 + wn * (BN / WN) + j * 16 + g * 4);   // (the fp8 path is the bias-free LLM)
         bv[j][0] = bflo(b2.x); bv[j][1] = bfhi(b2.x); bv[j][2] = bflo(b2.y); bv[j][3] = bfhi(b2.y);
     }
-    float sar[FP8 ? TM : 1], swc[FP8 ? TN : 1][4];
-    if constexpr (FP8) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) sar[i] = p.sa[min(m0 + wm * (BM / WM) + i * 16 + r, p.M - 1)];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(p.sw + n0 + wn * (BN / WN) + j * 16 + g * 4);
-            swc[j][0] = t4[0]; swc[j][1] = t4[1]; swc[j][2] = t4[2]; swc[j][3] = t4[3];
-        }
-    }
+    // fp8: the 256 row scales of A and the 256 row scales of W go through LDS (behind the staged tile): holding a lane's 8 + 16 of
+    // them in registers beside the 128 accumulators spilled
+    float* s_sa = reinterpret_cast<float*>(smem + BM * OSTRIDE);
+    float* s_sw = s_sa + BM;
     __syncthreads();
+    if constexpr (FP8) {
+        if (tid < BM) s_sa[tid] = p.sa[min(m0 + tid, p.M - 1)];
+        else if (tid < BM + BN) s_sw[tid - BM] = p.sw[n0 + tid - BM];
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mrow = wm * (BM / WM) + i * 16 + r;
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float x = acc[i][j][q];
-                    if constexpr (FP8) x *= sar[i] * swc[j][q];
+                    if constexpr (FP8) x *= s_sa[mrow] * s_sw[nl + q];
                     else x += bv[j][q];
                     if (EPI == EPI_QUICKGELU) x = x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x));
                     v[q] = x;
@@ -182,7 +194,10 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float gt = acc[i][2 * jj][q], up = acc[i][2 * jj + 1][q];
-                    if constexpr (FP8) { gt *= sar[i] * swc[2 * jj][q]; up *= sar[i] * swc[2 * jj + 1][q]; }
+                    if constexpr (FP8) {
+                        const int cg = wn * (BN / WN) + (2 * jj) * 16 + g * 4 + q;       // gate column of the tile; its up column is 16 further
+                        gt *= s_sa[mrow] * s_sw[cg]; up *= s_sa[mrow] * s_sw[cg + 16];
+                    }
                     v[q] = gt * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gt)) * up;
                 }
                 *reinterpret_cast<uint2*>(smem + mrow * OSTRIDE + nl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
@@ -234,7 +249,7 @@ void launch_one(const GemmArgs& p, int nblk, size_t lds, hipStream_t s) {
 
 int launch_gemm_ldr(const GemmArgs& p, int epi, hipStream_t s) {
     if (p.M < 1 || p.N % BN || p.K % BK) return TRACE_ERR_ARG;
-    constexpr size_t LOOPB = 2 * STAGE, OBYTES = (size_t)BM * (BN * 2 + 16);
+    constexpr size_t LOOPB = 2 * STAGE, OBYTES = (size_t)BM * (BN * 2 + 16) + (BM + BN) * 4;     // + the fp8 scale rows
     const size_t lds = LOOPB > OBYTES ? LOOPB : OBYTES;
     const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
     if (p.fp8) {

@@ -27,6 +27,21 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Sum over the 64 lanes on DPP (VALU speed, no LDS crossbar round trips): quad swaps, row mirrors, then the two row broadcasts leave the
+// total in lane 63; readlane returns it to every lane (as a scalar).  Fixed order.  __shfl_xor compiles to ds_bpermute_b32 — ~120
+// cycles of latency per step, which made per-row reductions the critical path of the slot pool.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define TRACE_DPP_ADD(CTRL, ROWMASK) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, true))
+    TRACE_DPP_ADD(0xB1, 0xf);      // quad_perm [1,0,3,2]
+    TRACE_DPP_ADD(0x4E, 0xf);      // quad_perm [2,3,0,1]
+    TRACE_DPP_ADD(0x141, 0xf);     // row_half_mirror
+    TRACE_DPP_ADD(0x140, 0xf);     // row_mirror: every lane of a 16-lane row holds the row's sum
+    TRACE_DPP_ADD(0x142, 0xa);     // row_bcast15 into rows 1, 3
+    TRACE_DPP_ADD(0x143, 0xc);     // row_bcast31 into rows 2, 3: lane 63 holds the wave's sum
+#undef TRACE_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

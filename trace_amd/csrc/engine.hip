@@ -65,6 +65,7 @@ struct trace_ctx {
     // ViT workspaces
     bf16_t *vX, *vH, *vQKV, *vVT, *vMLP;
     bf16_t *sl_res, *sl_out, *video;     // [T*S, vh], [T*S, H], [T*TPF, H]
+    float* sl_ws = nullptr; size_t sl_ws_floats = 0;   // slot pool: per-part softmax partials
     int video_rows = 0;
     // LLM prefill workspaces
     bf16_t *pX, *pH, *pQKV, *pO, *pACT;
@@ -210,6 +211,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
         A(c->vMLP, mlp > im2 ? mlp : im2);
     }
     A(c->sl_res, Tm * c->S * vh); A(c->sl_out, Tm * c->S * H);
+    if (!c->stc) { c->sl_ws_floats = launch_slot_pool_ws_floats((int)Tm, (int)vh); A(c->sl_ws, c->sl_ws_floats); }
     {
         const int g2 = c->G / 2 + 1;
         const size_t vr = c->stc ? (size_t)(Tm / 2 + 1) * g2 * g2 : Tm * c->TPF;
@@ -563,7 +565,7 @@ extern "C" int trace_slot_pool(trace_ctx* c, const void* feats, int T, void* slo
     const bf16_t* f = feats ? (const bf16_t*)feats : c->vX + vh;
     const long fs = feats ? (long)c->GG * vh : (long)c->NT * vh;
     LCHK(launch_slot_pool(f, fs, vh, c->sl_lnw, c->sl_lnb, c->sl_slots, c->slot_cos, c->slot_sin, c->sl_res, T, c->GG, vh,
-                          c->S, c->c.slot_eps, s));
+                          c->S, c->c.slot_eps, c->sl_ws, c->sl_ws_floats, s));
     TRY(gemm(c->sl_res, vh, c->sl_readout, vh, c->sl_out, c->H, nullptr, nullptr, 0, T * c->S, c->H, vh, EPI_NONE, s));
     if (slots_out) HIPCHK(hipMemcpyAsync(slots_out, c->sl_out, (size_t)T * c->S * c->H * 2, hipMemcpyDeviceToDevice, s));
     return TRACE_OK;

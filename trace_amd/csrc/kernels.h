@@ -68,9 +68,11 @@ bool attn_vit_wants_perm(int nkv_rows, bool has_vrow);
 
 // ---- SpatialSlotPool (slot_pool.hip) ----
 // feats rows: frame t patch p at feats + (t*frame_stride + p*row_stride); out RES [T*S, D] bf16 (pre-readout)
+// ws: launch_slot_pool_ws_floats(T, D) floats of scratch (per-part softmax partials)
 int launch_slot_pool(const bf16_t* feats, long frame_stride, int row_stride, const bf16_t* ln_w, const bf16_t* ln_b,
                      const bf16_t* slots /*[D,S]*/, const float* cos_t, const float* sin_t /*[n,D/2]*/,
-                     bf16_t* res, int T, int n, int D, int S, float eps, hipStream_t s);
+                     bf16_t* res, int T, int n, int D, int S, float eps, float* ws, size_t ws_floats, hipStream_t s);
+size_t launch_slot_pool_ws_floats(int T, int D);
 
 // ---- LLM glue (llm.hip) ----
 struct GatherTabs { const bf16_t* t[6]; };

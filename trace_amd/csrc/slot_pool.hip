@@ -3,11 +3,13 @@
 //   x = x*cos + rotate_half(x)*sin         (channel-axis RoPE, position = patch index, :289-359,:453-455)
 //   logits[n,s] = x[n,:] . slots[:,s]      (:457)      P = softmax over the n patches (:458)
 //   res[s,:] = sum_n P[n,s] * x[n,:]       (:462)
-// HBM-bound (one read of the 576x1024 frame features); one workgroup per frame, one wave per patch row.
-// Pass 1 computes LN statistics + logits (slot matrix in LDS in lane-major order: conflict-free b128 reads),
-// the 576-way softmax runs on the LDS logits, pass 2 re-reads the (L2-resident) row, re-applies LN+RoPE from
-// the saved statistics and accumulates the 8 x 1024 weighted sums in registers; the waves add them into LDS one
-// after the other (fixed order: bit-reproducible).  All arithmetic fp32; output bf16 [T*S, D], consumed by the readout GEMM.
+// Round 2: the first version (one 4-wave workgroup per frame, all arithmetic on fp32 VALU: ~1200 instructions per patch row) used
+// half the CUs and was VALU-bound — 454 us per 128 frames = 0.35 TB/s, 4 % of the HBM roofline its 151 MB of input would allow.
+// Now each frame is split over NPART workgroups (1024 for 128 frames), each with a LOCAL softmax (max, sum, weighted sums against its own
+// max) merged by a second small kernel (exact: exp(m_part - M) rescaling), and the per-row work is ~420 instructions: row sums by
+// v_dot2c_f32_bf16 on the packed input, logits by v_dot2c on the bf16-rounded rotated row against slot pairs held in registers (the
+// reference module runs in half precision here too), wave reductions on DPP instead of ds_bpermute shuffles, and
+// packed fp32 FMAs for the weighted sums.  Every reduction keeps a fixed order (bit-reproducible).  Output bf16 [T*S, D] for the readout GEMM.
 #include "common.h"
 #include "kernels.h"
 
@@ -19,182 +21,234 @@ __device__ __forceinline__ void unpack8(const uint4& u, float* v) {
     v[4] = bflo(u.z); v[5] = bfhi(u.z); v[6] = bflo(u.w); v[7] = bfhi(u.w);
 }
 
-__global__ __launch_bounds__(256) void slot_pool_kernel(const bf16_t* __restrict__ feats, long frame_stride, int row_stride,
-                                                        const bf16_t* __restrict__ ln_w, const bf16_t* __restrict__ ln_b,
-                                                        const bf16_t* __restrict__ slots, const float* __restrict__ cos_t,
-                                                        const float* __restrict__ sin_t, bf16_t* __restrict__ res, int n,
-                                                        int D, float eps) {
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+typedef __attribute__((ext_vector_type(2))) float f2_t;
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a), __builtin_bit_cast(bf2_t, b), c, false);
+}
+constexpr int NPART = 8;      // workgroups per frame
+
+// part g of frame t: patch rows [g*RP, (g+1)*RP).  Partial outputs: pm / pl [T][NPART][8] (local max, local sum of exp),
+// pres [T][NPART][8][D] fp32 (sum_p exp(l - m_local) * x_hat[p, :]).
+__global__ __launch_bounds__(256) void slot_pool_part_kernel(const bf16_t* __restrict__ feats, long frame_stride, int row_stride,
+                                                             const bf16_t* __restrict__ ln_w, const bf16_t* __restrict__ ln_b,
+                                                             const bf16_t* __restrict__ slots, const float* __restrict__ cos_t,
+                                                             const float* __restrict__ sin_t, float* __restrict__ pm, float* __restrict__ pl,
+                                                             float* __restrict__ pres, int n, int D, int RP, float eps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int NL = D >> 4;                       // active lanes per wave: lane owns d in [8l,8l+8) and D/2 + [8l,8l+8)
-    const int H2 = D >> 1;
-    // LDS carve-up
-    uint4* s_slots = reinterpret_cast<uint4*>(smem);                       // [16][NL] x (8 slots bf16) = D*16 B
-    float* s_logit = reinterpret_cast<float*>(smem + (size_t)D * 16);      // [n][8]
-    float* s_stat = s_logit + (size_t)n * NS;                              // [n][2] mean, rstd
-    float* s_res = s_stat + (size_t)n * 2;                                 // [8][D]
-    float* s_red = s_res + (size_t)NS * D;                                 // [8][2] max, 1/sum
-
+    const int H2 = D >> 1, NL = D >> 4;          // lane l < NL owns d in [8l, 8l+8) and H2 + [8l, 8l+8): the RoPE pairs (d, d + H2)
+    float* s_logit = reinterpret_cast<float*>(smem);                  // [RP][8]
+    float* s_stat = s_logit + (size_t)RP * NS;                        // [RP][2] mean, rstd
+    float* s_red = s_stat + (size_t)RP * 2;                           // [8] local max
+    float* s_res = s_red + 16;                                        // [8][D]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int t = blockIdx.x;
+    const int g = blockIdx.x, t = blockIdx.y;
+    const int p_beg = g * RP, p_end = min(n, p_beg + RP), np = max(0, p_end - p_beg);
     const bf16_t* fr = feats + (size_t)t * frame_stride;
+    const bool on = lane < NL;
+    const int lo = on ? lane : 0;
 
-    for (int i = tid; i < D; i += 256) {
-        // element d -> (e, owner lane): first half e = d&7, second half e = 8 + (d&7)
-        const int half = i >= H2, dd = half ? i - H2 : i;
-        const int ow = dd >> 3, e = (dd & 7) + 8 * half;
-        s_slots[e * NL + ow] = *reinterpret_cast<const uint4*>(slots + (size_t)i * NS);
+    float w1[8], w2[8], b1[8], b2[8];
+    {
+        uint4 u;
+        u = *reinterpret_cast<const uint4*>(ln_w + lo * 8); unpack8(u, w1);
+        u = *reinterpret_cast<const uint4*>(ln_w + H2 + lo * 8); unpack8(u, w2);
+        u = *reinterpret_cast<const uint4*>(ln_b + lo * 8); unpack8(u, b1);
+        u = *reinterpret_cast<const uint4*>(ln_b + H2 + lo * 8); unpack8(u, b2);
+    }
+    // one patch row's inputs: the lane's 16 features and its 8 cos / 8 sin values.  The loops below keep the NEXT row's loads in flight
+    // while the current row is computed (with 2 workgroups per CU nothing else hides the ~1.5 us the loads take)
+    struct RowIn { uint4 u1, u2; float4 c0, c1, s0, s1; };
+    auto load_row = [&](int p) {
+        RowIn q;
+        const bf16_t* xr = fr + (size_t)p * row_stride;
+        q.u1 = *reinterpret_cast<const uint4*>(xr + lo * 8);
+        q.u2 = *reinterpret_cast<const uint4*>(xr + H2 + lo * 8);
+        const float4* cp = reinterpret_cast<const float4*>(cos_t + (size_t)p * H2 + lo * 8);
+        const float4* sp_ = reinterpret_cast<const float4*>(sin_t + (size_t)p * H2 + lo * 8);
+        q.c0 = cp[0]; q.c1 = cp[1]; q.s0 = sp_[0]; q.s1 = sp_[1];
+        return q;
+    };
+    auto rotated = [&](const RowIn& q, float mean, float rstd, float (&r1)[8], float (&r2)[8]) {
+        float x1[8], x2[8];
+        unpack8(q.u1, x1); unpack8(q.u2, x2);
+        const float cs[8] = {q.c0.x, q.c0.y, q.c0.z, q.c0.w, q.c1.x, q.c1.y, q.c1.z, q.c1.w};
+        const float sn[8] = {q.s0.x, q.s0.y, q.s0.z, q.s0.w, q.s1.x, q.s1.y, q.s1.z, q.s1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = (x1[e] - mean) * rstd * w1[e] + b1[e];
+            const float b = (x2[e] - mean) * rstd * w2[e] + b2[e];
+            r1[e] = a * cs[e] - b * sn[e];
+            r2[e] = b * cs[e] + a * sn[e];
+        }
+    };
+
+    // ---------------- pass 1: LN statistics + logits ----------------
+    {
+        // slot pairs for v_dot2c: sp[j][k] = (slots[d_j, k], slots[d_j + 1, k]) for the lane's 8 element pairs (4 per half)
+        uint32_t sp[8][NS];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = (j < 4 ? 0 : H2) + lo * 8 + (j & 3) * 2;
+            const uint4 ra = *reinterpret_cast<const uint4*>(slots + (size_t)d * NS), rb = *reinterpret_cast<const uint4*>(slots + (size_t)(d + 1) * NS);
+            const uint32_t A[4] = {ra.x, ra.y, ra.z, ra.w}, Bv[4] = {rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sp[j][2 * q] = (A[q] & 0xffffu) | (Bv[q] << 16);
+                sp[j][2 * q + 1] = (A[q] >> 16) | (Bv[q] & 0xffff0000u);
+            }
+        }
+        RowIn nxt = load_row(p_beg + min(wid, max(np - 1, 0)));
+        for (int i = wid; i < np; i += 4) {
+            const RowIn cur = nxt;
+            if (i + 4 < np) nxt = load_row(p_beg + i + 4);
+            const uint4 u1 = on ? cur.u1 : make_uint4(0, 0, 0, 0), u2 = on ? cur.u2 : make_uint4(0, 0, 0, 0);
+            const uint32_t xp[8] = {u1.x, u1.y, u1.z, u1.w, u2.x, u2.y, u2.z, u2.w};
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sm = dot2(xp[j], 0x3f803f80u, sm); sq = dot2(xp[j], xp[j], sq); }
+            sm = wave_sum_dpp(sm); sq = wave_sum_dpp(sq);
+            const float mean = sm / (float)D;
+            const float rstd = rsqrtf(fmaxf(sq / (float)D - mean * mean, 0.f) + eps);
+            float r1[8], r2[8];
+            rotated(cur, mean, rstd, r1, r2);
+            uint32_t rp[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { rp[j] = pack2bf(r1[2 * j], r1[2 * j + 1]); rp[4 + j] = pack2bf(r2[2 * j], r2[2 * j + 1]); }
+            float lg[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a = dot2(rp[j], sp[j][k], a);
+                lg[k] = on ? a : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) lg[k] = wave_sum_dpp(lg[k]);       // eight independent DPP chains
+            if (lane == 0) {
+                *reinterpret_cast<float4*>(s_logit + i * NS) = make_float4(lg[0], lg[1], lg[2], lg[3]);
+                *reinterpret_cast<float4*>(s_logit + i * NS + 4) = make_float4(lg[4], lg[5], lg[6], lg[7]);
+            }
+            if (lane == 0) { s_stat[i * 2] = mean; s_stat[i * 2 + 1] = rstd; }
+        }
     }
     for (int i = tid; i < NS * D; i += 256) s_res[i] = 0.f;
     __syncthreads();
 
-    const bool on = lane < NL;
-    float w1[8], w2[8], b1[8], b2[8];
-    if (on) {
-        uint4 u;
-        u = *reinterpret_cast<const uint4*>(ln_w + lane * 8); unpack8(u, w1);
-        u = *reinterpret_cast<const uint4*>(ln_w + H2 + lane * 8); unpack8(u, w2);
-        u = *reinterpret_cast<const uint4*>(ln_b + lane * 8); unpack8(u, b1);
-        u = *reinterpret_cast<const uint4*>(ln_b + H2 + lane * 8); unpack8(u, b2);
-    }
-
-    // ---------------- pass 1: LN stats + RoPE + logits ----------------
-    for (int p = wid; p < n; p += 4) {
-        float x1[8], x2[8];
-        float s = 0.f;
-        if (on) {
-            const bf16_t* xr = fr + (size_t)p * row_stride;
-            uint4 u = *reinterpret_cast<const uint4*>(xr + lane * 8); unpack8(u, x1);
-            u = *reinterpret_cast<const uint4*>(xr + H2 + lane * 8); unpack8(u, x2);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += x1[e] + x2[e];
-        }
-        s = wave_sum(s);
-        const float mean = s / (float)D;
-        float q = 0.f;
-        if (on) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float a = x1[e] - mean, b = x2[e] - mean; q += a * a + b * b; }
-        }
-        q = wave_sum(q);
-        const float rstd = rsqrtf(q / (float)D + eps);
-        float lg[NS];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) lg[k] = 0.f;
-        if (on) {
-            const float4* cp = reinterpret_cast<const float4*>(cos_t + (size_t)p * H2 + lane * 8);
-            const float4* sp = reinterpret_cast<const float4*>(sin_t + (size_t)p * H2 + lane * 8);
-            const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
-            const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-            const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float a = (x1[e] - mean) * rstd * w1[e] + b1[e];
-                const float b = (x2[e] - mean) * rstd * w2[e] + b2[e];
-                const float r1 = a * cs[e] - b * sn[e];
-                const float r2 = b * cs[e] + a * sn[e];
-                float sv[8];
-                unpack8(s_slots[e * NL + lane], sv);
-#pragma unroll
-                for (int k = 0; k < NS; ++k) lg[k] += r1 * sv[k];
-                unpack8(s_slots[(e + 8) * NL + lane], sv);
-#pragma unroll
-                for (int k = 0; k < NS; ++k) lg[k] += r2 * sv[k];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NS; ++k) lg[k] = wave_sum(lg[k]);
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < NS; ++k) s_logit[p * NS + k] = lg[k];
-            s_stat[p * 2] = mean;
-            s_stat[p * 2 + 1] = rstd;
-        }
-    }
-    __syncthreads();
-
-    // ---------------- softmax over patches, per slot (2 slots per wave) ----------------
+    // ---------------- local softmax numerators: p = exp(l - m_local) (2 slots per wave) ----------------
     for (int k = wid * 2; k < wid * 2 + 2; ++k) {
         float mx = -1e30f;
-        for (int p = lane; p < n; p += 64) mx = fmaxf(mx, s_logit[p * NS + k]);
+        for (int i = lane; i < np; i += 64) mx = fmaxf(mx, s_logit[i * NS + k]);
         mx = wave_max(mx);
-        float sm = 0.f;
-        for (int p = lane; p < n; p += 64) sm += __expf(s_logit[p * NS + k] - mx);
-        sm = wave_sum(sm);
-        if (lane == 0) { s_red[k * 2] = mx; s_red[k * 2 + 1] = 1.f / sm; }
-    }
-    __syncthreads();
-    for (int i = tid; i < n * NS; i += 256) {
-        const int k = i & (NS - 1);
-        s_logit[i] = __expf(s_logit[i] - s_red[k * 2]) * s_red[k * 2 + 1];
+        float sme = 0.f;
+        for (int i = lane; i < np; i += 64) {
+            const float e = __expf(s_logit[i * NS + k] - mx);
+            s_logit[i * NS + k] = e;
+            sme += e;
+        }
+        sme = wave_sum(sme);
+        if (lane == 0) {
+            pm[((size_t)t * NPART + g) * NS + k] = mx;
+            pl[((size_t)t * NPART + g) * NS + k] = sme;
+        }
     }
     __syncthreads();
 
-    // ---------------- pass 2: res[s, d] = sum_p P[p, s] * x[p, d] ----------------
-    float a1[NS][8], a2[NS][8];
+    // ---------------- pass 2: sum_p p[p, s] * x_hat[p, :] ----------------
+    f2_t a1[NS][4], a2[NS][4];
 #pragma unroll
     for (int k = 0; k < NS; ++k)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { a1[k][e] = 0.f; a2[k][e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { a1[k][e] = f2_t{0.f, 0.f}; a2[k][e] = f2_t{0.f, 0.f}; }
     if (on) {
-        for (int p = wid; p < n; p += 4) {
-            float x1[8], x2[8];
-            const bf16_t* xr = fr + (size_t)p * row_stride;
-            uint4 u = *reinterpret_cast<const uint4*>(xr + lane * 8); unpack8(u, x1);
-            u = *reinterpret_cast<const uint4*>(xr + H2 + lane * 8); unpack8(u, x2);
-            const float mean = s_stat[p * 2], rstd = s_stat[p * 2 + 1];
-            const float4* cp = reinterpret_cast<const float4*>(cos_t + (size_t)p * H2 + lane * 8);
-            const float4* sp = reinterpret_cast<const float4*>(sin_t + (size_t)p * H2 + lane * 8);
-            const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
-            const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-            const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-            const float4 pa = *reinterpret_cast<const float4*>(s_logit + p * NS);
-            const float4 pb = *reinterpret_cast<const float4*>(s_logit + p * NS + 4);
+        RowIn nxt = load_row(p_beg + min(wid, max(np - 1, 0)));
+        for (int i = wid; i < np; i += 4) {
+            const RowIn cur = nxt;
+            if (i + 4 < np) nxt = load_row(p_beg + i + 4);
+            float r1[8], r2[8];
+            rotated(cur, s_stat[i * 2], s_stat[i * 2 + 1], r1, r2);
+            const float4 pa = *reinterpret_cast<const float4*>(s_logit + i * NS), pb = *reinterpret_cast<const float4*>(s_logit + i * NS + 4);
             const float pr[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float a = (x1[e] - mean) * rstd * w1[e] + b1[e];
-                const float b = (x2[e] - mean) * rstd * w2[e] + b2[e];
-                const float r1 = a * cs[e] - b * sn[e];
-                const float r2 = b * cs[e] + a * sn[e];
+            for (int k = 0; k < NS; ++k) {
+                const f2_t pk = {pr[k], pr[k]};
 #pragma unroll
-                for (int k = 0; k < NS; ++k) { a1[k][e] += pr[k] * r1; a2[k][e] += pr[k] * r2; }
+                for (int e = 0; e < 4; ++e) {
+                    a1[k][e] = __builtin_elementwise_fma(pk, f2_t{r1[2 * e], r1[2 * e + 1]}, a1[k][e]);
+                    a2[k][e] = __builtin_elementwise_fma(pk, f2_t{r2[2 * e], r2[2 * e + 1]}, a2[k][e]);
+                }
             }
         }
     }
-    // the four waves add their partial sums one after the other (LDS float atomics would add them in arrival order: the
-    // result then differs in the last bit from run to run, which 32 decoder layers amplify to 0.2 in the prefill hidden state)
+    // the four waves add their partial sums one after the other (fixed order: bit-reproducible)
     for (int w = 0; w < 4; ++w) {
         if (on && wid == w) {
 #pragma unroll
             for (int k = 0; k < NS; ++k)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    s_res[k * D + lane * 8 + e] += a1[k][e];
-                    s_res[k * D + H2 + lane * 8 + e] += a2[k][e];
+                for (int e = 0; e < 4; ++e) {
+                    f2_t* q1 = reinterpret_cast<f2_t*>(s_res + k * D + lane * 8 + 2 * e);
+                    f2_t* q2 = reinterpret_cast<f2_t*>(s_res + k * D + H2 + lane * 8 + 2 * e);
+                    *q1 += a1[k][e];
+                    *q2 += a2[k][e];
                 }
         }
         __syncthreads();
     }
+    float* out = pres + ((size_t)t * NPART + g) * NS * D;
+    for (int i = tid; i < NS * D / 4; i += 256) reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(s_res)[i];
+}
+
+// res[t, s, :] = sum_g exp(m_g - M) pres_g / sum_g exp(m_g - M) l_g,  M = max_g m_g  (parts in index order)
+__global__ __launch_bounds__(256) void slot_pool_merge_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                              const float* __restrict__ pres, bf16_t* __restrict__ res, int D) {
+    const int t = blockIdx.x, tid = threadIdx.x;
+    __shared__ float s_w[NPART][NS];
+    if (tid < NS) {
+        float M = -1e30f;
+        for (int g = 0; g < NPART; ++g) M = fmaxf(M, pm[((size_t)t * NPART + g) * NS + tid]);
+        float den = 0.f, w[NPART];
+        for (int g = 0; g < NPART; ++g) {
+            w[g] = __expf(pm[((size_t)t * NPART + g) * NS + tid] - M);
+            den += w[g] * pl[((size_t)t * NPART + g) * NS + tid];
+        }
+        for (int g = 0; g < NPART; ++g) s_w[g][tid] = w[g] / den;
+    }
+    __syncthreads();
     bf16_t* out = res + (size_t)t * NS * D;
     for (int i = tid; i < NS * D / 2; i += 256) {
-        const float2 v = *reinterpret_cast<const float2*>(s_res + 2 * i);
-        reinterpret_cast<uint32_t*>(out)[i] = pack2bf(v.x, v.y);
+        const int k = (2 * i) / D;
+        float x0 = 0.f, x1 = 0.f;
+        for (int g = 0; g < NPART; ++g) {
+            const float2 v = *reinterpret_cast<const float2*>(pres + ((size_t)t * NPART + g) * NS * D + 2 * i);
+            x0 += s_w[g][k] * v.x; x1 += s_w[g][k] * v.y;
+        }
+        reinterpret_cast<uint32_t*>(out)[i] = pack2bf(x0, x1);
     }
 }
 }  // namespace
 
+// scratch: [T*NPART*8] pm, [T*NPART*8] pl, [T*NPART*8*D] pres (floats): launch_slot_pool_ws_floats(T, D)
+size_t launch_slot_pool_ws_floats(int T, int D) { return (size_t)T * NPART * NS * (2 + (size_t)D); }
+
 int launch_slot_pool(const bf16_t* feats, long frame_stride, int row_stride, const bf16_t* ln_w, const bf16_t* ln_b,
                      const bf16_t* slots, const float* cos_t, const float* sin_t, bf16_t* res, int T, int n, int D, int S,
-                     float eps, hipStream_t s) {
+                     float eps, float* ws, size_t ws_floats, hipStream_t s) {
     if (S != NS || D % 16 || D > 1024 || T <= 0 || n <= 0 || (row_stride % 8)) return TRACE_ERR_ARG;
-    const size_t lds = (size_t)D * 16 + (size_t)n * NS * 4 + (size_t)n * 8 + (size_t)NS * D * 4 + 64;
+    if (!ws || ws_floats < launch_slot_pool_ws_floats(T, D)) return TRACE_ERR_ARG;
+    const int RP = (n + NPART - 1) / NPART;
+    const size_t lds = (size_t)RP * NS * 4 + (size_t)RP * 8 + 64 + (size_t)NS * D * 4;
     if (lds > 160 * 1024) return TRACE_ERR_ARG;
     static size_t set_for = 0;
     if (lds > set_for) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(slot_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(slot_pool_part_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         set_for = lds;
     }
-    hipLaunchKernelGGL(slot_pool_kernel, dim3(T), dim3(256), lds, s, feats, frame_stride, row_stride, ln_w, ln_b, slots,
-                       cos_t, sin_t, res, n, D, eps);
+    float* pm = ws;
+    float* pl = pm + (size_t)T * NPART * NS;
+    float* pres = pl + (size_t)T * NPART * NS;
+    hipLaunchKernelGGL(slot_pool_part_kernel, dim3(NPART, T), dim3(256), lds, s, feats, frame_stride, row_stride, ln_w, ln_b, slots, cos_t,
+                       sin_t, pm, pl, pres, n, D, RP, eps);
+    hipLaunchKernelGGL(slot_pool_merge_kernel, dim3(T), dim3(256), 0, s, pm, pl, pres, res, D);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }

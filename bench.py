@@ -34,12 +34,12 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s 
 
 def cpu_baseline(cfg, n_new: int, threads: int) -> dict:
     """Oracle (CPU restatement of the reference path, validated against the reference fixtures) timed on a bounded
-    sample of the same workload and extrapolated linearly: ViT on 4 of the 128 frames (all 23 layers), slot pool on
-    those frames, 2 of the 32 decoder layers at the full prefill length, and 8 single-token decode steps on those layers."""
+    sample of the same workload and extrapolated linearly: ViT on 8 of the 128 frames (all 23 layers; SURVEY 8d's sample), slot pool on
+    those frames, 4 of the 32 decoder layers at the full prefill length, and 8 single-token decode steps on those layers."""
     import dataclasses
     from oracle import trace_oracle as O
     torch.set_num_threads(threads)
-    SF, SL, SD = 4, 2, 8                      # sample: frames, decoder layers, decode steps
+    SF, SL, SD = 8, 4, 8                      # sample: frames, decoder layers, decode steps (~12 s of work on 32 threads)
     c1 = dataclasses.replace(cfg, num_hidden_layers=SL, vocab_size=64, num_frames=SF)
     sd = {}
     for name, shape, kind in synth.weight_specs(c1):

@@ -19,8 +19,8 @@ def counter_mean(d, counter, kernel_sub):
 
 fetch_kb, n1 = counter_mean(sys.argv[1], "FETCH_SIZE", "skinny_lds_kernel")
 write_kb, n2 = counter_mean(sys.argv[2], "WRITE_SIZE", "skinny_lds_kernel")
-gf_kb, g1 = counter_mean(sys.argv[1], "FETCH_SIZE", "gemm_ldr_kernel<2>")
-gw_kb, g2 = counter_mean(sys.argv[2], "WRITE_SIZE", "gemm_ldr_kernel<2>")
+gf_kb, g1 = counter_mean(sys.argv[1], "FETCH_SIZE", "gemm_ldr_kernel<2")
+gw_kb, g2 = counter_mean(sys.argv[2], "WRITE_SIZE", "gemm_ldr_kernel<2")
 FC1_M = 170 * 577       # tools/pmc_kernels.py: one 170-frame ViT call (the bench's probe shape)
 g_alg = FC1_M * 1024 * 2 + 4096 * 1024 * 2 + FC1_M * 4096 * 2
 g_total = gf_kb * 1024 * 2 + gw_kb * 1024

@@ -305,8 +305,10 @@ __global__ __launch_bounds__(256) void tile_pack_kernel(const bf16_t* __restrict
 // trip per chunk: 13 us at 16 chunks) and summed in chunk order.
 __global__ __launch_bounds__(1024) void add_rmsnorm_kernel(const float* __restrict__ part, int KS, const bf16_t* __restrict__ R, int ldr,
                                                            bf16_t* __restrict__ xout, int ldx, const bf16_t* __restrict__ w,
-                                                           bf16_t* __restrict__ y, int ldy, int N, float eps) {
+                                                           bf16_t* __restrict__ y, int ldy, int N, float eps,
+                                                           uint8_t* __restrict__ y8, float* __restrict__ sy) {
     __shared__ float s_red[16];
+    __shared__ float s_amax[16];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int c = tid;                                 // N <= 4096: one 4-element chunk per thread
     const bool on = c < (N >> 2);
@@ -344,7 +346,30 @@ __global__ __launch_bounds__(1024) void add_rmsnorm_kernel(const float* __restri
     if (on) {
         const float o0 = v[0] * rstd * bflo(wv.x), o1 = v[1] * rstd * bfhi(wv.x);
         const float o2 = v[2] * rstd * bflo(wv.y), o3 = v[3] * rstd * bfhi(wv.y);
-        *reinterpret_cast<uint2*>(y + (size_t)b * ldy + c * 4) = make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));
+        const uint2 yo = make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));
+        *reinterpret_cast<uint2*>(y + (size_t)b * ldy + c * 4) = yo;
+        v[0] = bflo(yo.x); v[1] = bfhi(yo.x); v[2] = bflo(yo.y); v[3] = bfhi(yo.y);
+    }
+    if (y8) {
+        // fp8 weight path: the next GEMV's activations, quantised here exactly as fp8.hip's quant_rows_fp8 would from y (per-row amax of
+        // the bf16-rounded values, q = rne(y * 448 / amax)) — saves that launch
+        float am = on ? fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) : 0.f;
+        am = wave_max(am);
+        if ((tid & 63) == 0) s_amax[tid >> 6] = am;
+        __syncthreads();
+        am = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) am = fmaxf(am, s_amax[i]);
+        const float inv = am > 0.f ? 448.f / am : 1.f;
+        if (tid == 0) sy[b] = am > 0.f ? am / 448.f : 1.f;
+        if (on) {
+            float f[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[e] = fminf(fmaxf(v[e] * inv, -448.f), 448.f);
+            int w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
+            *reinterpret_cast<int*>(y8 + (size_t)b * N + c * 4) = w;
+        }
     }
 }
 
@@ -927,9 +952,9 @@ int launch_tile_pack(const bf16_t* src, int ldw, bf16_t* dst, int N, int K, hipS
 }
 
 int launch_add_rmsnorm(const float* part, int KS, const bf16_t* R, int ldr, bf16_t* xout, int ldx, const bf16_t* w, bf16_t* y,
-                       int ldy, int B, int N, float eps, hipStream_t s) {
+                       int ldy, int B, int N, float eps, hipStream_t s, uint8_t* y8, float* sy) {
     if (B < 1 || B > SK_ROWS || KS < 1 || N % 4 || N > 4096 || (ldr % 4) || (ldx % 4) || (ldy % 4)) return TRACE_ERR_ARG;
-    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(B), dim3(1024), 0, s, part, KS, R, ldr, xout, ldx, w, y, ldy, N, eps);
+    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(B), dim3(1024), 0, s, part, KS, R, ldr, xout, ldx, w, y, ldy, N, eps, y8, sy);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 

@@ -83,8 +83,8 @@ struct trace_ctx {
     int B = 0, max_new = 0, eos = -1, has_forced = 0, ntiles = 0, nsplit = 32;
     int slot_len[64] = {0};
     int fp8 = 0;                       // decoder projections on the fp8 path
-    uint8_t *pA8 = nullptr, *dA8 = nullptr;      // quantised activations: prefill [2 max_ctx][max(H, I)], decode [64][I]
-    float *psa = nullptr, *dsa = nullptr;        // their per-row scales
+    uint8_t *pA8 = nullptr, *dA8 = nullptr, *dH8 = nullptr;      // quantised activations: prefill [2 max_ctx][max(H, I)], decode [64][I]; dH8 = the normed hidden rows
+    float *psa = nullptr, *dsa = nullptr, *dsh = nullptr;        // their per-row scales
     int host_mode = 0, fed = 0;        // host-driven token selection (sampling): head logits only, ids fed back by the host
     int steps_done = 0;                // decode steps taken since trace_decode_begin (bounded by max_new - 1: the KV slot and the RoPE tables end at max_ctx)
     hipGraphExec_t graphs[SK_ROWS + 1] = {nullptr};   // one captured decode step per batch size
@@ -223,7 +223,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     A(c->pX, 2 * Lm * H); A(c->pH, 2 * Lm * H); A(c->pQKV, 2 * Lm * c->QKV);
     A(c->pO, 2 * Lm * H); A(c->pACT, 2 * Lm * I);
     A(c->d_kind, Lm); A(c->d_row, Lm);
-    if (c->fp8) { A(c->pA8, 2 * Lm * std::max(H, I)); A(c->psa, 2 * Lm); A(c->dA8, (size_t)SK_ROWS * std::max(H, I)); A(c->dsa, SK_ROWS); }
+    if (c->fp8) { A(c->pA8, 2 * Lm * std::max(H, I)); A(c->psa, 2 * Lm); A(c->dA8, (size_t)SK_ROWS * std::max(H, I)); A(c->dsa, SK_ROWS); A(c->dH8, (size_t)SK_ROWS * H); A(c->dsh, SK_ROWS); }
     // --- decode ---
     A(c->dX, SK_ROWS * H); A(c->dH, SK_ROWS * H); A(c->dQKV, SK_ROWS * (size_t)c->QKV); A(c->dO, SK_ROWS * H); A(c->dACT, SK_ROWS * I);
     A(c->xlast, 64 * H);
@@ -937,21 +937,24 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
 #define GEMV8(X_, W8D_, SW_, N_, K_)                                                                           \
     LCHK(launch_quant_rows_fp8((X_), (K_), c->dA8, (K_), c->dsa, B, (K_), s));                                  \
     LCHK(launch_skinny_fp8(c->dA8, (K_), c->dsa, (W8D_), (SW_), B, (N_), (K_), c->sk_ws, c->sk_ws_floats, s));
+    // the normed hidden rows arrive already quantised (dH8 / dsh) from add_rmsnorm; only the step's first norm needs the quantiser
+#define GEMV8H(W8D_, SW_, N_) LCHK(launch_skinny_fp8(c->dH8, H, c->dsh, (W8D_), (SW_), B, (N_), H, c->sk_ws, c->sk_ws_floats, s));
     LCHK(launch_rmsnorm(c->dX, H, c->dH, H, c->llm[0].rms1, B, H, c->c.rms_eps, s));
+    if (f8) LCHK(launch_quant_rows_fp8(c->dH, H, c->dH8, H, c->dsh, B, H, s));
     for (int l = 0; l < c->NL; ++l) {
         const LlmLayer& W = c->llm[l];
         bf16_t* kc = c->kcache + (size_t)l * c->layer_stride;
         bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
         // (fusing the RMSNorm into the GEMV itself was tried: re-scaling the same activations in every workgroup cost
         //  more than a row kernel — 65 us vs 52 + 6 us for the gate|up GEMV)
-        if (f8) { GEMV8(c->dH, W.wqkv8_d, W.sqkv, QKV, H) }
+        if (f8) { GEMV8H(W.wqkv8_d, W.sqkv, QKV) }
         else LCHK(launch_skinny_gemm(c->dH, H, W.wqkv_d, H, nullptr, QKV, nullptr, 0, B, QKV, H, EPI_PARTIAL, 1, SKWS(c), s));
         LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots, c->d_pos, c->dO,
                                 H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, decode_nsplit(B), 1.0f / sqrtf((float)HD), 1,
                                 c->rope_cos, c->rope_sin, c->sk_ws, ks_q, s));
         if (f8) { GEMV8(c->dO, W.wo8_d, W.so, H, H) }
         else LCHK(launch_skinny_gemm(c->dO, H, W.wo_d, H, nullptr, H, nullptr, 0, B, H, H, EPI_PARTIAL, 1, SKWS(c), s));
-        LCHK(launch_add_rmsnorm(c->sk_ws, ks_o, c->dX, H, c->dX, H, W.rms2, c->dH, H, B, H, c->c.rms_eps, s));
+        LCHK(launch_add_rmsnorm(c->sk_ws, ks_o, c->dX, H, c->dX, H, W.rms2, c->dH, H, B, H, c->c.rms_eps, s, f8 ? c->dH8 : nullptr, f8 ? c->dsh : nullptr));
         // roofline probe: HIP events around ONE launch of the dominant kernel (layer 0 gate|up GEMV) per step
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (l == 0 && c->profile == 2) {
@@ -959,16 +962,17 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
             if (s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) { e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2; }
         }
         if (e0) hipEventRecord(e0, s);
-        if (f8) { GEMV8(c->dH, W.wgu8_d, W.sgu, 2 * I, H) }
+        if (f8) { GEMV8H(W.wgu8_d, W.sgu, 2 * I) }
         else LCHK(launch_skinny_gemm(c->dH, H, W.wgu_d, H, nullptr, 2 * I, nullptr, 0, B, 2 * I, H, EPI_PARTIAL, 1, SKWS(c), s));
         if (e1) hipEventRecord(e1, s);
         LCHK(launch_swiglu_combine(c->sk_ws, ks_g, 2 * I, c->dACT, I, B, s));
         if (f8) { GEMV8(c->dACT, W.wd8_d, W.sd, H, I) }
         else LCHK(launch_skinny_gemm(c->dACT, I, W.wd_d, I, nullptr, H, nullptr, 0, B, H, I, EPI_PARTIAL, 1, SKWS(c), s));
         const bf16_t* nw = l + 1 < c->NL ? c->llm[l + 1].rms1 : c->final_norm;
-        LCHK(launch_add_rmsnorm(c->sk_ws, ks_d, c->dX, H, c->dX, H, nw, c->dH, H, B, H, c->c.rms_eps, s));
+        LCHK(launch_add_rmsnorm(c->sk_ws, ks_d, c->dX, H, c->dX, H, nw, c->dH, H, B, H, c->c.rms_eps, s, f8 ? c->dH8 : nullptr, f8 ? c->dsh : nullptr));
     }
 #undef GEMV8
+#undef GEMV8H
     return head_and_select(c, c->dH, 1, logits_out, s);
 }
 

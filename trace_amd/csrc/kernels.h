@@ -99,8 +99,9 @@ int launch_tile_pack(const bf16_t* src, int ldw, bf16_t* dst, int N, int K, hipS
 // out[b][j] = bf16(silu(sum_ks gate) * sum_ks up) over EPI_PARTIAL rows [KS][SK_ROWS][N2] of the 16-row interleaved gate|up product
 int launch_swiglu_combine(const float* part, int KS, int N2, bf16_t* out, int ldo, int B, hipStream_t s);
 // x = bf16(sum_ks part[ks][b]) + R[b] -> xout (may alias R); y = RMSNorm(x) * w.  N <= 4096.
+// y8 / sy (optional): y also as e4m3 [B][N] + per-row scale, as launch_quant_rows_fp8(y) would give (fp8 weight path)
 int launch_add_rmsnorm(const float* part, int KS, const bf16_t* R, int ldr, bf16_t* xout, int ldx, const bf16_t* w, bf16_t* y,
-                       int ldy, int B, int N, float eps, hipStream_t s);
+                       int ldy, int B, int N, float eps, hipStream_t s, uint8_t* y8 = nullptr, float* sy = nullptr);
 // single-query GQA attention over the cache (context = pos[b] + 1 rows, split nsplit ways, <= 128 rows per split).
 // fuse_rope = 1: `qkv` rows are the raw [q | k | v] projections of the new token: q and the new k are rotated here
 // (RoPE at pos[b]) and k/v appended to the cache at row pos[b].  fuse_rope = 0: `qkv` holds ready q rows (ld ldq)

@@ -302,7 +302,7 @@ def main():
             "mfma_util": {"vit": vit_flops / (t_enc * 1e-3) / 2.5e15, "prefill": pre_flops / (t_pre * 1e-3) / 2.5e15},
             # dominant kernel of the run: the 256x256 MFMA GEMM (its four epilogue variants are ~half of GPU time; the probe
             # brackets its largest instance, the ViT fc1 projection, once per video inside the timed region)
-            "roofline": {"bound": "mfma", "kernel": f"gemm_ldr_kernel<EPI_QUICKGELU>, 256x256 tiles, 8 MFMA + 4 loader waves (ViT fc1 GEMM {g_M}x4096x1024 = one {eng.vit_batch_frames if B >= 2 else args.frames}-frame tower call, 1 bracketed launch per call)",
+            "roofline": {"bound": "mfma", "kernel": f"gemm_pers_kernel<EPI_QUICKGELU>, 256x256 tiles, persistent workgroups of 8 MFMA + 4 loader waves (ViT fc1 GEMM {g_M}x4096x1024 = one {eng.vit_batch_frames if B >= 2 else args.frames}-frame tower call, 1 bracketed launch per call)",
                          "achieved": g_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": (g_tf / 2500.0) if g_tf else None,
                          "traffic": g_traffic, "algorithmic_gflop_per_launch": g_gf, "algorithmic_bytes_per_launch": g_M * 1024 * 2 + 4096 * 1024 * 2 + g_M * 4096 * 2,
                          "avg_launch_ms": g_ms, "samples": g_n},

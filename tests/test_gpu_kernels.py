@@ -40,7 +40,7 @@ def check(name, got, ref, atol, rtol):
         pytest.fail(msg)
 
 
-@pytest.fixture(params=[0, 2, 3], ids=["auto", "tile128", "tile256"])
+@pytest.fixture(params=[0, 2, 3, 4, 5], ids=["auto", "tile128", "tile256", "ldr", "persistent"])
 def gemm_variant(request):
     ops.set_gemm_variant(request.param)
     yield request.param
@@ -90,6 +90,56 @@ def test_gemm_residual_in_place():
     Rc = R.clone()
     E._lib.check(lib.trace_op_gemm(E._ptr(A), K, E._ptr(W), K, E._ptr(Rc), N, None, E._ptr(Rc), N, M, N, K, E.EPI_RESIDUAL, E._stream()))
     check("residual in place", Rc, ref, 3e-2, 1e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (9000, 2048, 256), (70000, 1024, 128), (66000, 512, 192)])
+def test_gemm_persistent_equals_loader_wave_kernel(M, N, K):
+    """gemm_pers.hip (variant 5 ticketed, 6 static deal) against gemm_ldr.hip (variant 4), bit for bit, all four epilogues: ragged M, fewer
+    tiles than CUs, more than one tile per workgroup (the ticket path), the in-place residual, and back-to-back launches (the ticket counters
+    re-arm themselves at the end of every launch)."""
+    A, W, b, R = rnd(M, K), rnd(N, K, scale=0.05), rnd(N, scale=0.5), rnd(M, N)
+    lib = E._lib.load()
+    try:
+        for epi, kw in ((E.EPI_NONE, dict(bias=b)), (E.EPI_QUICKGELU, dict(bias=b)), (E.EPI_RESIDUAL, dict(bias=b, R=R)), (E.EPI_SWIGLU, {})):
+            ops.set_gemm_variant(4)
+            ref = ops.gemm(A, W, epilogue=epi, **kw)
+            for v in (5, 6):
+                ops.set_gemm_variant(v)
+                for rep in range(3):
+                    got = ops.gemm(A, W, epilogue=epi, **kw)
+                    assert torch.equal(got, ref), (epi, v, rep, (got.float() - ref.float()).abs().max().item())
+        ops.set_gemm_variant(4)
+        ref = ops.gemm(A, W, R=R, epilogue=E.EPI_RESIDUAL)
+        ops.set_gemm_variant(5)
+        Rc = R.clone()
+        E._lib.check(lib.trace_op_gemm(E._ptr(A), K, E._ptr(W), K, E._ptr(Rc), N, None, E._ptr(Rc), N, M, N, K, E.EPI_RESIDUAL, E._stream()))
+        assert torch.equal(Rc, ref)
+    finally:
+        ops.set_gemm_variant(0)
+
+
+def test_gemm_persistent_two_streams():
+    """Two persistent launches in flight on different streams: each stream has its own ticket counters."""
+    M, N, K = 40000, 1024, 256
+    A1, W1, A2, W2 = rnd(M, K), rnd(N, K, scale=0.05), rnd(M, K, seed=3), rnd(N, K, scale=0.05, seed=4)
+    try:
+        ops.set_gemm_variant(4)
+        r1, r2 = ops.gemm(A1, W1), ops.gemm(A2, W2)
+        ops.set_gemm_variant(5)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        outs = []
+        for _ in range(4):
+            with torch.cuda.stream(s1):
+                o1 = ops.gemm(A1, W1)
+            with torch.cuda.stream(s2):
+                o2 = ops.gemm(A2, W2)
+            outs.append((o1, o2))
+        torch.cuda.synchronize()
+        for o1, o2 in outs:
+            assert torch.equal(o1, r1) and torch.equal(o2, r2)
+    finally:
+        ops.set_gemm_variant(0)
 
 
 @pytest.mark.parametrize("rows,D", [(5, 128), (577, 1024), (33, 4096), (4618, 1024)])

@@ -38,8 +38,8 @@ def res(tmp_path_factory):
     if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
         pytest.skip("hipcc not available")
     tmp = str(tmp_path_factory.mktemp("kres"))
-    names = ["gemm_ldr", "gemm", "attn", "decode"]
-    with cf.ThreadPoolExecutor(max_workers=4) as ex:
+    names = ["gemm_ldr", "gemm_pers", "gemm", "attn", "decode"]
+    with cf.ThreadPoolExecutor(max_workers=5) as ex:
         return dict(zip(names, ex.map(lambda n: _resources(n, tmp), names)))
 
 
@@ -55,6 +55,14 @@ def test_loader_wave_gemm_fits_three_waves_per_simd(res):
         # a couple of address registers at most, no fragment or accumulator in scratch (the fp8 instantiations — ...ELb1E — carry one more
         # address dword: ISA read, one 4-byte reload per K-tile beside 128 MFMAs)
         assert v["ScratchSize"] <= (24 if "ELb1E" in k else 16), (k, v)
+
+
+def test_persistent_gemm_keeps_its_k_loop_in_registers(res):
+    """gemm_pers.hip: 3 waves per SIMD like gemm_ldr; a reload inside its tile loop is a dependent round trip per output tile (the first
+    build lost 12-15 us per tile that way).  The residual instantiation (not dispatched by default) may keep a few dwords in scratch across its two-pass epilogue, none in the K loop."""
+    for k, v in _pick(res["gemm_pers"], "gemm_pers_kernel").items():
+        assert v["VGPRs"] + v.get("AGPRs", 0) <= 168 and v["Occupancy"] >= 3, (k, v)
+        assert v["ScratchSize"] <= (24 if "ILi1E" in k else 0), (k, v)
 
 
 def test_plain_gemm_kernels_do_not_spill(res):

@@ -19,8 +19,8 @@ def counter_mean(d, counter, kernel_sub):
 
 fetch_kb, n1 = counter_mean(sys.argv[1], "FETCH_SIZE", "skinny_lds_kernel")
 write_kb, n2 = counter_mean(sys.argv[2], "WRITE_SIZE", "skinny_lds_kernel")
-gf_kb, g1 = counter_mean(sys.argv[1], "FETCH_SIZE", "gemm_ldr_kernel<2")
-gw_kb, g2 = counter_mean(sys.argv[2], "WRITE_SIZE", "gemm_ldr_kernel<2")
+gf_kb, g1 = counter_mean(sys.argv[1], "FETCH_SIZE", "gemm_pers_kernel<2")
+gw_kb, g2 = counter_mean(sys.argv[2], "WRITE_SIZE", "gemm_pers_kernel<2")
 FC1_M = 170 * 577       # tools/pmc_kernels.py: one 170-frame ViT call (the bench's probe shape)
 g_alg = FC1_M * 1024 * 2 + 4096 * 1024 * 2 + FC1_M * 4096 * 2
 g_total = gf_kb * 1024 * 2 + gw_kb * 1024
@@ -30,7 +30,7 @@ json.dump({
     "gemm_fc1_bytes_per_launch": g_total,
     "gemm_fc1_M": FC1_M,
     "gemm_fc1_detail": {
-        "kernel": "gemm_ldr_kernel<EPI_QUICKGELU> (ViT fc1, M=%d N=4096 K=1024), 3 launches" % FC1_M,
+        "kernel": "gemm_pers_kernel<EPI_QUICKGELU> (ViT fc1, M=%d N=4096 K=1024), 3 launches" % FC1_M,
         "FETCH_SIZE_KB_mean": gf_kb, "WRITE_SIZE_KB_mean": gw_kb, "launches": [g1, g2],
         "correction": "FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 (same gfx950 corrections as below; operand panels re-read by "
                       "other column tiles are served by L2 / infinity cache and only partly reach the memory-side counters)",

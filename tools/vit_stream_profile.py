@@ -1,5 +1,5 @@
 """The bench's ViT call shape for rocprofv3: three 170-frame tower calls (TraceEngine.full_round_frames) at the TRACE-7B
-geometry, nothing else — so the kernel-trace average of gemm_ldr_kernel<2> (fc1, EPI_QUICKGELU) in this profile is the average
+geometry, nothing else — so the kernel-trace average of gemm_pers_kernel<2, 0> (fc1, EPI_QUICKGELU) in this profile is the average
 of exactly the launch shape bench.py brackets with HIP events (`roofline.avg_launch_ms`)."""
 import dataclasses, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

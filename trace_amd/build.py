@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libtrace_hip.so")
-SOURCES = ["gemm", "gemm_ldr", "norm", "vit", "attn", "slot_pool", "llm", "decode", "fp8", "stc", "preproc", "engine"]
+SOURCES = ["gemm", "gemm_ldr", "gemm_pers", "norm", "vit", "attn", "slot_pool", "llm", "decode", "fp8", "stc", "preproc", "engine"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 

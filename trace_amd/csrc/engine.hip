@@ -1115,11 +1115,13 @@ extern int g_gemm_variant;
 extern int g_attn_debug;
 extern int g_attn_pf_debug;
 extern int g_skinny_debug;
+extern int g_gemm_pers_opt;
 extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 100 && variant < 104) { g_attn_debug = variant - 100; return TRACE_OK; }
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
-    if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }   // microbench: attention phase cut-offs
-    if (variant < 0 || variant > 4) return fail(TRACE_ERR_ARG, "variant must be 0..4");
+    if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
+    if (variant >= 300 && variant < 316) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }   // microbench: attention phase cut-offs
+    if (variant < 0 || variant > 6) return fail(TRACE_ERR_ARG, "variant must be 0..6");
     g_gemm_variant = variant;
     return TRACE_OK;
 }

@@ -320,7 +320,9 @@ int launch_glds(const GemmArgs& p, int epi, hipStream_t s) {
 
 }  // namespace
 
-int g_gemm_variant = 0;   // 0 = auto, 2 = 128^2 tiles, 3 = this file's 256^2 kernel, 4 = the loader-wave 256^2 kernel (tests / microbench)
+int g_gemm_variant = 0;   // 0 = auto, 2 = 128^2 tiles, 3 = this file's 256^2 kernel, 4 = the loader-wave 256^2 kernel, 5 / 6 = the persistent one
+                          // (gemm_pers.hip; 6 = static tile deal) — tests / microbench
+extern int g_gemm_pers_static;
 
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
     if (p.M <= 0 || p.N % BN || p.K % BK || p.K < BK) return TRACE_ERR_ARG;
@@ -338,9 +340,23 @@ int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
             const long rounds = (blocks256 + 255) / 256;
             v = (p.N % 256 == 0 && p.M >= 1024 && blocks256 * 10 >= rounds * 256 * 7) ? 3 : 2;
         }
-        // 256^2 tiles chosen automatically run on the loader-wave kernel (gemm_ldr.hip: same results bit for bit, +20-24 % on the
-        // K = 1024 ViT shapes); variant 3 forces this file's kernel for A/B runs
-        if (p.N % 256 == 0 && (g_gemm_variant == 4 || (g_gemm_variant == 0 && v == 3))) return launch_gemm_ldr(p, epi, s);
+        // 256^2 tiles run on the loader-wave kernels (same results bit for bit as this file's kernel, which variant 3 forces for A/B runs):
+        // gemm_ldr.hip (+20-24 % on the K = 1024 ViT shapes) and, where there is no residual to fetch, its persistent form gemm_pers.hip
+        // (tools/gemm_pers_ab.py, interleaved medians vs gemm_ldr: fc1 + QuickGELU -7.8 %, ViT qkv -5.3 %, prefill qkv / gate|up -2 .. -6 %;
+        // with a residual the tile ends in an HBM burst either way and the one-workgroup-per-tile kernel is 2-7 % ahead on the ViT shapes)
+        const bool pers_ok = p.N % 256 == 0 && !p.fp8 && p.K >= 128 && (long)p.M * p.ldc < (1L << 30) &&
+                             (epi != EPI_RESIDUAL || (long)p.M * p.ldr < (1L << 30));
+        if ((g_gemm_variant == 5 || g_gemm_variant == 6) && pers_ok) {
+            g_gemm_pers_static = g_gemm_variant == 6;
+            return launch_gemm_pers(p, epi, s);
+        }
+        if (p.N % 256 == 0 && (g_gemm_variant == 4 || (g_gemm_variant == 0 && v == 3))) {
+            if (g_gemm_variant == 0 && pers_ok && epi != EPI_RESIDUAL) {
+                g_gemm_pers_static = 0;
+                return launch_gemm_pers(p, epi, s);
+            }
+            return launch_gemm_ldr(p, epi, s);
+        }
         if (v == 3 && p.N % 256 == 0) return p.fp8 ? launch_glds<256, 256, 2, 4, true>(p, epi, s) : launch_glds<256, 256, 2, 4, false>(p, epi, s);
     }
     return p.fp8 ? launch_glds<128, 128, 2, 2, true>(p, epi, s) : launch_glds<128, 128, 2, 2, false>(p, epi, s);

@@ -1,0 +1,476 @@
+// PERSISTENT version of gemm_ldr.hip's 256x256 loader-wave GEMM: one workgroup per CU walks output tiles, and nothing outside the
+// K loop touches LDS or a barrier any more, so the loaders simply keep streaming K-tiles across the tile boundary.
+//
+// What gemm_ldr.hip pays per output tile outside its K loop (tools/gemm_trace.py, fc1 of the ViT: ~8 us of ~33): a fresh workgroup
+// (launch, 16 address set-ups, the first K-tile's round trip = 1.6 us with nothing to compute), the accumulators staged through
+// 135 KB of LDS (two workgroup barriers, every MFMA wave waiting for the slowest) and only then the stores.  Here:
+//   * grid = #CUs; a workgroup takes its first tile statically and every further one from a per-XCD ticket counter (the tile order
+//     stays XCD-contiguous and grouped, as in gemm.hip), fetched one tile ahead by one lane so the ticket's latency is never seen;
+//   * the 4 loader waves run one continuous stream of K-tiles: the barrier that hands K-tile q to the MFMA waves lets them issue
+//     K-tile q+1 — whether that is this tile's next K-tile or the NEXT tile's first one;
+//   * the 8 MFMA waves pass that barrier one quarter-step EARLY (all their fragment reads of the stage are in registers by then)
+//     and prefetch the next step's fragments under the last 8 MFMAs of the current one — across K-tiles and across output tiles
+//     (the next tile's first fragments are read in the middle of the epilogue), so a tile starts with its operands in registers
+//     and both LDS stages full;
+//   * the epilogue never leaves the wave: bias (from a 512-byte LDS row the loaders fill) / QuickGELU / SwiGLU in fp32 registers,
+//     packed to bf16, then ONE v_permlane16_swap per register pair turns "4 columns of one row per lane, 16 columns apart per
+//     fragment" into 8 consecutive columns per lane -> 16-byte non-temporal stores, 64 contiguous bytes per row per instruction,
+//     the two halves of a 128-byte line back to back.  No LDS staging, no barrier, no waiting for the other waves: the stores of
+//     tile n drain under the K loop of tile n+1 (raw s_barrier: it does not wait for the store acknowledgements).
+// Same K order, same fp32 -> bf16 roundings as gemm_ldr.hip / gemm.hip: results are bit-identical (tests/test_gpu_kernels.py).
+#include <mutex>
+#include <unordered_map>
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64, WM = 2, WN = 4;
+constexpr int NMT = WM * WN * 64;                 // 512 MFMA threads
+constexpr int NLW = 4;                            // loader waves
+constexpr int NTHR = NMT + NLW * 64;              // 768
+constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+constexpr int CTL_OFF = 2 * STAGE;                // int s_next[2] | 2 x 512-byte bias rows
+constexpr int BIAS_OFF = CTL_OFF + 64;
+constexpr int LDS_BYTES = BIAS_OFF + 2 * 512;
+constexpr int CTR_STRIDE = 32;                    // ints between the per-XCD ticket counters (one 128-byte line each)
+
+__device__ __forceinline__ int swz(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ bf16x8_t lds16(const char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+
+// logical tile id -> (row panel, column panel): groups of 8 row panels x all column panels (gemm.hip's order)
+__device__ __forceinline__ void tile_coords(int t, int ntm, int ntn, int& tm, int& tn) {
+    constexpr int GM = 8;
+    const int per_group = GM * ntn;
+    const int gid = t / per_group, first = gid * GM;
+    const int gsz = min(ntm - first, GM);
+    const int in_g = t - gid * per_group;
+    tm = first + in_g % gsz;
+    tn = in_g / gsz;
+}
+
+// One k-step (32 k of the 64-wide K-tile) of a wave's 128x64 sub-tile: 32 MFMAs.  wf / ac hold this step's W fragments and first
+// two A fragments on entry and the NEXT step's on exit (NEXT): the A fragments of m-tile pairs 1..3 are read a pair ahead as in
+// gemm_ldr.hip; under the last pair's 8 MFMAs the next step's first A pair and — each as soon as its last MFMA has issued — its four W
+// fragments.  BARRIER: the next step reads the other LDS stage; everything this wave reads from the current stage is in registers
+// before the last pair, so the barrier that releases the stage to the loaders sits there.
+// LDS addresses: y is the lane's swizzled offset inside a 16-row fragment block (k-step 0; k-step 1 is y ^ 64), oa / oa_n / ow_n the
+// wave-uniform offsets of the A block of this step and the A / W blocks of the next one.  y passes through an empty asm so that the
+// four (lane offset x stage) combinations are NOT hoisted out of the loop as invariants: there is exactly one register for them.
+// The MFMAs are inline asm with the accumulator TIED (dst = srcC = one register tuple for the whole tile).  Left to the register allocator,
+// the 128 accumulators were renumbered between the peeled first / last K-tile blocks and the loop body — with 160 of 168 registers pinned it
+// did that through scratch: ~20 dependent reload round trips per output tile, 12-15 us, far more than the epilogue this kernel is about.
+// volatile keeps them in source order; the compiler still places the s_waitcnt for their fragment operands.  Hazards it no longer sees:
+// an accumulator is touched again 32 MFMAs later (no back-to-back dependence), and the epilogue's first VALU read of one comes after an
+// explicit s_nop pair.
+__device__ __forceinline__ void mfma_acc(f32x4_t& c, const bf16x8_t& w, const bf16x8_t& a) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(a));
+}
+__device__ __forceinline__ void mfma_new(f32x4_t& c, const bf16x8_t& w, const bf16x8_t& a) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(w), "v"(a));
+}
+#define PERS_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// OPT (A/B builds): bit 1 = the hand-over barrier at the END of the k-step (fragments of the next K-tile read after it, as gemm_ldr.hip
+// does) instead of before its last 8 MFMAs
+template <bool FIRST, bool BARRIER, bool NEXT, int KS, int OPT>
+__device__ __forceinline__ void kstep(f32x4_t (&acc)[TM][TN], bf16x8_t (&wf)[TN], bf16x8_t (&ac)[2], int& y, int oa, int oa_n, int ow_n,
+                                      const char* lds) {
+    constexpr bool LATE = BARRIER && (OPT & 2);
+    PERS_FENCE();                                                   // every group below stays where it is written
+    asm volatile("" : "+v"(y));
+    const char* fa = lds + ((y ^ (KS << 6)) + oa);
+    bf16x8_t an[2];
+#pragma unroll
+    for (int ip = 0; ip < TM / 2 - 1; ++ip) {
+        an[0] = lds16(fa + (2 * ip + 2) * 2048);
+        an[1] = lds16(fa + (2 * ip + 3) * 2048);
+        PERS_FENCE();
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (FIRST) mfma_new(acc[2 * ip + ii][j], wf[j], ac[ii]);
+                else mfma_acc(acc[2 * ip + ii][j], wf[j], ac[ii]);
+            }
+        PERS_FENCE();
+        ac[0] = an[0]; ac[1] = an[1];
+    }
+    constexpr int ip = TM / 2 - 1;
+    if (BARRIER && !LATE) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    const char* fa_n = lds + ((y ^ ((KS ^ 1) << 6)) + oa_n);
+    const char* fw_n = lds + ((y ^ ((KS ^ 1) << 6)) + ow_n);
+    if (NEXT && !LATE) {
+        an[0] = lds16(fa_n);
+        an[1] = lds16(fa_n + 2048);
+        PERS_FENCE();
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        if (FIRST) { mfma_new(acc[2 * ip][j], wf[j], ac[0]); mfma_new(acc[2 * ip + 1][j], wf[j], ac[1]); }
+        else { mfma_acc(acc[2 * ip][j], wf[j], ac[0]); mfma_acc(acc[2 * ip + 1][j], wf[j], ac[1]); }
+        PERS_FENCE();
+        if (NEXT && !LATE) {
+            wf[j] = lds16(fw_n + j * 2048);
+            PERS_FENCE();
+        }
+    }
+    if (LATE) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (NEXT) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = lds16(fw_n + j * 2048);
+            an[0] = lds16(fa_n);
+            an[1] = lds16(fa_n + 2048);
+        }
+    }
+    if (NEXT) { ac[0] = an[0]; ac[1] = an[1]; }
+    PERS_FENCE();
+}
+
+// v_permlane16_swap: rows (16 lanes) 1 and 3 of a <-> rows 0 and 2 of b
+__device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    const u2_t r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// rows I0 .. I0+NI-1 (16-row m-tiles) of the wave's sub-tile: activation in registers, lane transposition, stores.  C and R are addressed
+// through buffer descriptors (scalar base + ONE 32-bit byte offset register per access) whose extent is the M valid rows: rows of the
+// last row panel that hang over M are dropped (stores) / read as zero (loads) by the bounds check, no predicates and no second code path.
+template <int EPI, int I0, int NI, int PD>
+__device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp)[TN], __amdgpu_buffer_rsrc_t crs, __amdgpu_buffer_rsrc_t rrs,
+                                              int coff, int cstep, int roff, int rstep) {
+    constexpr bool GLU = (EPI == EPI_SWIGLU);
+    constexpr int NH = GLU ? 1 : 2;               // 32-column output groups per m-tile
+    u32x4 rr[NI][NH];
+#define PERS_RLOAD(I)                                                                                                                  \
+    _Pragma("unroll") for (int h = 0; h < NH; ++h) rr[I][h] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + (I0 + (I)) * rstep + h * 64, 0, 0);
+    if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+        for (int i = 0; i < (NI < PD ? NI : PD); ++i) PERS_RLOAD(i);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if (EPI == EPI_RESIDUAL && i + PD < NI) PERS_RLOAD(i + PD);
+        uint32_t pk[2 * NH][2];
+        if (!GLU) {
+            // the packed bias is re-unpacked for every m-tile (opaque to CSE): unpacked once, it is 16 registers beside 128 accumulators
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bp[j].x), "+v"(bp[j].y));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                // two elements per VALU instruction where the ISA has packed fp32 (add / mul); exp2 and rcp stay one per element
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                const f32x2_t b01 = {bflo(bp[j].x), bfhi(bp[j].x)}, b23 = {bflo(bp[j].y), bfhi(bp[j].y)};
+                f32x2_t x01 = f32x2_t{acc[I0 + i][j][0], acc[I0 + i][j][1]} + b01;
+                f32x2_t x23 = f32x2_t{acc[I0 + i][j][2], acc[I0 + i][j][3]} + b23;
+                if (EPI == EPI_QUICKGELU) {
+                    const f32x2_t t01 = x01 * -2.4554669595930157f, t23 = x23 * -2.4554669595930157f;
+                    const f32x2_t d01 = f32x2_t{__builtin_amdgcn_exp2f(t01[0]), __builtin_amdgcn_exp2f(t01[1])} + 1.f;
+                    const f32x2_t d23 = f32x2_t{__builtin_amdgcn_exp2f(t23[0]), __builtin_amdgcn_exp2f(t23[1])} + 1.f;
+                    x01 = x01 * f32x2_t{__builtin_amdgcn_rcpf(d01[0]), __builtin_amdgcn_rcpf(d01[1])};
+                    x23 = x23 * f32x2_t{__builtin_amdgcn_rcpf(d23[0]), __builtin_amdgcn_rcpf(d23[1])};
+                }
+                pk[j][0] = pack2bf(x01[0], x01[1]);
+                pk[j][1] = pack2bf(x23[0], x23[1]);
+            }
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < TN / 2; ++jj) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float gt = acc[I0 + i][2 * jj][q], up = acc[I0 + i][2 * jj + 1][q];
+                    v[q] = gt * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gt)) * up;
+                }
+                pk[jj][0] = pack2bf(v[0], v[1]);
+                pk[jj][1] = pack2bf(v[2], v[3]);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            // lane (r, g) holds columns g*4..+3 of fragment 2h in pk[2h] and of fragment 2h+1 (16 columns further) in pk[2h+1]; after the swaps
+            // it holds 8 consecutive columns starting at {0, 16, 8, 24}[g] of the 32-column group: {pk[2h][0], pk[2h][1], pk[2h+1][0], pk[2h+1][1]}
+            swap16(pk[2 * h][0], pk[2 * h + 1][0]);
+            swap16(pk[2 * h][1], pk[2 * h + 1][1]);
+            u32x4 v = {pk[2 * h][0], pk[2 * h][1], pk[2 * h + 1][0], pk[2 * h + 1][1]};
+            if (EPI == EPI_RESIDUAL) {
+                const u32x4 q = rr[i][h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = pack2bf(bflo(v[e]) + bflo(q[e]), bfhi(v[e]) + bfhi(q[e]));
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(v, crs, coff + (I0 + i) * cstep + h * 64, 0, 2);       // aux 2 = nt
+        }
+    }
+#undef PERS_RLOAD
+}
+
+// EPI_RESIDUAL in two passes.  Pass 1 turns the 128 accumulator registers into 64 registers of packed, lane-transposed bf16(acc + bias) —
+// exactly what the one-pass epilogue holds before it adds the residual, so the roundings are unchanged — and, with the registers that
+// frees, requests ALL 16 residual pieces of the lane before the first store: on this ISA loads and stores share one in-order counter, and
+// a residual load issued behind a store cannot be waited for without waiting for that store's acknowledgement as well.
+__device__ __forceinline__ void residual_pack(f32x4_t (&acc)[TM][TN], uint2 (&bp)[TN], u32x4 (&out)[TM][2], u32x4 (&rr)[TM][2],
+                                              __amdgpu_buffer_rsrc_t rrs, int roff, int rstep) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bp[j].x), "+v"(bp[j].y));
+        uint32_t pk[TN][2];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            pk[j][0] = pack2bf(acc[i][j][0] + bflo(bp[j].x), acc[i][j][1] + bfhi(bp[j].x));
+            pk[j][1] = pack2bf(acc[i][j][2] + bflo(bp[j].y), acc[i][j][3] + bfhi(bp[j].y));
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            swap16(pk[2 * h][0], pk[2 * h + 1][0]);
+            swap16(pk[2 * h][1], pk[2 * h + 1][1]);
+            out[i][h] = u32x4{pk[2 * h][0], pk[2 * h][1], pk[2 * h + 1][0], pk[2 * h + 1][1]};
+            rr[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + i * rstep + h * 64, 0, 0);
+        }
+    }
+}
+__device__ __forceinline__ void residual_store(u32x4 (&out)[TM][2], u32x4 (&rr)[TM][2], __amdgpu_buffer_rsrc_t crs, int coff, int cstep) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4 v = out[i][h];
+            const u32x4 q = rr[i][h];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = pack2bf(bflo(v[e]) + bflo(q[e]), bfhi(v[e]) + bfhi(q[e]));
+            __builtin_amdgcn_raw_buffer_store_b128(v, crs, coff + i * cstep + h * 64, 0, 2);
+        }
+}
+
+template <int EPI, int OPT>
+__global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, int dynamic) {
+    constexpr bool GLU = (EPI == EPI_SWIGLU);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* s_next = reinterpret_cast<int*>(smem + CTL_OFF);
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM, total = ntm * ntn;
+    const int nk = p.K / BK;
+    // this workgroup's XCD and that XCD's contiguous chunk of logical tile ids (common.h xcd_remap's split)
+    const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int cnt = q8 + (xcd < r8 ? 1 : 0);
+    const int base = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int nwg = (G >> 3) + (xcd < (G & 7) ? 1 : 0);            // workgroups on this XCD (<= cnt: the launcher keeps G <= total)
+
+    if (wid >= WM * WN) {
+        // ---------------- loader wave lw: pieces of 8 tile rows x 128 bytes; lw 0,1 -> A rows 0..127 / 128..255, lw 2,3 -> W ----------------
+        const int lw = wid - WM * WN;
+        const bool isA = lw < 2;
+        const int half = (lw & 1) * 128;
+        const int region = (isA ? 0 : A_BYTES) + half * 128;
+        const char* src[16];
+        int li = slot, n = 0, q = 0, ticket = 0;
+        uint2 bias2 = make_uint2(0u, 0u);
+#define PERS_SETUP()                                                                                                                   \
+        {                                                                                                                              \
+            int tm_, tn_;                                                                                                              \
+            tile_coords(base + li, ntm, ntn, tm_, tn_);                                                                                \
+            const int m0_ = tm_ * BM, n0_ = tn_ * BN;                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                                           \
+                const int row = half + j * 8 + (lane >> 3);                                                                            \
+                const int kc = (lane & 7) ^ ((row >> 1) & 7);                                                                          \
+                src[j] = isA ? reinterpret_cast<const char*>(p.A) + ((size_t)min(m0_ + row, p.M - 1) * p.lda + kc * 8) * 2             \
+                             : reinterpret_cast<const char*>(p.W) + ((size_t)(n0_ + row) * p.ldw + kc * 8) * 2;                        \
+            }                                                                                                                          \
+            if (!GLU && lw == 3 && p.bias) bias2 = *reinterpret_cast<const uint2*>(p.bias + n0_ + lane * 4);  /* else stays zero */   \
+        }
+#define PERS_ISSUE(STG, KO)                                                                                                            \
+        {                                                                                                                              \
+            char* dst_ = smem + (STG) * STAGE + region;                                                                                \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j)                                                                             \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (KO)),                       \
+                                                 (__attribute__((address_space(3))) void*)(dst_ + j * 1024), 16, 0, 0);                \
+        }
+        PERS_SETUP();
+        PERS_ISSUE(0, 0);
+        while (true) {
+            for (int kt = 0; kt < nk; ++kt, ++q) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (kt == 0 && !GLU && lw == 3)                     // this tile's bias row (zeros without a bias), read by the MFMA waves after the K loop
+                    *reinterpret_cast<uint2*>(smem + BIAS_OFF + (n & 1) * 512 + lane * 8) = bias2;
+                if (kt == 1 && tid == NMT) {                        // the tile after this one: everyone reads it after this tile's last hand-over
+                    s_next[(n + 1) & 1] = dynamic ? nwg + ticket : li + nwg;
+                    if (dynamic && ticket == cnt - 1) ctr[xcd * CTR_STRIDE] = 0;   // the launch's last ticket on this XCD: re-arm the counter
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                       // K-tile q handed over; the stage of q-1 is free
+                // the ticket rides with K-tile 1's pieces: from the second tile on that hand-over is an epilogue away, so its latency is free
+                if (kt == 0 && dynamic && tid == NMT) ticket = atomicAdd(ctr + xcd * CTR_STRIDE, 1);
+                if (kt + 1 < nk) {
+                    PERS_ISSUE((q + 1) & 1, (kt + 1) * 128);
+                } else {
+                    li = __builtin_amdgcn_readfirstlane(s_next[(n + 1) & 1]);
+                    if (li < cnt) {
+                        PERS_SETUP();
+                        PERS_ISSUE((q + 1) & 1, 0);
+                    }
+                }
+            }
+            if (li >= cnt) break;
+            ++n;
+        }
+#undef PERS_SETUP
+#undef PERS_ISSUE
+        return;
+    }
+
+    // ---------------- MFMA waves ----------------
+    const int wm = wid / WN, wn = wid % WN;
+    int y = swz(lane & 15, lane >> 4);                              // lane offset inside a 16-row fragment block (rows r, 16-byte chunk g, swizzled)
+    const int oa0 = wm * (BM / WM) * 128, ow0 = A_BYTES + wn * (BN / WN) * 128;      // this wave's A / W blocks inside a stage
+    f32x4_t acc[TM][TN];
+    bf16x8_t wf[TN], ac[2];
+    int li = slot, n = 0, q = 0;
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, p.M * p.ldc * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(EPI == EPI_RESIDUAL ? p.R : p.C), 0,
+                                                                         p.M * (EPI == EPI_RESIDUAL ? p.ldr : p.ldc) * 2, 0x00020000);
+
+#define PERS_ST(Q) (((Q) & 1) * STAGE)
+#define PERS_FRAGS(Q)                                                                              \
+    {                                                                                              \
+        /* y is rebuilt from an id the optimiser cannot see through, so it is not kept (spilled) across the epilogue */ \
+        int lane_y;                                                                                \
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_y)); \
+        y = swz(lane_y & 15, lane_y >> 4);                                                         \
+        const char* fw_ = smem + (y + PERS_ST(Q) + ow0);                                           \
+        const char* fa_ = smem + (y + PERS_ST(Q) + oa0);                                           \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) wf[j] = lds16(fw_ + j * 2048);              \
+        ac[0] = lds16(fa_);                                                                        \
+        ac[1] = lds16(fa_ + 2048);                                                                 \
+    }
+// the two k-steps of K-tile Q; the second one hands the stage back and prefetches from K-tile Q+1 (B1 / N1)
+#define PERS_KTILE(FIRST, B1, N1, Q)                                                                                               \
+    kstep<FIRST, false, true, 0, OPT>(acc, wf, ac, y, PERS_ST(Q) + oa0, PERS_ST(Q) + oa0, PERS_ST(Q) + ow0, smem);                     \
+    kstep<false, B1, N1, 1, OPT>(acc, wf, ac, y, PERS_ST(Q) + oa0, PERS_ST((Q) + 1) + oa0, PERS_ST((Q) + 1) + ow0, smem);
+    __builtin_amdgcn_s_barrier();                                   // K-tile 0 of the first tile has landed
+    PERS_FRAGS(0);
+    while (true) {
+        int tm, tn;
+        tile_coords(base + li, ntm, ntn, tm, tn);
+        const int m0 = tm * BM, n0 = tn * BN;
+        PERS_KTILE(true, true, true, q);
+        ++q;
+        for (int kt = 1; kt < nk - 1; ++kt, ++q) { PERS_KTILE(false, true, true, q); }
+        PERS_KTILE(false, false, false, q);
+        ++q;
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");             // the last MFMAs' results are read by plain VALU code from here on
+        __builtin_amdgcn_sched_barrier(0);
+        const int li_next = __builtin_amdgcn_readfirstlane(s_next[(n + 1) & 1]);
+        const bool has_next = li_next < cnt;
+        int lane_e;
+        // the lane's row / column offsets are recomputed per tile from an id the optimiser cannot hoist: as loop invariants they would
+        // sit in registers across the K loop, which has none to spare (128 accumulators + 32 fragment registers of 168)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+        const int g_e = lane_e >> 4;
+        uint2 bp[TN];                                               // this lane's 4 x 4 bias values, packed (unpacked where they are used)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bp[j] = make_uint2(0u, 0u);
+            if (!GLU) bp[j] = *reinterpret_cast<const uint2*>(smem + BIAS_OFF + (n & 1) * 512 + (wn * (BN / WN) + j * 16 + g_e * 4) * 2);
+        }
+        if (has_next) {                                             // K-tile 0 of the next tile: the loaders go on to its K-tile 1 during the epilogue
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const int pcol = ((g_e & 1) << 4) | ((g_e >> 1) << 3);      // first of the lane's 8 consecutive columns within a 32-column group
+        const int mbase = m0 + wm * (BM / WM) + (lane_e & 15);
+        const int cbase = (GLU ? n0 / 2 + wn * (BN / WN / 2) : n0 + wn * (BN / WN)) + pcol;
+        const int coff = (mbase * p.ldc + cbase) * 2, roff = (EPI == EPI_RESIDUAL) ? (mbase * p.ldr + cbase) * 2 : 0;     // bytes
+        if constexpr (EPI == EPI_RESIDUAL) {
+            u32x4 out[TM][2], rr[TM][2];
+            residual_pack(acc, bp, out, rr, rrs, roff, 32 * p.ldr);
+            if (has_next) PERS_FRAGS(q);
+            residual_store(out, rr, crs, coff, 32 * p.ldc);
+        } else {
+            epilogue_rows<EPI, 0, TM / 2, 1>(acc, bp, crs, rrs, coff, 32 * p.ldc, roff, 32 * p.ldr);
+            if (has_next) PERS_FRAGS(q);                            // 24 registers the first half of the epilogue has freed
+            epilogue_rows<EPI, TM / 2, TM / 2, 2>(acc, bp, crs, rrs, coff, 32 * p.ldc, roff, 32 * p.ldr);
+        }
+        if (!has_next) break;
+        li = li_next;
+        ++n;
+    }
+#undef PERS_ST
+#undef PERS_KTILE
+#undef PERS_FRAGS
+}
+
+int g_ncu = 0;
+// ticket counters: 8 per stream (two launches that may run concurrently must not share them; launches on one stream are ordered)
+std::mutex g_ctr_mu;
+std::unordered_map<hipStream_t, int*> g_ctrs;
+int* counters_for(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_ctr_mu);
+    auto it = g_ctrs.find(s);
+    if (it != g_ctrs.end()) return it->second;
+    if (!g_ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
+        g_ncu = prop.multiProcessorCount;
+    }
+    int* c = nullptr;
+    if (hipMalloc(&c, 8 * CTR_STRIDE * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(c, 0, 8 * CTR_STRIDE * sizeof(int), s) != hipSuccess) { (void)hipFree(c); return nullptr; }   // ordered before the launch
+    g_ctrs[s] = c;
+    return c;
+}
+
+template <int EPI, int OPT>
+void launch_opt(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers_kernel<EPI, OPT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        done = true;
+    }
+    hipLaunchKernelGGL((gemm_pers_kernel<EPI, OPT>), dim3(nblk), dim3(NTHR), LDS_BYTES, s, p, ctr, dynamic);
+}
+int g_opt = 0;
+template <int EPI>
+void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
+    switch (g_opt) {
+        case 2: launch_opt<EPI, 2>(p, nblk, dynamic, ctr, s); break;
+        default: launch_opt<EPI, 0>(p, nblk, dynamic, ctr, s); break;
+    }
+}
+
+}  // namespace
+
+int g_gemm_pers_opt = 0;           // A/B builds of the K loop (trace_op_set_gemm_variant(300 + opt))
+int g_gemm_pers_static = 0;        // 1: tiles dealt round-robin instead of by ticket (A/B runs)
+
+// Creates the ticket counters of a stream ahead of its first launch (an allocation + a memset: not something to meet inside a timed or
+// captured region); launch_gemm_pers does it on demand otherwise.
+int gemm_pers_init(hipStream_t s) { return counters_for(s) ? TRACE_OK : TRACE_ERR_HIP; }
+
+int launch_gemm_pers(const GemmArgs& p, int epi, hipStream_t s) {
+    if (p.M < 1 || p.N % BN || p.K % BK || p.K < 2 * BK || p.fp8) return TRACE_ERR_ARG;
+    if ((long)p.M * p.ldc >= (1L << 30) || (epi == EPI_RESIDUAL && (long)p.M * p.ldr >= (1L << 30))) return TRACE_ERR_ARG;   // 32-bit byte offsets
+    int* ctr = counters_for(s);
+    if (!ctr) return TRACE_ERR_HIP;
+    const int total = ((p.M + BM - 1) / BM) * (p.N / BN);
+    const int nblk = total < g_ncu ? total : g_ncu;
+    const int dynamic = g_gemm_pers_static ? 0 : 1;
+    g_opt = g_gemm_pers_opt;
+    switch (epi) {
+        case EPI_NONE: launch_one<EPI_NONE>(p, nblk, dynamic, ctr, s); break;
+        case EPI_RESIDUAL: launch_one<EPI_RESIDUAL>(p, nblk, dynamic, ctr, s); break;
+        case EPI_QUICKGELU: launch_one<EPI_QUICKGELU>(p, nblk, dynamic, ctr, s); break;
+        case EPI_SWIGLU: launch_one<EPI_SWIGLU>(p, nblk, dynamic, ctr, s); break;
+        default: return TRACE_ERR_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+}

@@ -424,6 +424,271 @@ __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, i
 #undef PERS_FRAGS
 }
 
+// =====================================================================================================================================
+// The same kernel on v_mfma_f32_32x32x16_bf16.  Why: on this part a GEMM runs at the clock its power budget allows (~1.9 of 2.4 GHz here), and
+// per flop the 32x32 MFMA reads half the A / B operand registers of the 16x16x32 one (the guide's register-resident MFMA loops sustain
+// 2382 vs 2075 TFLOP/s).  Per wave still a 128 x 64 sub-tile = 4 x 2 blocks of 32 x 32 (128 accumulator registers), per 16-k step 2 W + 4 A
+// fragments (one ds_read_b128 each from the same swizzled LDS image) for 8 MFMAs; every fragment of step s+1 is requested right after the
+// last MFMA that reads its register in step s — a full step (8 MFMAs = 256 cycles) ahead of its first use.  The k order inside an MFMA
+// differs from the 16x16x32 kernels (two 16-k sums instead of one 32-k sum), so results agree with them to fp32 rounding, not bit for bit.
+// Lane layout of an accumulator (operands swapped, D = W . A^T): lane l, register 4b + q  <->  row m = l % 32, column 8b + 4 (l / 32) + q.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+__device__ __forceinline__ void mfma32_acc(f32x16_t& c, const bf16x8_t& w, const bf16x8_t& a) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(a));
+}
+__device__ __forceinline__ void mfma32_new(f32x16_t& c, const bf16x8_t& w, const bf16x8_t& a) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(w), "v"(a));
+}
+// v_permlane32_swap: lanes 32..63 of a <-> lanes 0..31 of b
+__device__ __forceinline__ void swap32(uint32_t& a, uint32_t& b) {
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+constexpr int TM2 = 4, TN2 = 2;
+
+// One 16-k step: four pairs of MFMAs (one A fragment x the two W fragments each).  A fragment register is reloaded ONE PAIR AFTER the pair
+// that read it: a ds_read whose destination an in-flight MFMA still reads cannot issue (SQ_WAIT_INST_LDS: the first build reloaded right behind
+// the reading pair and lost 25 % to it), so on entry a[0..2] hold this step's fragments, a[3] is requested behind pair 0, the next step's
+// a[0..2] behind pairs 1..3, its W fragments (a second register pair, swapped at the end) behind pair 0.
+// MODE 0: the next step is in the same LDS stage.  MODE 1: it is the next K-tile (other stage): the hand-over barrier sits behind pair 1 —
+// every read of the current stage has been waited for by then.  MODE 2: last step of an output tile, nothing to prefetch.
+template <bool FIRST, int MODE>
+__device__ __forceinline__ void kstep32(f32x16_t (&acc)[TM2][TN2], bf16x8_t (&w)[TN2], bf16x8_t (&a)[TM2], int& y, int cur, int oa, int nxt, int oa_n,
+                                        int ow_n, const char* lds) {
+    PERS_FENCE();
+    asm volatile("" : "+v"(y));
+    const char* fa = lds + ((y ^ cur) + oa);
+    const char* fa_n = lds + ((y ^ nxt) + oa_n);
+    const char* fw_n = lds + ((y ^ nxt) + ow_n);
+    bf16x8_t wn_[TN2];
+#define PERS_PAIR(MB)                                                                              \
+    _Pragma("unroll") for (int nb = 0; nb < TN2; ++nb) {                                           \
+        if (FIRST) mfma32_new(acc[MB][nb], w[nb], a[MB]);                                          \
+        else mfma32_acc(acc[MB][nb], w[nb], a[MB]);                                                \
+    }                                                                                              \
+    PERS_FENCE();
+    PERS_PAIR(0);
+    a[3] = lds16(fa + 3 * 4096);
+    if (MODE == 0) {
+#pragma unroll
+        for (int nb = 0; nb < TN2; ++nb) wn_[nb] = lds16(fw_n + nb * 4096);
+    }
+    PERS_FENCE();
+    PERS_PAIR(1);
+    if (MODE == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int nb = 0; nb < TN2; ++nb) wn_[nb] = lds16(fw_n + nb * 4096);
+    }
+    if (MODE != 2) { a[0] = lds16(fa_n); PERS_FENCE(); }
+    PERS_PAIR(2);
+    if (MODE != 2) { a[1] = lds16(fa_n + 4096); PERS_FENCE(); }
+    PERS_PAIR(3);
+    if (MODE != 2) {
+        a[2] = lds16(fa_n + 2 * 4096);
+#pragma unroll
+        for (int nb = 0; nb < TN2; ++nb) w[nb] = wn_[nb];
+    }
+#undef PERS_PAIR
+    PERS_FENCE();
+}
+
+// activation + packing of one 32 x 32 accumulator block: pk[b] = columns 8b + 4 hi + 0..3 of the lane's row (bias = the matching 4 x 4 values, packed)
+template <int EPI>
+__device__ __forceinline__ void pack_block32(const f32x16_t& c, const uint2 (&bp)[4], uint32_t (&pk)[4][2]) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const f32x2_t b01 = {bflo(bp[b].x), bfhi(bp[b].x)}, b23 = {bflo(bp[b].y), bfhi(bp[b].y)};
+        f32x2_t x01 = f32x2_t{c[4 * b], c[4 * b + 1]} + b01;
+        f32x2_t x23 = f32x2_t{c[4 * b + 2], c[4 * b + 3]} + b23;
+        if (EPI == EPI_QUICKGELU) {
+            const f32x2_t t01 = x01 * -2.4554669595930157f, t23 = x23 * -2.4554669595930157f;
+            const f32x2_t d01 = f32x2_t{__builtin_amdgcn_exp2f(t01[0]), __builtin_amdgcn_exp2f(t01[1])} + 1.f;
+            const f32x2_t d23 = f32x2_t{__builtin_amdgcn_exp2f(t23[0]), __builtin_amdgcn_exp2f(t23[1])} + 1.f;
+            x01 = x01 * f32x2_t{__builtin_amdgcn_rcpf(d01[0]), __builtin_amdgcn_rcpf(d01[1])};
+            x23 = x23 * f32x2_t{__builtin_amdgcn_rcpf(d23[0]), __builtin_amdgcn_rcpf(d23[1])};
+        }
+        pk[b][0] = pack2bf(x01[0], x01[1]);
+        pk[b][1] = pack2bf(x23[0], x23[1]);
+    }
+}
+// Lane transposition of a block's 32 packed columns: after the v_permlane32_swaps a lane holds columns 8 hi + 0..7 (P0) and 16 + 8 hi + 0..7 (P1)
+// of its row; after the v_permlane16_swaps, lo = rows 0..15 and hi_ = rows 16..31 of the block, each lane 8 consecutive columns starting at
+// {0, 16, 8, 24}[lane / 16], i.e. 16 rows x 64 contiguous bytes per store — the same picture as the 16x16 kernel's epilogue.
+__device__ __forceinline__ void transpose_block32(uint32_t (&pk)[4][2], u32x4& lo, u32x4& hi_) {
+    swap32(pk[0][0], pk[1][0]); swap32(pk[0][1], pk[1][1]);
+    swap32(pk[2][0], pk[3][0]); swap32(pk[2][1], pk[3][1]);
+    lo = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+    hi_ = u32x4{pk[2][0], pk[2][1], pk[3][0], pk[3][1]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        uint32_t x = lo[e], z = hi_[e];
+        swap16(x, z);
+        lo[e] = x; hi_[e] = z;
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NTHR) void gemm_pers32_kernel(GemmArgs p, int* ctr, int dynamic) {
+    constexpr bool GLU = (EPI == EPI_SWIGLU);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* s_next = reinterpret_cast<int*>(smem + CTL_OFF);
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Sched sc = make_sched(p);
+    const int ntn = sc.ntn, ntm = sc.ntm, nk = sc.nk, cnt = sc.cnt, base = sc.base;
+    if (wid >= WM * WN) {
+        loader_role<GLU>(p, sc, smem, ctr, dynamic, wid - WM * WN, tid, lane);
+        return;
+    }
+    const int wm = wid / WN, wn = wid % WN;
+    const int oa0 = wm * (BM / WM) * 128, ow0 = A_BYTES + wn * (BN / WN) * 128;      // this wave's A / W blocks inside a stage
+    f32x16_t acc[TM2][TN2];
+    bf16x8_t w[TN2], a[TM2];
+    int y = 0;
+    int li = sc.slot, n = 0, q = 0;
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, p.M * p.ldc * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(EPI == EPI_RESIDUAL ? p.R : p.C), 0,
+                                                                         p.M * (EPI == EPI_RESIDUAL ? p.ldr : p.ldc) * 2, 0x00020000);
+#define PERS_ST(Q) (((Q) & 1) * STAGE)
+// lane offset inside a 32-row fragment block at 16-k step 0: row l % 32, 16-byte chunk l / 32 (step s: chunk 2s + l / 32, i.e. offset ^ (s << 5))
+#define PERS_FRAGS32(Q)                                                                            \
+    {                                                                                              \
+        int lane_y;                                                                                \
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_y)); \
+        y = swz(lane_y & 31, lane_y >> 5);                                                         \
+        const char* fw_ = smem + (y + PERS_ST(Q) + ow0);                                           \
+        const char* fa_ = smem + (y + PERS_ST(Q) + oa0);                                           \
+        _Pragma("unroll") for (int nb = 0; nb < TN2; ++nb) w[nb] = lds16(fw_ + nb * 4096);         \
+        _Pragma("unroll") for (int mb = 0; mb < TM2 - 1; ++mb) a[mb] = lds16(fa_ + mb * 4096);     \
+    }
+// K-tile Q: four 16-k steps; the last one hands the stage back and prefetches from K-tile Q+1 (LAST = MODE of the fourth step)
+#define PERS_KTILE32(FIRST, LAST, Q)                                                                                \
+    kstep32<FIRST, 0>(acc, w, a, y, 0 << 5, PERS_ST(Q) + oa0, 1 << 5, PERS_ST(Q) + oa0, PERS_ST(Q) + ow0, smem);   \
+    kstep32<false, 0>(acc, w, a, y, 1 << 5, PERS_ST(Q) + oa0, 2 << 5, PERS_ST(Q) + oa0, PERS_ST(Q) + ow0, smem);   \
+    kstep32<false, 0>(acc, w, a, y, 2 << 5, PERS_ST(Q) + oa0, 3 << 5, PERS_ST(Q) + oa0, PERS_ST(Q) + ow0, smem);   \
+    kstep32<false, LAST>(acc, w, a, y, 3 << 5, PERS_ST(Q) + oa0, 0, PERS_ST((Q) + 1) + oa0, PERS_ST((Q) + 1) + ow0, smem);
+    __builtin_amdgcn_s_barrier();                                   // K-tile 0 of the first tile has landed
+    PERS_FRAGS32(0);
+    while (true) {
+        int tm, tn;
+        tile_coords(base + li, ntm, ntn, tm, tn);
+        const int m0 = tm * BM, n0 = tn * BN;
+        PERS_KTILE32(true, 1, q);
+        ++q;
+        for (int kt = 1; kt < nk - 1; ++kt, ++q) { PERS_KTILE32(false, 1, q); }
+        PERS_KTILE32(false, 2, q);
+        ++q;
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // the last MFMAs' results are read by plain VALU code from here on
+        __builtin_amdgcn_sched_barrier(0);
+        const int li_next = __builtin_amdgcn_readfirstlane(s_next[(n + 1) & 1]);
+        const bool has_next = li_next < cnt;
+        if (has_next) {                                             // K-tile 0 of the next tile: the loaders go on to its K-tile 1 during the epilogue
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        int lane_e;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+        const int hi = lane_e >> 5, g_e = lane_e >> 4;
+        const int pcol = ((g_e & 1) << 4) | ((g_e >> 1) << 3);      // first of the lane's 8 consecutive columns within a 32-column group (after the transposition)
+        const int mrow = m0 + wm * (BM / WM) + (lane_e & 15);       // row of the `lo` store of block 0; `hi_` stores 16 rows further, block mb 32 mb further
+        const int cbase = (GLU ? n0 / 2 + wn * (BN / WN / 2) : n0 + wn * (BN / WN)) + pcol;
+        const int coff = (mrow * p.ldc + cbase) * 2, roff = (EPI == EPI_RESIDUAL) ? (mrow * p.ldr + cbase) * 2 : 0;     // bytes
+        const int cstep = 32 * p.ldc, rstep = 32 * p.ldr;           // bytes per 16 rows
+        int boff = BIAS_OFF + (n & 1) * 512 + (wn * (BN / WN) + 4 * hi) * 2;          // the lane's bias values: + (32 nb + 8 b) * 2 bytes
+        if constexpr (EPI == EPI_RESIDUAL) {
+            u32x4 out[TM2][TN2][2], rr[TM2][TN2][2];
+#pragma unroll
+            for (int mb = 0; mb < TM2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < TN2; ++nb) {
+                    asm volatile("" : "+v"(boff));
+                    uint2 bp[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) bp[b] = *reinterpret_cast<const uint2*>(smem + boff + (32 * nb + 8 * b) * 2);
+                    uint32_t pk[4][2];
+                    pack_block32<EPI_NONE>(acc[mb][nb], bp, pk);
+                    transpose_block32(pk, out[mb][nb][0], out[mb][nb][1]);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        rr[mb][nb][h] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + (2 * mb + h) * rstep + nb * 64, 0, 0);
+                }
+            if (has_next) PERS_FRAGS32(q);
+#pragma unroll
+            for (int mb = 0; mb < TM2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < TN2; ++nb)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        u32x4 v = out[mb][nb][h];
+                        const u32x4 r = rr[mb][nb][h];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = pack2bf(bflo(v[e]) + bflo(r[e]), bfhi(v[e]) + bfhi(r[e]));
+                        __builtin_amdgcn_raw_buffer_store_b128(v, crs, coff + (2 * mb + h) * cstep + nb * 64, 0, 2);
+                    }
+        } else if constexpr (GLU) {
+            // a 32-column block of the interleaved weights is 16 gate + 16 up columns: registers 0..7 (b = 0, 1) and 8..15; its 16 outputs are
+            // columns 8b + 4 hi + q of the wave's output block nb -> permlane32 makes them 8 consecutive per lane, permlane16 joins the two blocks
+#pragma unroll
+            for (int mb = 0; mb < TM2; ++mb) {
+                uint32_t o[TN2][2][2];
+#pragma unroll
+                for (int nb = 0; nb < TN2; ++nb)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float gt = acc[mb][nb][4 * b + e], up = acc[mb][nb][8 + 4 * b + e];
+                            v[e] = gt * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gt)) * up;
+                        }
+                        o[nb][b][0] = pack2bf(v[0], v[1]);
+                        o[nb][b][1] = pack2bf(v[2], v[3]);
+                    }
+                u32x4 lo, hi_;
+#pragma unroll
+                for (int nb = 0; nb < TN2; ++nb) { swap32(o[nb][0][0], o[nb][1][0]); swap32(o[nb][0][1], o[nb][1][1]); }
+                lo = u32x4{o[0][0][0], o[0][0][1], o[0][1][0], o[0][1][1]};
+                hi_ = u32x4{o[1][0][0], o[1][0][1], o[1][1][0], o[1][1][1]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    uint32_t x = lo[e], z = hi_[e];
+                    swap16(x, z);
+                    lo[e] = x; hi_[e] = z;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(lo, crs, coff + (2 * mb) * cstep, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(hi_, crs, coff + (2 * mb + 1) * cstep, 0, 2);
+                if (mb == 1 && has_next) PERS_FRAGS32(q);
+            }
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < TM2; ++mb) {
+#pragma unroll
+                for (int nb = 0; nb < TN2; ++nb) {
+                    asm volatile("" : "+v"(boff));
+                    uint2 bp[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) bp[b] = *reinterpret_cast<const uint2*>(smem + boff + (32 * nb + 8 * b) * 2);
+                    uint32_t pk[4][2];
+                    pack_block32<EPI>(acc[mb][nb], bp, pk);
+                    u32x4 lo, hi_;
+                    transpose_block32(pk, lo, hi_);
+                    __builtin_amdgcn_raw_buffer_store_b128(lo, crs, coff + (2 * mb) * cstep + nb * 64, 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(hi_, crs, coff + (2 * mb + 1) * cstep + nb * 64, 0, 2);
+                }
+                if (mb == 1 && has_next) PERS_FRAGS32(q);             // 24 registers the first half of the epilogue has freed
+            }
+        }
+        if (!has_next) break;
+        li = li_next;
+        ++n;
+    }
+#undef PERS_ST
+#undef PERS_KTILE32
+#undef PERS_FRAGS32
+}
+
 int g_ncu = 0;
 // ticket counters: 8 per stream (two launches that may run concurrently must not share them; launches on one stream are ordered)
 std::mutex g_ctr_mu;
@@ -456,8 +721,18 @@ void launch_opt(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
 }
 int g_opt = 0;
 template <int EPI>
+void launch_32(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers32_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        done = true;
+    }
+    hipLaunchKernelGGL((gemm_pers32_kernel<EPI>), dim3(nblk), dim3(NTHR), LDS_BYTES, s, p, ctr, dynamic);
+}
+template <int EPI>
 void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
     switch (g_opt) {
+        case 1: launch_32<EPI>(p, nblk, dynamic, ctr, s); break;
         case 2: launch_opt<EPI, 2>(p, nblk, dynamic, ctr, s); break;
         default: launch_opt<EPI, 0>(p, nblk, dynamic, ctr, s); break;
     }

@@ -40,11 +40,11 @@ for name, M, N, K, epi, has_bias in shapes:
             if rnd_i == 0:
                 out = run()
                 if ref is None: ref = out
-                same[vn] = torch.equal(out, ref)
+                same[vn] = torch.equal(out, ref) or "max|d| %.3g (%d of %d differ)" % ((out.float() - ref.float()).abs().max().item(), int((out != ref).sum()), out.numel())
             ts[vn].append(timed(run))
     ops.set_gemm_variant(300)
     ops.set_gemm_variant(0)
     med = {k: statistics.median(v[1:]) for k, v in ts.items()}
     tf = lambda t: 2.0 * M * N * K / t / 1e6
     print("%-20s M=%6d N=%5d K=%5d | " % (name, M, N, K) + " | ".join("%s %7.1f us %6.1f TF %+5.1f%% %s" % (
-        k, med[k], tf(med[k]), (med[k] / med["ldr"] - 1) * 100, "" if same[k] else "DIFF") for k in med), flush=True)
+        k, med[k], tf(med[k]), (med[k] / med["ldr"] - 1) * 100, "" if same[k] is True else same[k]) for k in med), flush=True)

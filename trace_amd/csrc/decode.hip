@@ -958,6 +958,69 @@ int launch_add_rmsnorm(const float* part, int KS, const bf16_t* R, int ldr, bf16
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 
+// The qkv GEMV's fp32 partial rows -> bf16 q (RoPE applied) in `qout`, the new k row (RoPE applied) and v column appended to the caches:
+// what attn_decode_kernel's fused prologue does, as a kernel of its own (8 lanes per (sequence, head): lane c holds d = 8c..8c+7 and its
+// rotate-half partner d + 64).  Same sums (chunk order), same roundings as the fused path.
+__global__ __launch_bounds__(256) void qkv_finish_kernel(const float* __restrict__ part, int ks, int ldq, bf16_t* __restrict__ qout,
+                                                         bf16_t* __restrict__ kcache, bf16_t* __restrict__ vtcache, long slot_stride,
+                                                         long kv_head_stride, int ctx_stride, const int32_t* __restrict__ slots,
+                                                         const int32_t* __restrict__ pos, int B, int nq, int nkv,
+                                                         const float* __restrict__ cos_t, const float* __restrict__ sin_t) {
+    constexpr int HD = 128, HALF = 64;
+    const int nh = nq + 2 * nkv;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * nh * 8) return;
+    const int c = idx & 7, hh = (idx >> 3) % nh, b = (idx >> 3) / nh;
+    const int p_new = pos[b];
+    const float* pp = part + (size_t)b * ldq + (size_t)hh * HD + c * 8;
+    f32x4_t x[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // d..d+3, d+4..d+7, d+64.., d+68..
+    for (int k = 0; k < ks; ++k) {
+        const float* pk = pp + (size_t)k * SK_ROWS * ldq;
+        x[0] += *reinterpret_cast<const f32x4_t*>(pk);
+        x[1] += *reinterpret_cast<const f32x4_t*>(pk + 4);
+        x[2] += *reinterpret_cast<const f32x4_t*>(pk + HALF);
+        x[3] += *reinterpret_cast<const f32x4_t*>(pk + HALF + 4);
+    }
+    uint32_t a[4] = {pack2bf(x[0][0], x[0][1]), pack2bf(x[0][2], x[0][3]), pack2bf(x[1][0], x[1][1]), pack2bf(x[1][2], x[1][3])};
+    uint32_t bb[4] = {pack2bf(x[2][0], x[2][1]), pack2bf(x[2][2], x[2][3]), pack2bf(x[3][0], x[3][1]), pack2bf(x[3][2], x[3][3])};
+    if (hh >= nq + nkv) {                                // v: down a column of V^T
+        bf16_t* vb = vtcache + (size_t)slots[b] * slot_stride + (size_t)(hh - nq - nkv) * kv_head_stride + p_new;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            vb[(size_t)(c * 8 + 2 * e) * ctx_stride] = (bf16_t)(a[e] & 0xffffu);
+            vb[(size_t)(c * 8 + 2 * e + 1) * ctx_stride] = (bf16_t)(a[e] >> 16);
+            vb[(size_t)(HALF + c * 8 + 2 * e) * ctx_stride] = (bf16_t)(bb[e] & 0xffffu);
+            vb[(size_t)(HALF + c * 8 + 2 * e + 1) * ctx_stride] = (bf16_t)(bb[e] >> 16);
+        }
+        return;
+    }
+    const float4* cp = reinterpret_cast<const float4*>(cos_t + (size_t)p_new * HALF + c * 8);
+    const float4* sp = reinterpret_cast<const float4*>(sin_t + (size_t)p_new * HALF + c * 8);
+    const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+    const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    uint32_t o1[4], o2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x1l = bflo(a[e]), x1h = bfhi(a[e]), x2l = bflo(bb[e]), x2h = bfhi(bb[e]);
+        o1[e] = pack2bf(x1l * cs[2 * e] - x2l * sn[2 * e], x1h * cs[2 * e + 1] - x2h * sn[2 * e + 1]);
+        o2[e] = pack2bf(x2l * cs[2 * e] + x1l * sn[2 * e], x2h * cs[2 * e + 1] + x1h * sn[2 * e + 1]);
+    }
+    bf16_t* dst = hh < nq ? qout + (size_t)b * ldq + (size_t)hh * HD
+                          : kcache + (size_t)slots[b] * slot_stride + (size_t)(hh - nq) * kv_head_stride + (size_t)p_new * HD;
+    *reinterpret_cast<uint4*>(dst + c * 8) = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+    *reinterpret_cast<uint4*>(dst + HALF + c * 8) = make_uint4(o2[0], o2[1], o2[2], o2[3]);
+}
+int launch_qkv_finish(const float* part, int ks, int ldq, bf16_t* qout, bf16_t* kcache, bf16_t* vtcache, long slot_stride, long kv_head_stride,
+                      int ctx_stride, const int32_t* slots, const int32_t* pos, int B, int nq, int nkv, const float* cos_t, const float* sin_t,
+                      hipStream_t s) {
+    if (B < 1 || ks < 1 || (ldq % 8)) return TRACE_ERR_ARG;
+    const int total = B * (nq + 2 * nkv) * 8;
+    hipLaunchKernelGGL(qkv_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, ks, ldq, qout, kcache, vtcache, slot_stride,
+                       kv_head_stride, ctx_stride, slots, pos, B, nq, nkv, cos_t, sin_t);
+    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+}
+
 int g_attn_debug = 0;   // microbenchmark-only phase cut-offs (0 = full kernel)
 int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vtcache, long slot_stride, long kv_head_stride,
                        int ctx_stride, const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,

@@ -108,6 +108,10 @@ int launch_add_rmsnorm(const float* part, int KS, const bf16_t* R, int ldr, bf16
 // fuse_rope = 1: `qkv` rows are the raw [q | k | v] projections of the new token: q and the new k are rotated here
 // (RoPE at pos[b]) and k/v appended to the cache at row pos[b].  fuse_rope = 0: `qkv` holds ready q rows (ld ldq)
 // and the cache already contains row pos[b].  tickets: zeroed uint32 [B*nkv].  O [B, nq*hd].
+// the fused prologue of launch_attn_decode(fuse_rope = 1, qpart) as a kernel of its own: partial rows -> roped bf16 q rows in qout, k / v appended
+int launch_qkv_finish(const float* part, int ks, int ldq, bf16_t* qout, bf16_t* kcache, bf16_t* vtcache, long slot_stride, long kv_head_stride,
+                      int ctx_stride, const int32_t* slots, const int32_t* pos, int B, int nq, int nkv, const float* cos_t, const float* sin_t,
+                      hipStream_t s);
 int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vtcache, long slot_stride, long kv_head_stride,
                        int ctx_stride, const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,
                        int nq, int nkv, int hd, int nsplit, float scale, int fuse_rope, const float* cos_t, const float* sin_t,

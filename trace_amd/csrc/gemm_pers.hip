@@ -72,7 +72,7 @@ __device__ __forceinline__ void mfma_new(f32x4_t& c, const bf16x8_t& w, const bf
 }
 #define PERS_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-// OPT (A/B builds): bit 1 = the hand-over barrier at the END of the k-step (fragments of the next K-tile read after it, as gemm_ldr.hip
+// OPT (A/B builds, tools/gemm_pers_ab.py): bit 1 = the hand-over barrier at the END of the k-step (fragments of the next K-tile read after it, as gemm_ldr.hip
 // does) instead of before its last 8 MFMAs
 template <bool FIRST, bool BARRIER, bool NEXT, int KS, int OPT>
 __device__ __forceinline__ void kstep(f32x4_t (&acc)[TM][TN], bf16x8_t (&wf)[TN], bf16x8_t (&ac)[2], int& y, int oa, int oa_n, int ow_n,
@@ -87,13 +87,25 @@ __device__ __forceinline__ void kstep(f32x4_t (&acc)[TM][TN], bf16x8_t (&wf)[TN]
         an[0] = lds16(fa + (2 * ip + 2) * 2048);
         an[1] = lds16(fa + (2 * ip + 3) * 2048);
         PERS_FENCE();
+        // W-fragment-major: wf[3], the last fragment the previous step requested (behind its final MFMA pair), is first read by the 7th
+        // MFMA of the step instead of the 4th (OPT bit 2: the A-fragment-major order, for A/B runs)
+        if (OPT & 4) {
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+            for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (FIRST) mfma_new(acc[2 * ip + ii][j], wf[j], ac[ii]);
-                else mfma_acc(acc[2 * ip + ii][j], wf[j], ac[ii]);
-            }
+                for (int j = 0; j < TN; ++j) {
+                    if (FIRST) mfma_new(acc[2 * ip + ii][j], wf[j], ac[ii]);
+                    else mfma_acc(acc[2 * ip + ii][j], wf[j], ac[ii]);
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    if (FIRST) mfma_new(acc[2 * ip + ii][j], wf[j], ac[ii]);
+                    else mfma_acc(acc[2 * ip + ii][j], wf[j], ac[ii]);
+                }
+        }
         PERS_FENCE();
         ac[0] = an[0]; ac[1] = an[1];
     }
@@ -459,6 +471,7 @@ template <int EPI>
 void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
     switch (g_opt) {
         case 2: launch_opt<EPI, 2>(p, nblk, dynamic, ctr, s); break;
+        case 4: launch_opt<EPI, 4>(p, nblk, dynamic, ctr, s); break;
         default: launch_opt<EPI, 0>(p, nblk, dynamic, ctr, s); break;
     }
 }

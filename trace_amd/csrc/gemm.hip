@@ -346,8 +346,8 @@ int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
         // with a residual the tile ends in an HBM burst either way and the one-workgroup-per-tile kernel is 2-7 % ahead on the ViT shapes)
         const bool pers_ok = p.N % 256 == 0 && !p.fp8 && p.K >= 128 && (long)p.M * p.ldc < (1L << 30) &&
                              (epi != EPI_RESIDUAL || (long)p.M * p.ldr < (1L << 30));
-        if ((g_gemm_variant == 5 || g_gemm_variant == 6) && pers_ok) {
-            g_gemm_pers_static = g_gemm_variant == 6;
+        if ((g_gemm_variant >= 5 && g_gemm_variant <= 7) && pers_ok) {
+            g_gemm_pers_static = g_gemm_variant - 5;        // 5 ticketed, 6 static deal, 7 one workgroup per tile
             return launch_gemm_pers(p, epi, s);
         }
         if (p.N % 256 == 0 && (g_gemm_variant == 4 || (g_gemm_variant == 0 && v == 3))) {

@@ -156,21 +156,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // rows I0 .. I0+NI-1 (16-row m-tiles) of the wave's sub-tile: activation in registers, lane transposition, stores.  C and R are addressed
 // through buffer descriptors (scalar base + ONE 32-bit byte offset register per access) whose extent is the M valid rows: rows of the
 // last row panel that hang over M are dropped (stores) / read as zero (loads) by the bounds check, no predicates and no second code path.
-template <int EPI, int I0, int NI, int PD>
-__device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp)[TN], __amdgpu_buffer_rsrc_t crs, __amdgpu_buffer_rsrc_t rrs,
-                                              int coff, int cstep, int roff, int rstep) {
+template <int EPI, int I0, int NI>
+__device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp)[TN], __amdgpu_buffer_rsrc_t crs, int coff, int cstep, bool hi8) {
     constexpr bool GLU = (EPI == EPI_SWIGLU);
     constexpr int NH = GLU ? 1 : 2;               // 32-column output groups per m-tile
-    u32x4 rr[NI][NH];
-#define PERS_RLOAD(I)                                                                                                                  \
-    _Pragma("unroll") for (int h = 0; h < NH; ++h) rr[I][h] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + (I0 + (I)) * rstep + h * 64, 0, 0);
-    if (EPI == EPI_RESIDUAL) {
-#pragma unroll
-        for (int i = 0; i < (NI < PD ? NI : PD); ++i) PERS_RLOAD(i);
-    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        if (EPI == EPI_RESIDUAL && i + PD < NI) PERS_RLOAD(i + PD);
         uint32_t pk[2 * NH][2];
         if (!GLU) {
             // the packed bias is re-unpacked for every m-tile (opaque to CSE): unpacked once, it is 16 registers beside 128 accumulators
@@ -206,22 +197,33 @@ __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp
                 pk[jj][1] = pack2bf(v[2], v[3]);
             }
         }
+        // lane (r, g) holds columns g*4..+3 of fragment 2h in pk[2h] and of fragment 2h+1 (16 columns further) in pk[2h+1]; after the swaps it
+        // holds 8 consecutive columns starting at {0, 16, 8, 24}[g] of the 32-column group h: P[h] = {pk[2h][0], pk[2h][1], pk[2h+1][0], pk[2h+1][1]}
+        u32x4 P[NH];
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            // lane (r, g) holds columns g*4..+3 of fragment 2h in pk[2h] and of fragment 2h+1 (16 columns further) in pk[2h+1]; after the swaps
-            // it holds 8 consecutive columns starting at {0, 16, 8, 24}[g] of the 32-column group: {pk[2h][0], pk[2h][1], pk[2h+1][0], pk[2h+1][1]}
             swap16(pk[2 * h][0], pk[2 * h + 1][0]);
             swap16(pk[2 * h][1], pk[2 * h + 1][1]);
-            u32x4 v = {pk[2 * h][0], pk[2 * h][1], pk[2 * h + 1][0], pk[2 * h + 1][1]};
-            if (EPI == EPI_RESIDUAL) {
-                const u32x4 q = rr[i][h];
+            P[h] = u32x4{pk[2 * h][0], pk[2 * h][1], pk[2 * h + 1][0], pk[2 * h + 1][1]};
+        }
+        if (NH == 2) {
+            // Full 128-byte lines per store: rows r and r + 8 trade a piece (DPP row_ror:8), so that one instruction writes rows 0..7 of the m-tile
+            // — lanes r < 8 their own columns 0..31, lanes r >= 8 the columns 32..63 of row r - 8 — and the next one rows 8..15.  With 64-byte
+            // pieces (the two halves of a line in two instructions) the memory-side write counter read 22 % above the bytes of C.
+            u32x4 A, B;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = pack2bf(bflo(v[e]) + bflo(q[e]), bfhi(v[e]) + bfhi(q[e]));
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t snd = hi8 ? P[0][e] : P[NH - 1][e];
+                const uint32_t rcv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)snd, 0x128, 0xf, 0xf, false);     // row_ror:8 = lane r ^ 8
+                A[e] = hi8 ? rcv : P[0][e];
+                B[e] = hi8 ? P[NH - 1][e] : rcv;
             }
-            __builtin_amdgcn_raw_buffer_store_b128(v, crs, coff + (I0 + i) * cstep + h * 64, 0, 2);       // aux 2 = nt
+            __builtin_amdgcn_raw_buffer_store_b128(A, crs, coff + (I0 + i) * cstep, 0, 2);                 // aux 2 = nt
+            __builtin_amdgcn_raw_buffer_store_b128(B, crs, coff + (I0 + i) * cstep + (cstep >> 1), 0, 2);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(P[0], crs, coff + (I0 + i) * cstep, 0, 2);
         }
     }
-#undef PERS_RLOAD
 }
 
 // EPI_RESIDUAL in two passes.  Pass 1 turns the 128 accumulator registers into 64 registers of packed, lane-transposed bf16(acc + bias) —
@@ -423,9 +425,12 @@ __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, i
             if (has_next) PERS_FRAGS(q);
             residual_store(out, rr, crs, coff, 32 * p.ldc);
         } else {
-            epilogue_rows<EPI, 0, TM / 2, 1>(acc, bp, crs, rrs, coff, 32 * p.ldc, roff, 32 * p.ldr);
+            // full-line stores (not SwiGLU: its 32 output columns per wave are one 64-byte piece): lanes r >= 8 write row r - 8 / r, columns 32..63
+            const bool hi8 = (lane_e & 8) != 0;
+            const int coff2 = GLU ? coff : coff + (hi8 ? 64 - 16 * p.ldc : 0);
+            epilogue_rows<EPI, 0, TM / 2>(acc, bp, crs, coff2, 32 * p.ldc, hi8);
             if (has_next) PERS_FRAGS(q);                            // 24 registers the first half of the epilogue has freed
-            epilogue_rows<EPI, TM / 2, TM / 2, 2>(acc, bp, crs, rrs, coff, 32 * p.ldc, roff, 32 * p.ldr);
+            epilogue_rows<EPI, TM / 2, TM / 2>(acc, bp, crs, coff2, 32 * p.ldc, hi8);
         }
         if (!has_next) break;
         li = li_next;
@@ -491,7 +496,9 @@ int launch_gemm_pers(const GemmArgs& p, int epi, hipStream_t s) {
     int* ctr = counters_for(s);
     if (!ctr) return TRACE_ERR_HIP;
     const int total = ((p.M + BM - 1) / BM) * (p.N / BN);
-    const int nblk = total < g_ncu ? total : g_ncu;
+    // g_gemm_pers_static == 2: one workgroup per tile (the dispatcher places them as CUs free up, nothing persists): this kernel's K loop and
+    // register epilogue without the tile walk (A/B runs)
+    const int nblk = g_gemm_pers_static == 2 ? total : (total < g_ncu ? total : g_ncu);
     const int dynamic = g_gemm_pers_static ? 0 : 1;
     g_opt = g_gemm_pers_opt;
     switch (epi) {

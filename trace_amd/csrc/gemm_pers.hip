@@ -231,7 +231,7 @@ __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp
 // frees, requests ALL 16 residual pieces of the lane before the first store: on this ISA loads and stores share one in-order counter, and
 // a residual load issued behind a store cannot be waited for without waiting for that store's acknowledgement as well.
 __device__ __forceinline__ void residual_pack(f32x4_t (&acc)[TM][TN], uint2 (&bp)[TN], u32x4 (&out)[TM][2], u32x4 (&rr)[TM][2],
-                                              __amdgpu_buffer_rsrc_t rrs, int roff, int rstep) {
+                                              __amdgpu_buffer_rsrc_t rrs, int roff, int rstep, bool hi8) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -242,13 +242,29 @@ __device__ __forceinline__ void residual_pack(f32x4_t (&acc)[TM][TN], uint2 (&bp
             pk[j][0] = pack2bf(acc[i][j][0] + bflo(bp[j].x), acc[i][j][1] + bfhi(bp[j].x));
             pk[j][1] = pack2bf(acc[i][j][2] + bflo(bp[j].y), acc[i][j][3] + bfhi(bp[j].y));
         }
+        u32x4 P[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             swap16(pk[2 * h][0], pk[2 * h + 1][0]);
             swap16(pk[2 * h][1], pk[2 * h + 1][1]);
-            out[i][h] = u32x4{pk[2 * h][0], pk[2 * h][1], pk[2 * h + 1][0], pk[2 * h + 1][1]};
-            rr[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + i * rstep + h * 64, 0, 0);
+            P[h] = u32x4{pk[2 * h][0], pk[2 * h][1], pk[2 * h + 1][0], pk[2 * h + 1][1]};
         }
+        // the full-line arrangement of epilogue_rows (out[i][0] = rows 0..7 of the m-tile, out[i][1] = rows 8..15): the residual is read the same way
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t snd = hi8 ? P[0][e] : P[1][e];
+            const uint32_t rcv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)snd, 0x128, 0xf, 0xf, false);
+            out[i][0][e] = hi8 ? rcv : P[0][e];
+            out[i][1][e] = hi8 ? P[1][e] : rcv;
+        }
+        asm volatile("" : "+v"(out[i][0]), "+v"(out[i][1]));       // the selects happen here (left lazy, P and the received pieces stay live: 96 registers for 64)
+    }
+    // all 16 residual pieces of the lane, before the first store (and only now: beside 128 accumulators nothing fits — hence the fence)
+    PERS_FENCE();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        rr[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + i * rstep, 0, 0);
+        rr[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + i * rstep + (rstep >> 1), 0, 0);
     }
 }
 __device__ __forceinline__ void residual_store(u32x4 (&out)[TM][2], u32x4 (&rr)[TM][2], __amdgpu_buffer_rsrc_t crs, int coff, int cstep) {
@@ -260,7 +276,7 @@ __device__ __forceinline__ void residual_store(u32x4 (&out)[TM][2], u32x4 (&rr)[
             const u32x4 q = rr[i][h];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = pack2bf(bflo(v[e]) + bflo(q[e]), bfhi(v[e]) + bfhi(q[e]));
-            __builtin_amdgcn_raw_buffer_store_b128(v, crs, coff + i * cstep + h * 64, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(v, crs, coff + i * cstep + h * (cstep >> 1), 0, 2);
         }
 }
 
@@ -418,19 +434,19 @@ __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, i
         const int pcol = ((g_e & 1) << 4) | ((g_e >> 1) << 3);      // first of the lane's 8 consecutive columns within a 32-column group
         const int mbase = m0 + wm * (BM / WM) + (lane_e & 15);
         const int cbase = (GLU ? n0 / 2 + wn * (BN / WN / 2) : n0 + wn * (BN / WN)) + pcol;
-        const int coff = (mbase * p.ldc + cbase) * 2, roff = (EPI == EPI_RESIDUAL) ? (mbase * p.ldr + cbase) * 2 : 0;     // bytes
+        // full-line accesses (not SwiGLU: its 32 output columns per wave are one 64-byte piece): lanes r >= 8 handle row r - 8 / r, columns 32..63
+        const bool hi8 = (lane_e & 8) != 0;
+        const int coff = (mbase * p.ldc + cbase) * 2 + (!GLU && hi8 ? 64 - 16 * p.ldc : 0);                                   // bytes
         if constexpr (EPI == EPI_RESIDUAL) {
+            const int roff = (mbase * p.ldr + cbase) * 2 + (hi8 ? 64 - 16 * p.ldr : 0);
             u32x4 out[TM][2], rr[TM][2];
-            residual_pack(acc, bp, out, rr, rrs, roff, 32 * p.ldr);
+            residual_pack(acc, bp, out, rr, rrs, roff, 32 * p.ldr, hi8);
             if (has_next) PERS_FRAGS(q);
             residual_store(out, rr, crs, coff, 32 * p.ldc);
         } else {
-            // full-line stores (not SwiGLU: its 32 output columns per wave are one 64-byte piece): lanes r >= 8 write row r - 8 / r, columns 32..63
-            const bool hi8 = (lane_e & 8) != 0;
-            const int coff2 = GLU ? coff : coff + (hi8 ? 64 - 16 * p.ldc : 0);
-            epilogue_rows<EPI, 0, TM / 2>(acc, bp, crs, coff2, 32 * p.ldc, hi8);
+            epilogue_rows<EPI, 0, TM / 2>(acc, bp, crs, coff, 32 * p.ldc, hi8);
             if (has_next) PERS_FRAGS(q);                            // 24 registers the first half of the epilogue has freed
-            epilogue_rows<EPI, TM / 2, TM / 2>(acc, bp, crs, coff2, 32 * p.ldc, hi8);
+            epilogue_rows<EPI, TM / 2, TM / 2>(acc, bp, crs, coff, 32 * p.ldc, hi8);
         }
         if (!has_next) break;
         li = li_next;

@@ -22,6 +22,7 @@ shapes = [("vit fc1 gelu", 170 * 577, 4096, 1024, E.EPI_QUICKGELU, True), ("vit 
           ("prefill qkv pair", 3934, 6144, 4096, E.EPI_NONE, False), ("prefill o res", 3934, 4096, 4096, E.EPI_RESIDUAL, False),
           ("prefill gateup pair", 3934, 28672, 4096, E.EPI_SWIGLU, False), ("prefill down res", 3934, 4096, 14336, E.EPI_RESIDUAL, False),
           ("prefill qkv one", 1967, 6144, 4096, E.EPI_NONE, False), ("prefill gateup one", 1967, 28672, 4096, E.EPI_SWIGLU, False),
+          ("vit out none", 170 * 577, 1024, 1024, E.EPI_NONE, True), ("vit fc2 none", 170 * 577, 1024, 4096, E.EPI_NONE, True),
           ("down shape none", 3934, 4096, 14336, E.EPI_NONE, False), ("o shape none", 3934, 4096, 4096, E.EPI_NONE, False),
           ("c5 qkv pair", 7668, 6144, 4096, E.EPI_NONE, False), ("c5 gateup pair", 7668, 28672, 4096, E.EPI_SWIGLU, False)]
 only = [a for a in sys.argv[1:] if not a.isdigit()]

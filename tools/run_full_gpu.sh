@@ -15,13 +15,13 @@ python bench.py --config c5 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c5
 python bench.py --config c5 --no-fp8 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c5_bf16.json 2>> $O/bench_c5.err; echo "bench c5 bf16 rc=$?"
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/$O/prof_bench.log 2>&1; echo "prof rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_dec -- python $R/tools/decode_profile.py --steps 32 --eager > $R/$O/prof_dec.log 2>&1; echo "prof dec rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_vitstream -- python $R/tools/vit_stream_profile.py > $R/$O/prof_vitstream.log 2>&1; echo "prof vit stream rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_c5 -- python $R/bench.py --config c5 --steps 1 --warmup 1 --no-cpu-baseline > $R/$O/prof_c5.log 2>&1; echo "prof c5 rc=$?"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_fetch -- python $R/tools/pmc_kernels.py gemm gemv > $R/$O/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_write -- python $R/tools/pmc_kernels.py gemm gemv > $R/$O/pmc_write.log 2>&1; echo "pmc write rc=$?"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $R/$O/pmc_sq -- python $R/tools/pmc_kernels.py > $R/$O/pmc_sq.log 2>&1; echo "pmc sq rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/$O/prof_bench.log 2>&1; echo "prof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_dec -- python $R/tools/decode_profile.py --steps 32 --eager > $R/$O/prof_dec.log 2>&1; echo "prof dec rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_vitstream -- python $R/tools/vit_stream_profile.py > $R/$O/prof_vitstream.log 2>&1; echo "prof vit stream rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_c5 -- python $R/bench.py --config c5 --steps 1 --warmup 1 --no-cpu-baseline > $R/$O/prof_c5.log 2>&1; echo "prof c5 rc=$?"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_fetch -- python $R/tools/pmc_kernels.py gemm gemv > $R/$O/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_write -- python $R/tools/pmc_kernels.py gemm gemv > $R/$O/pmc_write.log 2>&1; echo "pmc write rc=$?"
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $R/$O/pmc_sq -- python $R/tools/pmc_kernels.py > $R/$O/pmc_sq.log 2>&1; echo "pmc sq rc=$?"
 cd $R
 python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/traffic.json; head -5 $O/traffic.json
 python tools/pmc_summary.py $O/pmc_sq > $O/pmc_sq.txt

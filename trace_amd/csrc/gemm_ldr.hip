@@ -84,8 +84,27 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
         };
         issue(0);
         for (int kt = 0; kt < nk; ++kt) {
-            __syncthreads();                       // own pieces of tile kt landed (vmcnt(0)); everyone is done with tile kt-1
+            // own pieces of tile kt landed; everyone is done with tile kt-1.  Behind the LAST K-tile's pieces ride the residual touches (below):
+            // the counter is in order, so waiting down to 4 outstanding means exactly "all pieces, not the touches"
+            const bool touch = EPI == EPI_RESIDUAL && !FP8 && nk > 2 && !(p.opt & 1);
+            // (touches one K-tile earlier, waited for with everything else: 2-6 % SLOWER than none — tools/gemm_pers_ab.py, r02_gemm_pers_ab.txt)
+            if (touch && kt == nk - 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             if (kt + 1 < nk) issue(kt + 1);
+            if (touch && kt + 2 == nk) {
+                // Residual touches: one byte of each of the tile's 1024 residual lines (256 rows x 512 bytes), four per loader lane, so that the
+                // MFMA waves' residual loads — requested only after the K loop, when the accumulators have left their registers — come from L2
+                // instead of waiting ~2 us for HBM with nothing left to overlap
+                const int L = lw * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = L + q * 256, row = idx >> 2, seg = idx & 3;
+                    const bf16_t* ra = p.R + (size_t)min(m0 + row, p.M - 1) * p.ldr + n0 + seg * 64;
+                    unsigned dummy;
+                    asm volatile("global_load_ubyte %0, %1, off" : "=v"(dummy) : "v"(ra) : "memory");
+                }
+            }
         }
         __syncthreads();                           // the MFMA waves' epilogue barriers (one more on the fp8 path: the scale rows)
         if (FP8) __syncthreads();
@@ -247,7 +266,10 @@ void launch_one(const GemmArgs& p, int nblk, size_t lds, hipStream_t s) {
 
 }  // namespace
 
-int launch_gemm_ldr(const GemmArgs& p, int epi, hipStream_t s) {
+int g_gemm_ldr_opt = 0;            // A/B: bit 0 = no residual touches (trace_op_set_gemm_variant(400 + opt))
+int launch_gemm_ldr(const GemmArgs& p0, int epi, hipStream_t s) {
+    GemmArgs p = p0;
+    p.opt = g_gemm_ldr_opt;
     if (p.M < 1 || p.N % BN || p.K % BK) return TRACE_ERR_ARG;
     constexpr size_t LOOPB = 2 * STAGE, OBYTES = (size_t)BM * (BN * 2 + 16) + (BM + BN) * 4;     // + the fp8 scale rows
     const size_t lds = LOOPB > OBYTES ? LOOPB : OBYTES;

@@ -18,6 +18,7 @@ struct GemmArgs {
     unsigned long long* trace;      // profiling only (tools/gemm_trace.py): 8 x u64 per workgroup, or null
     // fp8 = 1: A and W point at e4m3 BYTES (lda / ldw in bytes, K % 128 == 0); C = (A8 . W8^T) * sa[m] * sw[n] (+ epilogue)
     int fp8; const float* sa; const float* sw;
+    int opt;                        // A/B switches of a kernel (0 = shipped behaviour)
 };
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s);
 int launch_gemm_ldr(const GemmArgs& p, int epi, hipStream_t s);    // gemm_ldr.hip: 256x256 tiles, 8 MFMA + 4 loader waves (N % 256 == 0)

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + ko),
                                                  (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
         };
+        unsigned tdst[4] = {0u, 0u, 0u, 0u};       // destination registers of the touch loads: kept live until the loads have returned
         issue(0);
         for (int kt = 0; kt < nk; ++kt) {
             // own pieces of tile kt landed; everyone is done with tile kt-1.  Behind the LAST K-tile's pieces ride the residual touches (below):
@@ -101,14 +102,16 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
                 for (int q = 0; q < 4; ++q) {
                     const int idx = L + q * 256, row = idx >> 2, seg = idx & 3;
                     const bf16_t* ra = p.R + (size_t)min(m0 + row, p.M - 1) * p.ldr + n0 + seg * 64;
-                    unsigned dummy;
-                    asm volatile("global_load_ubyte %0, %1, off" : "=v"(dummy) : "v"(ra) : "memory");
+                    asm volatile("global_load_ubyte %0, %1, off" : "=v"(tdst[q]) : "v"(ra) : "memory");
                 }
             }
         }
         __syncthreads();                           // the MFMA waves' epilogue barriers (one more on the fp8 path: the scale rows)
         if (FP8) __syncthreads();
         __syncthreads();
+        // an asm load's destination is written when the load RETURNS: nothing else may be allocated to it before that
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" :: "v"(tdst[0]), "v"(tdst[1]), "v"(tdst[2]), "v"(tdst[3]));
         return;
     }
 

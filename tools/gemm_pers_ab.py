@@ -16,7 +16,7 @@ def timed(fn, n=5):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 opts = [int(a) for a in sys.argv[1:] if a.isdigit()] or [0]
-variants = [("ldr", 4, 0), ("ldr/notouch", 4, -1)] + [("pers%s" % ("" if o == 0 else "/opt%d" % o), 5, o) for o in opts] + [("static", 6, 0), ("1tile/wg", 7, 0)]
+variants = [("ldr", 4, 0), ("ldr/noA", 4, -2), ("ldr/none", 4, -3)] + [("pers%s" % ("" if o == 0 else "/opt%d" % o), 5, o) for o in opts] + [("static", 6, 0), ("1tile/wg", 7, 0)]
 shapes = [("vit fc1 gelu", 170 * 577, 4096, 1024, E.EPI_QUICKGELU, True), ("vit qkv", 170 * 577, 3072, 1024, E.EPI_NONE, True),
           ("vit fc2 res", 170 * 577, 1024, 4096, E.EPI_RESIDUAL, True), ("vit out res", 170 * 577, 1024, 1024, E.EPI_RESIDUAL, True),
           ("prefill qkv pair", 3934, 6144, 4096, E.EPI_NONE, False), ("prefill o res", 3934, 4096, 4096, E.EPI_RESIDUAL, False),

@@ -1130,7 +1130,7 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
     if (variant == 120 || variant == 121) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
-    if (variant >= 300 && variant < 316) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
+    if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
     if (variant >= 400 && variant < 404) { g_gemm_ldr_opt = variant - 400; return TRACE_OK; }   // microbench: attention phase cut-offs
     if (variant < 0 || variant > 7) return fail(TRACE_ERR_ARG, "variant must be 0..7");
     g_gemm_variant = variant;

@@ -342,8 +342,10 @@ int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
         }
         // 256^2 tiles run on the loader-wave kernels (same results bit for bit as this file's kernel, which variant 3 forces for A/B runs):
         // gemm_ldr.hip (+20-24 % on the K = 1024 ViT shapes) and, where there is no residual to fetch, its persistent form gemm_pers.hip
-        // (tools/gemm_pers_ab.py, interleaved medians vs gemm_ldr over several boxes: fc1 + QuickGELU -5 .. -8 %, prefill gate|up -3 .. -6 %;
-        // with a residual the tile ends in an HBM burst either way and the one-workgroup-per-tile kernel is 2-7 % ahead on the ViT shapes)
+        // (tools/gemm_pers_ab.py, interleaved medians vs gemm_ldr over several boxes, both with their L2 touches: fc1 + QuickGELU -8 .. -11 %,
+        // ViT qkv -4 .. -6 %, prefill gate|up -3 .. -7 %, prefill qkv 0 .. -5 %).  With a residual the one-workgroup-per-tile kernel stays: its
+        // LDS-staged epilogue reads the touched residual lines as full rows; the persistent kernel's two-pass register epilogue measured
+        // -5 .. +14 % against it depending on the box.
         const bool pers_ok = p.N % 256 == 0 && !p.fp8 && p.K >= 128 && (long)p.M * p.ldc < (1L << 30) &&
                              (epi != EPI_RESIDUAL || (long)p.M * p.ldr < (1L << 30));
         if ((g_gemm_variant >= 5 && g_gemm_variant <= 7) && pers_ok) {
@@ -351,10 +353,7 @@ int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
             return launch_gemm_pers(p, epi, s);
         }
         if (p.N % 256 == 0 && (g_gemm_variant == 4 || (g_gemm_variant == 0 && v == 3))) {
-            // (plain epilogue: only where a workgroup walks several tiles — ViT qkv, 18 per workgroup: -5.3 / -2.7 / +0.5 % on three boxes;
-            //  the prefill qkv shapes, 1-2 tiles per workgroup, measured -4 .. +7 % and stay on the one-tile-per-workgroup kernel)
-            const long tiles = (long)((p.M + 255) / 256) * (p.N / 256);
-            if (g_gemm_variant == 0 && pers_ok && (epi == EPI_QUICKGELU || epi == EPI_SWIGLU || (epi == EPI_NONE && tiles >= 1024))) {
+            if (g_gemm_variant == 0 && pers_ok && epi != EPI_RESIDUAL) {
                 g_gemm_pers_static = 0;
                 return launch_gemm_pers(p, epi, s);
             }

@@ -23,6 +23,7 @@ constexpr int NLW = 4;                            // loader waves
 constexpr int NTHR = NMT + NLW * 64;              // 768
 constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
 constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+constexpr int TOUCH_OFF = BM * (BN * 2 + 16) + (BM + BN) * 4;      // behind the staged output tile and the fp8 scale rows: 4 x 256 bytes of touch scratch
 
 __device__ __forceinline__ int swz(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
 
@@ -82,36 +83,55 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + ko),
                                                  (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
         };
-        unsigned tdst[4] = {0u, 0u, 0u, 0u};       // destination registers of the touch loads: kept live until the loads have returned
+        // L2 touches of the A rows, LEAD K-tiles ahead of their LDS-DMA pieces (gemm_pers.hip's loader has the full story: with two LDS stages one
+        // K-tile is in flight, so a K-tile costs the load's latency unless the line is already in L2).  One instruction per workgroup and K-tile:
+        // the 4 workgroups that share a row panel (column tiles tn, tn + 1, ..) touch 64 rows of it each.  p.opt bit 1 switches them off (A/B).
+        constexpr int LEAD = 3;
+        const bool atouch = lw == 0 && !(p.opt & 2);
+        const char* tsrc = reinterpret_cast<const char*>(p.A) + (size_t)min(m0 + (tn & 3) * 64 + lane, p.M - 1) * p.lda * ESZ;
+        // a touch = one dword per lane by LDS-DMA into the wave's 256-byte scratch behind the staged tile: an L2 fill with no register destination
+        // (a dummy register written by an asm load is dead to the compiler at once — and overwritten for real microseconds later: gemm_pers.hip)
+        char* tscr = smem + TOUCH_OFF + lw * 256;
+#define LDR_TOUCH_AT(PTR)                                                                                                          \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(PTR), (__attribute__((address_space(3))) void*)tscr, 4, 0, 0)
+#define LDR_TOUCH(KT, D) LDR_TOUCH_AT(tsrc + (KT) * 128)
+        const bool rtouch = EPI == EPI_RESIDUAL && !FP8 && nk > 2 && !(p.opt & 1);
+        int pend = 0;                              // touch loads issued behind the latest batch of pieces: the in-order counter is waited down to them
         issue(0);
+        if (atouch) {
+            if (1 < nk) { LDR_TOUCH(1, 1); ++pend; }
+            if (2 < nk) { LDR_TOUCH(2, 2); ++pend; }
+        }
         for (int kt = 0; kt < nk; ++kt) {
-            // own pieces of tile kt landed; everyone is done with tile kt-1.  Behind the LAST K-tile's pieces ride the residual touches (below):
-            // the counter is in order, so waiting down to 4 outstanding means exactly "all pieces, not the touches"
-            const bool touch = EPI == EPI_RESIDUAL && !FP8 && nk > 2 && !(p.opt & 1);
-            // (touches one K-tile earlier, waited for with everything else: 2-6 % SLOWER than none — tools/gemm_pers_ab.py, r02_gemm_pers_ab.txt)
-            if (touch && kt == nk - 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // own pieces of tile kt landed (not the touches behind them); everyone is done with tile kt-1
+            if (pend == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (pend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (pend == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            pend = 0;
             if (kt + 1 < nk) issue(kt + 1);
-            if (touch && kt + 2 == nk) {
-                // Residual touches: one byte of each of the tile's 1024 residual lines (256 rows x 512 bytes), four per loader lane, so that the
-                // MFMA waves' residual loads — requested only after the K loop, when the accumulators have left their registers — come from L2
-                // instead of waiting ~2 us for HBM with nothing left to overlap
+            if (atouch && kt + LEAD < nk) { LDR_TOUCH(kt + LEAD, 0); pend = 1; }
+            if (rtouch && kt + 2 == nk) {
+                // Residual touches: one byte of each of the tile's 1024 residual lines (256 rows x 512 bytes), four per loader lane, behind the
+                // LAST K-tile's pieces, so that the MFMA waves' residual loads — requested only after the K loop, when the accumulators have left
+                // their registers — come from L2 instead of waiting ~2 us for HBM with nothing left to overlap.  (One K-tile earlier, waited for
+                // with everything else: 2-6 % SLOWER than none — tools/gemm_pers_ab.py, r02_gemm_pers_ab.txt.)
                 const int L = lw * 64 + lane;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int idx = L + q * 256, row = idx >> 2, seg = idx & 3;
                     const bf16_t* ra = p.R + (size_t)min(m0 + row, p.M - 1) * p.ldr + n0 + seg * 64;
-                    asm volatile("global_load_ubyte %0, %1, off" : "=v"(tdst[q]) : "v"(ra) : "memory");
+                    LDR_TOUCH_AT(ra);
                 }
+                pend = 4;                          // (kt + LEAD >= nk here: no A touch in this iteration)
             }
         }
+#undef LDR_TOUCH
+#undef LDR_TOUCH_AT
         __syncthreads();                           // the MFMA waves' epilogue barriers (one more on the fp8 path: the scale rows)
         if (FP8) __syncthreads();
         __syncthreads();
-        // an asm load's destination is written when the load RETURNS: nothing else may be allocated to it before that
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("" :: "v"(tdst[0]), "v"(tdst[1]), "v"(tdst[2]), "v"(tdst[3]));
         return;
     }
 
@@ -274,7 +294,7 @@ int launch_gemm_ldr(const GemmArgs& p0, int epi, hipStream_t s) {
     GemmArgs p = p0;
     p.opt = g_gemm_ldr_opt;
     if (p.M < 1 || p.N % BN || p.K % BK) return TRACE_ERR_ARG;
-    constexpr size_t LOOPB = 2 * STAGE, OBYTES = (size_t)BM * (BN * 2 + 16) + (BM + BN) * 4;     // + the fp8 scale rows
+    constexpr size_t LOOPB = 2 * STAGE, OBYTES = (size_t)TOUCH_OFF + 4 * 256;      // staged tile + the fp8 scale rows + the touch scratch
     const size_t lds = LOOPB > OBYTES ? LOOPB : OBYTES;
     const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
     if (p.fp8) {

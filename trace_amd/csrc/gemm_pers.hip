@@ -31,9 +31,10 @@ constexpr int NLW = 4;                            // loader waves
 constexpr int NTHR = NMT + NLW * 64;              // 768
 constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
 constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
-constexpr int CTL_OFF = 2 * STAGE;                // int s_next[2] | 2 x 512-byte bias rows
+constexpr int CTL_OFF = 2 * STAGE;                // int s_next[2] | 2 x 512-byte bias rows | touch scratch
 constexpr int BIAS_OFF = CTL_OFF + 64;
-constexpr int LDS_BYTES = BIAS_OFF + 2 * 512;
+constexpr int TOUCH_OFF = BIAS_OFF + 2 * 512;    // 4 x 256 bytes: where the loader waves' L2 touches land (never read)
+constexpr int LDS_BYTES = TOUCH_OFF + 4 * 256;
 constexpr int CTR_STRIDE = 32;                    // ints between the per-XCD ticket counters (one 128-byte line each)
 
 __device__ __forceinline__ int swz(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
@@ -298,8 +299,9 @@ __device__ __forceinline__ Sched make_sched(const GemmArgs& p) {
 
 // ---------------- loader wave lw: pieces of 8 tile rows x 128 bytes; lw 0,1 -> A rows 0..127 / 128..255, lw 2,3 -> W ----------------
 // One continuous stream of K-tiles over all the tiles of the workgroup; also publishes the next tile's index (ticket) and the tile's bias row.
-template <bool GLU>
+template <int EPI, int OPT>
 __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, char* smem, int* ctr, int dynamic, int lw, int tid, int lane) {
+    constexpr bool GLU = (EPI == EPI_SWIGLU);
     int* s_next = reinterpret_cast<int*>(smem + CTL_OFF);
     const int ntm = sc.ntm, ntn = sc.ntn, nk = sc.nk, xcd = sc.xcd, cnt = sc.cnt, base = sc.base, nwg = sc.nwg;
     const bool isA = lw < 2;
@@ -308,11 +310,36 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
     const char* src[16];
     int li = sc.slot, n = 0, q = 0, ticket = 0;
     uint2 bias2 = make_uint2(0u, 0u);
+    // L2 touches (OPT bit 3 switches them off for A/B runs).  With two LDS stages only ONE K-tile is ever in flight, so when an operand streams
+    // from HBM (ViT fc2: an 803 MB A) a K-tile costs the load's latency, not its MFMA time — and even from the Infinity Cache the pieces land
+    // late often enough to show.  One byte of every A line of K-tile kt + LEAD, requested LEAD - 1 hand-overs before its LDS-DMA pieces, turns
+    // those pieces into L2 hits.  ONE instruction per workgroup and K-tile: the row panel is shared by the 4 workgroups of its XCD that hold
+    // column tiles tn, tn+1, .. (they run in step), so each touches the 64 rows (tn & 3) * 64 .. of it.  The touch rides BEHIND the pieces
+    // of K-tile kt + 1: the in-order counter is waited down to that 1 load, not to 0.  Measured (tools/gemm_pers_ab.py, r02_gemm_pers_ab.txt,
+    // vs the kernel without them): ViT fc2 shape 767 -> 571 us, out-proj shape 164 -> 158, fc1 693 -> 679, prefill qkv pair 176 -> 162, long-K
+    // 325 -> 309; touching every line from every loader wave (A and W, 8 instructions per K-tile) loses on the cached shapes: the CU's
+    // address path is the scarce thing; W rows split over their 8 sharers on top: mixed (-5 % on one shape, +1 % on others), left out.
+    constexpr bool TOUCH = (OPT & 8) == 0;
+    constexpr int LEAD = 3;
+    const bool toucher = TOUCH && lw == 0;
+    const char* tsrc = nullptr;                      // row (tn & 3) * 64 + lane of the tile's A panel
+    // EPI_RESIDUAL: every loader wave also touches its quarter of the tile's 1024 residual lines, behind the LAST K-tile's pieces (gemm_ldr.hip)
+    constexpr bool RTOUCH = TOUCH && EPI == EPI_RESIDUAL;
+    int rm0 = 0, rn0 = 0;
+    int pend = 0;                                    // touch instructions issued behind the latest batch of pieces
+// A touch = one dword per lane by LDS-DMA into the wave's 256-byte scratch: an L2 fill with NO register destination.  (The first version used
+// global_load_ubyte into a dummy register from inline asm: the compiler considers such an output dead at once and hands the register to the
+// next address computation, and the load — which returns microseconds later — then overwrote a live LDS-DMA source pointer: memory faults.)
+#define PERS_TOUCH_AT(PTR)                                                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(PTR),                                             \
+                                     (__attribute__((address_space(3))) void*)(smem + TOUCH_OFF + lw * 256), 4, 0, 0)
+#define PERS_TOUCH(KT, D) PERS_TOUCH_AT(tsrc + (KT) * 128)
 #define PERS_SETUP()                                                                                                                   \
     {                                                                                                                                  \
         int tm_, tn_;                                                                                                                  \
         tile_coords(base + li, ntm, ntn, tm_, tn_);                                                                                    \
         const int m0_ = tm_ * BM, n0_ = tn_ * BN;                                                                                      \
+        rm0 = m0_; rn0 = n0_;                                                                                                          \
         _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                                               \
             const int row = half + j * 8 + (lane >> 3);                                                                                \
             const int kc = (lane & 7) ^ ((row >> 1) & 7);                                                                              \
@@ -320,6 +347,8 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
                          : reinterpret_cast<const char*>(p.W) + ((size_t)(n0_ + row) * p.ldw + kc * 8) * 2;                            \
         }                                                                                                                              \
         if (!GLU && lw == 3 && p.bias) bias2 = *reinterpret_cast<const uint2*>(p.bias + n0_ + lane * 4);  /* else stays zero */       \
+        if (toucher)                                                                                                                   \
+            tsrc = reinterpret_cast<const char*>(p.A) + (size_t)min(m0_ + (tn_ & 3) * 64 + lane, p.M - 1) * p.lda * 2;                 \
     }
 #define PERS_ISSUE(STG, KO)                                                                                                            \
     {                                                                                                                                  \
@@ -328,11 +357,25 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (KO)),                           \
                                              (__attribute__((address_space(3))) void*)(dst_ + j * 1024), 16, 0, 0);                    \
     }
+// the wait for the latest batch of pieces: everything but the `pend` touches issued behind it
+#define PERS_WAIT_PIECES()                                                                         \
+    if (pend == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                \
+    else if (pend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                           \
+    else if (pend == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                           \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+// a tile's K-tiles 1 and 2 are touched with its first pieces (K-tile 0 has no lead to gain), K-tile kt + LEAD with the pieces of kt + 1
+#define PERS_TOUCH_HEAD()                                                                          \
+    pend = 0;                                                                                      \
+    if (toucher) {                                                                                 \
+        if (1 < nk) { PERS_TOUCH(1, 1); ++pend; }                                                  \
+        if (2 < nk) { PERS_TOUCH(2, 2); ++pend; }                                                  \
+    }
     PERS_SETUP();
     PERS_ISSUE(0, 0);
+    PERS_TOUCH_HEAD();
     while (true) {
         for (int kt = 0; kt < nk; ++kt, ++q) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PERS_WAIT_PIECES();
             if (kt == 0 && !GLU && lw == 3)                         // this tile's bias row (zeros without a bias), read by the MFMA waves after the K loop
                 *reinterpret_cast<uint2*>(smem + BIAS_OFF + (n & 1) * 512 + lane * 8) = bias2;
             if (kt == 1 && tid == NMT) {                            // the tile after this one: everyone reads it after this tile's last hand-over
@@ -343,21 +386,39 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
             __builtin_amdgcn_s_barrier();                           // K-tile q handed over; the stage of q-1 is free
             // the ticket rides with K-tile 1's pieces: from the second tile on that hand-over is an epilogue away, so its latency is free
             if (kt == 0 && dynamic && tid == NMT) ticket = atomicAdd(ctr + xcd * CTR_STRIDE, 1);
+            pend = 0;
             if (kt + 1 < nk) {
                 PERS_ISSUE((q + 1) & 1, (kt + 1) * 128);
+                if (toucher && kt + LEAD < nk) { PERS_TOUCH(kt + LEAD, 0); pend = 1; }
+                if (RTOUCH && kt + 2 == nk && nk > 2) {             // (kt + LEAD >= nk: no A touch in this iteration)
+                    const int L = lw * 64 + lane;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int idx = L + t * 256, row = idx >> 2, seg = idx & 3;
+                        const bf16_t* ra = p.R + (size_t)min(rm0 + row, p.M - 1) * p.ldr + rn0 + seg * 64;
+                        PERS_TOUCH_AT(ra);
+                    }
+                    pend = 4;
+                }
             } else {
                 li = __builtin_amdgcn_readfirstlane(s_next[(n + 1) & 1]);
                 if (li < cnt) {
                     PERS_SETUP();
                     PERS_ISSUE((q + 1) & 1, 0);
+                    PERS_TOUCH_HEAD();
                 }
             }
         }
         if (li >= cnt) break;
         ++n;
     }
+#undef PERS_WAIT_PIECES
+#undef PERS_TOUCH_HEAD
+#undef PERS_TOUCH
+#undef PERS_TOUCH_AT
 #undef PERS_SETUP
 #undef PERS_ISSUE
+
 }
 
 template <int EPI, int OPT>
@@ -369,7 +430,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, i
     const Sched sc = make_sched(p);
     const int ntn = sc.ntn, ntm = sc.ntm, nk = sc.nk, slot = sc.slot, cnt = sc.cnt, base = sc.base;
     if (wid >= WM * WN) {
-        loader_role<GLU>(p, sc, smem, ctr, dynamic, wid - WM * WN, tid, lane);
+        loader_role<EPI, OPT>(p, sc, smem, ctr, dynamic, wid - WM * WN, tid, lane);
         return;
     }
 
@@ -493,6 +554,7 @@ void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
     switch (g_opt) {
         case 2: launch_opt<EPI, 2>(p, nblk, dynamic, ctr, s); break;
         case 4: launch_opt<EPI, 4>(p, nblk, dynamic, ctr, s); break;
+        case 8: launch_opt<EPI, 8>(p, nblk, dynamic, ctr, s); break;
         default: launch_opt<EPI, 0>(p, nblk, dynamic, ctr, s); break;
     }
 }

@@ -14,9 +14,11 @@
 //     and both LDS stages full;
 //   * the epilogue never leaves the wave: bias (from a 512-byte LDS row the loaders fill) / QuickGELU / SwiGLU in fp32 registers,
 //     packed to bf16, then ONE v_permlane16_swap per register pair turns "4 columns of one row per lane, 16 columns apart per
-//     fragment" into 8 consecutive columns per lane -> 16-byte non-temporal stores, 64 contiguous bytes per row per instruction,
-//     the two halves of a 128-byte line back to back.  No LDS staging, no barrier, no waiting for the other waves: the stores of
-//     tile n drain under the K loop of tile n+1 (raw s_barrier: it does not wait for the store acknowledgements).
+//     fragment" into 8 consecutive columns per lane and a DPP row_ror:8 exchange between rows r and r + 8 makes every 16-byte
+//     non-temporal store instruction 8 rows x one full 128-byte line.  No LDS staging, no barrier, no waiting for the other waves:
+//     the stores of tile n drain under the K loop of tile n+1 (raw s_barrier: it does not wait for the store acknowledgements);
+//   * one loader wave also touches the A lines of K-tile kt + 3 into L2 (loader_role): with one K-tile in flight, load latency
+//     would otherwise be the K-tile time on operands that stream from HBM.
 // Same K order, same fp32 -> bf16 roundings as gemm_ldr.hip / gemm.hip: results are bit-identical (tests/test_gpu_kernels.py).
 #include <mutex>
 #include <unordered_map>

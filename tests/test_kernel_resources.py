@@ -80,3 +80,14 @@ def test_attention_kernels_keep_their_occupancy(res):
 def test_decode_gemv_does_not_spill(res):
     for k, v in _pick(res["decode"], "skinny_lds_kernel").items():
         assert v["ScratchSize"] == 0, (k, v)
+
+
+def test_no_asm_load_into_a_dummy_register():
+    """An inline-asm load whose output is never read is dead to the compiler the moment it is issued: the register goes to the next address
+    computation and the load, returning microseconds later, overwrites it (the first L2-touch implementation faulted that way under load and
+    in no unit test).  Touches are LDS-DMA dwords into a scratch; no kernel source may bring the pattern back."""
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            src = open(os.path.join(CSRC, f)).read()
+            for m in re.finditer(r'asm\s+volatile\s*\(\s*"(global_load|buffer_load|flat_load|scratch_load)[^"]*"', src):
+                assert "lds" in m.group(0), (f, m.group(0))

@@ -1,5 +1,5 @@
 """A/B of decode-step variants on the 7B engine (random embeddings prefilled, no ViT): the attention's fused prologue (RoPE + cache append inside
-attn_decode_kernel, default) against the same work as a kernel of its own (trace_op_set_gemm_variant(121)).  Interleaved rounds, median.
+attn_decode_kernel: 122) against the same work as a kernel of its own (121; the engine's default from batch 32 up).  Interleaved rounds, median.
 python tools/decode_ab.py [--batch B] [--ctx L]"""
 import argparse, os, sys, time, statistics
 import torch
@@ -22,7 +22,7 @@ torch.cuda.synchronize()
 slots = list(range(a.batch))
 lg = {}
 for v in (0, 1):
-    ops.set_gemm_variant(120 + v)
+    ops.set_gemm_variant(122 - v)                      # 122 = fused prologue, 121 = separate kernel
     steps = [eng.decode_begin(slots, [1] * a.batch, 256, eos=-1, want_logits=True).clone()]
     for _ in range(3):
         steps.append(eng.decode_steps(1, use_graph=False, want_logits=True).clone())
@@ -31,7 +31,7 @@ print("logits of 4 steps identical:", torch.equal(lg[0], lg[1]), " max|d|", (lg[
 ts = {0: [], 1: []}
 for rnd in range(6):
     for v in (0, 1):
-        ops.set_gemm_variant(120 + v)
+        ops.set_gemm_variant(122 - v)
         eng.decode_begin(slots, [1] * a.batch, 256, eos=-1)        # every round restarts at the prefilled context
         eng.decode_steps(2, use_graph=False)
         torch.cuda.synchronize()

@@ -923,7 +923,9 @@ static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* l
 // B=32 1 -> 45 us; B=32 with 16 splits: 79 us)
 static int decode_nsplit(int B) { const int n = (40 + B / 2) / B; return n < 1 ? 1 : n > 16 ? 16 : n; }
 
-int g_decode_unfused = 0;   // A/B: RoPE + cache append as a kernel of its own before the decode attention (trace_op_set_gemm_variant(121 / 120))
+int g_decode_unfused = 0;   // RoPE + cache append as a kernel of its own before the decode attention: 0 = from batch 32 up (bit-identical to the fused
+                            // prologue, 1 % faster per 64-sequence step, one launch more — which batch 1 would feel), 1 = always, 2 = never
+                            // (trace_op_set_gemm_variant(120 + x), tools/decode_ab.py)
 // one decode step for the current batch: consumes dX (embedding of the last token), leaves the next one in dX
 static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
     const int H = c->H, I = c->I, HD = c->HD, QKV = c->QKV, B = c->B;
@@ -950,7 +952,7 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
         //  more than a row kernel — 65 us vs 52 + 6 us for the gate|up GEMV)
         if (f8) { GEMV8H(W.wqkv8_d, W.sqkv, QKV) }
         else LCHK(launch_skinny_gemm(c->dH, H, W.wqkv_d, H, nullptr, QKV, nullptr, 0, B, QKV, H, EPI_PARTIAL, 1, SKWS(c), s));
-        if (g_decode_unfused) {
+        if (g_decode_unfused == 1 || (g_decode_unfused == 0 && B >= 32)) {
             LCHK(launch_qkv_finish(c->sk_ws, ks_q, QKV, c->dQKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots,
                                    c->d_pos, B, c->NQ, c->NKV, c->rope_cos, c->rope_sin, s));
             LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots, c->d_pos, c->dO,
@@ -1128,7 +1130,7 @@ extern int g_gemm_ldr_opt;
 extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 100 && variant < 104) { g_attn_debug = variant - 100; return TRACE_OK; }
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
-    if (variant == 120 || variant == 121) { g_decode_unfused = variant - 120; return TRACE_OK; }
+    if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
     if (variant >= 400 && variant < 404) { g_gemm_ldr_opt = variant - 400; return TRACE_OK; }   // microbench: attention phase cut-offs

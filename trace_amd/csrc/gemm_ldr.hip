@@ -129,6 +129,7 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
         }
 #undef LDR_TOUCH
 #undef LDR_TOUCH_AT
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA (touch) of this wave in flight beyond this point (LDS is released with the workgroup)
         __syncthreads();                           // the MFMA waves' epilogue barriers (one more on the fp8 path: the scale rows)
         if (FP8) __syncthreads();
         __syncthreads();

@@ -361,10 +361,14 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
     }
 // the wait for the latest batch of pieces: everything but the `pend` touches issued behind it
 #define PERS_WAIT_PIECES()                                                                         \
-    if (pend == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                \
-    else if (pend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                           \
-    else if (pend == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                           \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    switch (pend) {                                                                                \
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;                            \
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;                            \
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;                            \
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;                            \
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;                            \
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;                           \
+    }
 // a tile's K-tiles 1 and 2 are touched with its first pieces (K-tile 0 has no lead to gain), K-tile kt + LEAD with the pieces of kt + 1
 #define PERS_TOUCH_HEAD()                                                                          \
     pend = 0;                                                                                      \
@@ -392,22 +396,26 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
             if (kt + 1 < nk) {
                 PERS_ISSUE((q + 1) & 1, (kt + 1) * 128);
                 if (toucher && kt + LEAD < nk) { PERS_TOUCH(kt + LEAD, 0); pend = 1; }
-                if (RTOUCH && kt + 2 == nk && nk > 2) {             // (kt + LEAD >= nk: no A touch in this iteration)
-                    const int L = lw * 64 + lane;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int idx = L + t * 256, row = idx >> 2, seg = idx & 3;
-                        const bf16_t* ra = p.R + (size_t)min(rm0 + row, p.M - 1) * p.ldr + rn0 + seg * 64;
-                        PERS_TOUCH_AT(ra);
-                    }
-                    pend = 4;
-                }
             } else {
                 li = __builtin_amdgcn_readfirstlane(s_next[(n + 1) & 1]);
+                const int crm0 = rm0, crn0 = rn0;                  // the tile whose last K-tile has just been handed over
                 if (li < cnt) {
                     PERS_SETUP();
                     PERS_ISSUE((q + 1) & 1, 0);
                     PERS_TOUCH_HEAD();
+                }
+                if (RTOUCH) {
+                    // residual touches of the tile just finished loading: the MFMA waves ask for R one K-tile of MFMAs + the first epilogue pass
+                    // from now.  (Issued a K-tile earlier they sat in front of the s_next read above, which the compiler — seeing LDS-DMA in
+                    // flight — guards with vmcnt(0): the next tile's first pieces then left ~3 us late.)
+                    const int L = lw * 64 + lane;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int idx = L + t * 256, row = idx >> 2, seg = idx & 3;
+                        const bf16_t* ra = p.R + (size_t)min(crm0 + row, p.M - 1) * p.ldr + crn0 + seg * 64;
+                        PERS_TOUCH_AT(ra);
+                    }
+                    pend += 4;
                 }
             }
         }
@@ -420,6 +428,7 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
 #undef PERS_TOUCH_AT
 #undef PERS_SETUP
 #undef PERS_ISSUE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA (touch) of this wave may still be in flight when the workgroup's LDS is released
 
 }
 

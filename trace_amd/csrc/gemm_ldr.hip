@@ -94,13 +94,13 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
         char* tscr = smem + TOUCH_OFF + lw * 256;
 #define LDR_TOUCH_AT(PTR)                                                                                                          \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(PTR), (__attribute__((address_space(3))) void*)tscr, 4, 0, 0)
-#define LDR_TOUCH(KT, D) LDR_TOUCH_AT(tsrc + (KT) * 128)
+#define LDR_TOUCH(KT) LDR_TOUCH_AT(tsrc + (KT) * 128)
         const bool rtouch = EPI == EPI_RESIDUAL && !FP8 && nk > 2 && !(p.opt & 1);
         int pend = 0;                              // touch loads issued behind the latest batch of pieces: the in-order counter is waited down to them
         issue(0);
         if (atouch) {
-            if (1 < nk) { LDR_TOUCH(1, 1); ++pend; }
-            if (2 < nk) { LDR_TOUCH(2, 2); ++pend; }
+            if (1 < nk) { LDR_TOUCH(1); ++pend; }
+            if (2 < nk) { LDR_TOUCH(2); ++pend; }
         }
         for (int kt = 0; kt < nk; ++kt) {
             // own pieces of tile kt landed (not the touches behind them); everyone is done with tile kt-1
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
             __builtin_amdgcn_s_barrier();
             pend = 0;
             if (kt + 1 < nk) issue(kt + 1);
-            if (atouch && kt + LEAD < nk) { LDR_TOUCH(kt + LEAD, 0); pend = 1; }
+            if (atouch && kt + LEAD < nk) { LDR_TOUCH(kt + LEAD); pend = 1; }
             if (rtouch && kt + 2 == nk) {
                 // Residual touches: one byte of each of the tile's 1024 residual lines (256 rows x 512 bytes), four per loader lane, behind the
                 // LAST K-tile's pieces, so that the MFMA waves' residual loads — requested only after the K loop, when the accumulators have left

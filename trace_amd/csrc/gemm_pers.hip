@@ -335,7 +335,7 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
 #define PERS_TOUCH_AT(PTR)                                                                                                             \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(PTR),                                             \
                                      (__attribute__((address_space(3))) void*)(smem + TOUCH_OFF + lw * 256), 4, 0, 0)
-#define PERS_TOUCH(KT, D) PERS_TOUCH_AT(tsrc + (KT) * 128)
+#define PERS_TOUCH(KT) PERS_TOUCH_AT(tsrc + (KT) * 128)
 #define PERS_SETUP()                                                                                                                   \
     {                                                                                                                                  \
         int tm_, tn_;                                                                                                                  \
@@ -373,8 +373,8 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
 #define PERS_TOUCH_HEAD()                                                                          \
     pend = 0;                                                                                      \
     if (toucher) {                                                                                 \
-        if (1 < nk) { PERS_TOUCH(1, 1); ++pend; }                                                  \
-        if (2 < nk) { PERS_TOUCH(2, 2); ++pend; }                                                  \
+        if (1 < nk) { PERS_TOUCH(1); ++pend; }                                                  \
+        if (2 < nk) { PERS_TOUCH(2); ++pend; }                                                  \
     }
     PERS_SETUP();
     PERS_ISSUE(0, 0);
@@ -395,7 +395,7 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
             pend = 0;
             if (kt + 1 < nk) {
                 PERS_ISSUE((q + 1) & 1, (kt + 1) * 128);
-                if (toucher && kt + LEAD < nk) { PERS_TOUCH(kt + LEAD, 0); pend = 1; }
+                if (toucher && kt + LEAD < nk) { PERS_TOUCH(kt + LEAD); pend = 1; }
             } else {
                 li = __builtin_amdgcn_readfirstlane(s_next[(n + 1) & 1]);
                 const int crm0 = rm0, crn0 = rn0;                  // the tile whose last K-tile has just been handed over

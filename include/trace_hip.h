@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define TRACE_ABI_VERSION 2
+#define TRACE_ABI_VERSION 3
 
 typedef struct trace_ctx trace_ctx;
 
@@ -34,7 +34,8 @@ typedef struct trace_config {
     float slot_eps, slot_rope_base;
     int32_t max_frames;      /* largest T per video                                    */
     int32_t max_ctx;         /* KV-cache length per sequence slot (prefill + new tokens) */
-    int32_t max_batch;       /* KV-cache sequence slots = largest decode batch, <= 64      */
+    int32_t max_batch;       /* KV-cache sequence slots, <= 128; one decode batch takes at most 64 of them (the rest can be
+                              * prefilled meanwhile: trace_amd.engine.TraceEngine.generate_stream) */
     int32_t max_new_tokens;  /* capacity of the on-device output id buffer               */
     int32_t projector_type;  /* 0 = spatial_slot (TRACE), 1 = stc_connector (legacy API) */
     int32_t vit_batch_frames; /* frames one trace_vit_forward call may take (ViT workspaces); 0 = max_frames.  Larger than
@@ -129,6 +130,16 @@ int trace_decode_read(trace_ctx* ctx, int32_t* out_ids, int32_t* out_len, int32_
  * trace_decode_feed applies them (output record, head switch, next-token embedding).  One eager step at a time. */
 int trace_decode_host_mode(trace_ctx* ctx, int on);
 int trace_decode_feed(trace_ctx* ctx, const int32_t* tokens, int B, void* stream);
+
+/* Two-stage pipeline support (trace/eval/evaluate.py:298-417 loops over independent videos: while one batch decodes — HBM-bound —
+ * the next batch's ViT + prefill — MFMA-bound — can run on another stream into other KV slots; the stages share no buffers).
+ * trace_stream_create: a HIP stream confined to cu_count CUs starting at logical CU cu_first (hipExtStreamCreateWithCUMask; mask bit i
+ * is CU i / 8 of XCD i % 8, so a run of bits is spread evenly over the XCDs; cu_first and cu_count multiples of 8); cu_count == 0: an
+ * ordinary non-blocking stream.  trace_set_gemm_cus: the persistent GEMM launches at most n workgroups (0 = the device's CU count) —
+ * set it to the CU count of the stream the ViT / prefill GEMMs run on.  Streams are destroyed with trace_stream_destroy (idle). */
+int trace_stream_create(trace_ctx* ctx, int cu_first, int cu_count, void** stream_out);
+int trace_stream_destroy(trace_ctx* ctx, void* stream);
+int trace_set_gemm_cus(trace_ctx* ctx, int n);
 
 /* Timing hook for bench.py: average device time (ms, hipEvents on `stream`) of the last trace_decode_steps call
  * per step, and of its skinny-GEMM launches if profiling was enabled with trace_set_profile(ctx, 1). */

@@ -26,7 +26,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.trace_abi_version() == 2
+    assert lib.trace_abi_version() == 3
     assert isinstance(lib.trace_last_error(), (bytes, type(None)))
 
 

@@ -1,0 +1,99 @@
+"""Two-stage pipeline (TraceEngine.generate_stream): while batch k decodes on one stream, batch k+1 runs ViT + slot pool + prefill on
+another into the other bank of KV slots.  The stages share no buffers and every reduction has a fixed order, so the bar is bit-exact:
+the ids of every batch equal generate()'s for that batch alone — on plain streams and on CU-partitioned streams (trace_stream_create),
+where the persistent GEMM runs with a capped grid.  Reference loop being pipelined: trace/eval/evaluate.py:298-417 (independent videos)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a HIP device", allow_module_level=True)
+
+from trace_amd import config as tcfg, synth  # noqa: E402
+from trace_amd._lib import TraceHipError  # noqa: E402
+from trace_amd.engine import TraceEngine, ops  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def eng():
+    cfg = tcfg.tiny(num_frames=4)
+    e = TraceEngine(cfg, max_batch=8, max_ctx=192, max_frames=4, max_new_tokens=32)
+    e.load_weights(synth.state_dict(cfg).items())
+    yield cfg, e
+    e.close()
+
+
+def _batches(cfg, nb, sizes):
+    out = []
+    for k in range(nb):
+        B = sizes[k % len(sizes)]
+        vids = [synth.synth_frames(cfg, 10 * k + b).to(torch.bfloat16).cuda() for b in range(B)]
+        ts = [[[float(i) * 2.5 + b] for i in range(4)] for b in range(B)]
+        ids = [synth.synth_prompt_ids(cfg, n_text=24 + (b % 2) * 3, video_pos=10, seed=k * 7 + b).tolist() for b in range(B)]
+        out.append((vids, ts, ids, [1] * B, None))
+    return out
+
+
+@pytest.mark.parametrize("decode_cus", [0, 64])
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_pipeline_equals_batch_by_batch(eng, decode_cus, use_graph):
+    cfg, e = eng
+    n = 12
+    batches = _batches(cfg, 5, [4, 3, 4, 1])
+    want = [e.generate(v, t, i, h, n, use_graph=use_graph) for v, t, i, h, _ in batches]
+    streams = e.make_streams(decode_cus)
+    try:
+        got = list(e.generate_stream(batches, n, use_graph=use_graph, streams=streams))
+    finally:
+        e.lib.trace_set_gemm_cus(e.h, 0)
+    assert len(got) == len(want)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g[0] == w[0], f"batch {k}: pipeline ids differ from generate()"
+        assert g[1] == w[1]
+    # and again: the banks are reused, stale KV rows of earlier batches must not leak
+    got2 = list(e.generate_stream(batches[::-1], n, use_graph=use_graph, streams=streams))
+    for k, (g, w) in enumerate(zip(got2, want[::-1])):
+        assert g[0] == w[0], f"second pass, batch {k}"
+
+
+def test_pipeline_with_eos_and_forced(eng):
+    """EOS stop + teacher forcing through the pipeline: same ids as generate()."""
+    cfg, e = eng
+    n = 10
+    batches = _batches(cfg, 3, [2, 4])
+    V = cfg.vocab_size
+    forced = [V + 1 + 3, V + 1 + 4, V + 1 + 1]          # two time digits, time <sync> -> score head
+    batches = [(v, t, i, h, [forced] * len(v)) for v, t, i, h, _ in batches]
+    want = [e.generate(v, t, i, h, n, eos=2, forced=f) for v, t, i, h, f in batches]
+    got = list(e.generate_stream(batches, n, eos=2))
+    assert [g[0] for g in got] == [w[0] for w in want]
+    assert [g[1] for g in got] == [w[1] for w in want]
+
+
+def test_pipeline_limits(eng):
+    cfg, e = eng
+    b = _batches(cfg, 1, [5])                           # 5 > max_batch // 2
+    with pytest.raises(ValueError, match="max_batch // 2"):
+        list(e.generate_stream(b, 4))
+    with pytest.raises(ValueError):
+        e.make_streams(12)                              # not a multiple of 8
+    with pytest.raises(TraceHipError):
+        h = __import__("ctypes").c_void_p()
+        from trace_amd import _lib
+        _lib.check(e.lib.trace_stream_create(e.h, 8, 4096, __import__("ctypes").byref(h)))
+
+
+def test_persistent_gemm_capped_grid_is_bit_identical():
+    """trace_set_gemm_cus / the grid cap: fewer persistent workgroups walk the same tiles in the same K order."""
+    torch.manual_seed(0)
+    A = (torch.randn(3000, 1024, device="cuda") * 0.5).to(torch.bfloat16)
+    W = (torch.randn(4096, 1024, device="cuda") * 0.05).to(torch.bfloat16)
+    bias = (torch.randn(4096, device="cuda") * 0.1).to(torch.bfloat16)
+    ref = ops.gemm(A, W, bias=bias, epilogue=2)
+    try:
+        for cap in (192, 104, 9, 3):
+            ops.set_gemm_variant(1000 + cap)
+            assert torch.equal(ops.gemm(A, W, bias=bias, epilogue=2), ref), cap
+    finally:
+        ops.set_gemm_variant(1000)

@@ -52,6 +52,9 @@ SIGNATURES = {
     "trace_decode_read": (I, [P, P, P, P, P]),
     "trace_decode_host_mode": (I, [P, I]),
     "trace_decode_feed": (I, [P, P, I, P]),
+    "trace_stream_create": (I, [P, I, I, C.POINTER(P)]),
+    "trace_stream_destroy": (I, [P, P]),
+    "trace_set_gemm_cus": (I, [P, I]),
     "trace_set_profile": (I, [P, I]),
     "trace_get_profile": (I, [P, P, I]),
     "trace_op_gemm": (I, [P, I, P, I, P, I, P, P, I, I, I, I, I, P]),
@@ -94,7 +97,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.trace_abi_version() != 2:
+    if lib.trace_abi_version() != 3:
         raise TraceHipError("libtrace_hip.so ABI version mismatch")
     _lib = lib
     return lib

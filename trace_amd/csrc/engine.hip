@@ -34,6 +34,9 @@ struct LlmLayer {
 };
 struct StcBlock { bf16_t *w1, *n1w, *n1b, *wdw, *n2w, *n2b, *fc1w, *fc1b, *fc2w, *fc2b, *w3, *n3w, *n3b, *wd, *ndw, *ndb; int cin, rd; };
 
+constexpr int MAX_SLOTS = 128;   // KV-cache sequence slots per context (a decode batch is at most SK_ROWS of them)
+static int g_ctx_per_dev[16] = {0};
+
 struct trace_ctx {
     trace_config c{};
     int dev = 0;
@@ -47,6 +50,7 @@ struct trace_ctx {
     size_t total_bytes = 0;
     std::unordered_map<std::string, int> loaded;
     bool finalized = false;
+    bool counted = false;            // in g_ctx_per_dev (the last context of a device frees the persistent GEMM's ticket counters)
     // weights
     bf16_t *patch_w, *cls, *pos_emb, *pre_w, *pre_b;
     std::vector<VitLayer> vit;
@@ -81,7 +85,7 @@ struct trace_ctx {
     int32_t *d_slots, *d_pos, *d_heads, *d_done, *d_out_ids, *d_out_len, *d_step, *d_forced, *d_params;
     int32_t* d_heads_tmp;                // head id per row for trace_llm_head_logits
     int B = 0, max_new = 0, eos = -1, has_forced = 0, ntiles = 0, nsplit = 32;
-    int slot_len[64] = {0};
+    int slot_len[MAX_SLOTS] = {0};
     int fp8 = 0;                       // decoder projections on the fp8 path
     uint8_t *pA8 = nullptr, *dA8 = nullptr, *dH8 = nullptr;      // quantised activations: prefill [2 max_ctx][max(H, I)], decode [64][I]; dH8 = the normed hidden rows
     float *psa = nullptr, *dsa = nullptr, *dsh = nullptr;        // their per-row scales
@@ -89,6 +93,7 @@ struct trace_ctx {
     int steps_done = 0;                // decode steps taken since trace_decode_begin (bounded by max_new - 1: the KV slot and the RoPE tables end at max_ctx)
     hipGraphExec_t graphs[SK_ROWS + 1] = {nullptr};   // one captured decode step per batch size
     hipStream_t cap_stream = nullptr;
+    std::vector<hipStream_t> streams;   // trace_stream_create
     // profiling
     int profile = 0;                  // 1: time decode_steps calls; 2: also bracket the layer-0 gate|up GEMV launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -146,7 +151,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     c->fp8 = cfg->llm_weights_fp8 != 0;
     if (c->fp8 && (c->H % 128 || c->I % 128 || c->I > 16384)) return bad("fp8 weight path needs hidden / intermediate sizes that are multiples of 128 (intermediate <= 16384)");
     if (!c->stc && (c->S != 8 || c->vh > 1024)) return bad("slot pool kernel needs 8 slots and mm_hidden <= 1024");
-    if (c->max_B < 1 || c->max_B > 64) return bad("max_batch (KV slots) must be in [1,64]");
+    if (c->max_B < 1 || c->max_B > MAX_SLOTS) return bad("max_batch (KV slots) must be in [1,128]");
     c->nsplit = 32;                                           // upper bound (workspace size); per-batch value below
     {
         const int g2 = c->G / 2 + 1;
@@ -226,7 +231,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     if (c->fp8) { A(c->pA8, 2 * Lm * std::max(H, I)); A(c->psa, 2 * Lm); A(c->dA8, (size_t)SK_ROWS * std::max(H, I)); A(c->dsa, SK_ROWS); A(c->dH8, (size_t)SK_ROWS * H); A(c->dsh, SK_ROWS); }
     // --- decode ---
     A(c->dX, SK_ROWS * H); A(c->dH, SK_ROWS * H); A(c->dQKV, SK_ROWS * (size_t)c->QKV); A(c->dO, SK_ROWS * H); A(c->dACT, SK_ROWS * I);
-    A(c->xlast, 64 * H);
+    A(c->xlast, (size_t)std::max(c->max_B, 64) * H);
     A(c->attn_ws, (size_t)SK_ROWS * c->NQ * c->nsplit * (c->HD + 2)); A(c->tickets, SK_ROWS * c->NKV);
     {
         size_t f = skinny_ws_floats(c->QKV, H, EPI_NONE);
@@ -253,6 +258,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     hipEventCreate(&c->mev0); hipEventCreate(&c->mev1);
     c->kev.resize(1024);
     for (auto& e : c->kev) hipEventCreate(&e);
+    if (device_id >= 0 && device_id < 16) { g_ctx_per_dev[device_id] += 1; c->counted = true; }
     *out = c;
     return TRACE_OK;
 }
@@ -260,6 +266,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
 extern "C" int trace_ctx_destroy(trace_ctx* c) {
     if (!c) return TRACE_OK;
     hipDeviceSynchronize();
+    for (auto& st : c->streams) hipStreamDestroy(st);
     for (auto& g : c->graphs) if (g) hipGraphExecDestroy(g);
     for (auto& e : c->kev) if (e) hipEventDestroy(e);
     if (c->mev0) hipEventDestroy(c->mev0);
@@ -272,6 +279,7 @@ extern "C" int trace_ctx_destroy(trace_ctx* c) {
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->counted && c->dev >= 0 && c->dev < 16 && --g_ctx_per_dev[c->dev] == 0) gemm_pers_release(c->dev);
     delete c;
     return TRACE_OK;
 }
@@ -478,6 +486,10 @@ extern "C" int trace_ctx_finalize(trace_ctx* c) {
             LCHK(launch_tile_pack_fp8(l.wd8, c->I, l.wd8_d, c->H, c->I, 0));
         }
     }
+    // ticket counters of the persistent GEMM for the streams this context launches on by itself (an allocation + a memset: not something to
+    // meet inside a timed or captured region); a caller's own stream gets its counters at its first launch
+    HIPCHK(hipSetDevice(c->dev));
+    if (gemm_pers_init(nullptr) != TRACE_OK || gemm_pers_init(c->cap_stream) != TRACE_OK) return fail(TRACE_ERR_HIP, "persistent GEMM ticket counters");
     HIPCHK(hipDeviceSynchronize());
     c->finalized = true;
     return TRACE_OK;
@@ -1104,6 +1116,44 @@ extern "C" int trace_decode_feed(trace_ctx* c, const int32_t* tokens, int B, voi
     return TRACE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ pipeline streams
+extern int g_gemm_pers_grid_cap;
+extern "C" int trace_stream_create(trace_ctx* c, int cu_first, int cu_count, void** stream_out) {
+    if (!c || !stream_out) return fail(TRACE_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->dev));
+    hipStream_t s = nullptr;
+    if (cu_count == 0) {
+        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    } else {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, c->dev));
+        const int ncu = prop.multiProcessorCount;
+        if (cu_first < 0 || cu_count < 8 || (cu_first % 8) || (cu_count % 8) || cu_first + cu_count > ncu)
+            return fail(TRACE_ERR_ARG, "CU range must be multiples of 8 (one CU per XCD) inside the device's " + std::to_string(ncu) + " CUs");
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int i = cu_first; i < cu_first + cu_count; ++i) mask[i / 32] |= 1u << (i % 32);
+        HIPCHK(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+    }
+    if (gemm_pers_init(s) != TRACE_OK) { hipStreamDestroy(s); return fail(TRACE_ERR_HIP, "persistent GEMM ticket counters"); }
+    c->streams.push_back(s);
+    *stream_out = (void*)s;
+    return TRACE_OK;
+}
+extern "C" int trace_stream_destroy(trace_ctx* c, void* stream) {
+    if (!c || !stream) return fail(TRACE_ERR_ARG, "null argument");
+    auto it = std::find(c->streams.begin(), c->streams.end(), (hipStream_t)stream);
+    if (it == c->streams.end()) return fail(TRACE_ERR_ARG, "not a stream of this context");
+    HIPCHK(hipStreamSynchronize(*it));
+    HIPCHK(hipStreamDestroy(*it));
+    c->streams.erase(it);
+    return TRACE_OK;
+}
+extern "C" int trace_set_gemm_cus(trace_ctx* c, int n) {
+    if (!c || n < 0) return fail(TRACE_ERR_ARG, "bad argument");
+    g_gemm_pers_grid_cap = n;
+    return TRACE_OK;
+}
+
 extern "C" int trace_set_profile(trace_ctx* c, int on) {
     if (!c) return fail(TRACE_ERR_ARG, "null ctx");
     c->profile = on; c->ksum_ms = 0.0; c->ksamples = 0; c->kev_used = 0; c->msum_ms = 0.0; c->msamples = 0; c->mM = 0;
@@ -1128,6 +1178,7 @@ extern int g_skinny_debug;
 extern int g_gemm_pers_opt;
 extern int g_gemm_ldr_opt;
 extern "C" int trace_op_set_gemm_variant(int variant) {
+    if (variant >= 1000 && variant <= 1000 + 1024) { g_gemm_pers_grid_cap = variant - 1000; return TRACE_OK; }   // persistent GEMM: at most n workgroups (0 = #CUs)
     if (variant >= 100 && variant < 104) { g_attn_debug = variant - 100; return TRACE_OK; }
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }

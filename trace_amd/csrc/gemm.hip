@@ -355,7 +355,9 @@ int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
         if (p.N % 256 == 0 && (g_gemm_variant == 4 || (g_gemm_variant == 0 && v == 3))) {
             if (g_gemm_variant == 0 && pers_ok && epi != EPI_RESIDUAL) {
                 g_gemm_pers_static = 0;
-                return launch_gemm_pers(p, epi, s);
+                const int rc = launch_gemm_pers(p, epi, s);
+                // no ticket counters for this stream and none can be made inside a capture: the one-workgroup-per-tile kernel gives the same bits
+                if (rc != TRACE_ERR_STATE) return rc;
             }
             return launch_gemm_ldr(p, epi, s);
         }

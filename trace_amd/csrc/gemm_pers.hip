@@ -529,24 +529,36 @@ __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, i
 #undef PERS_FRAGS
 }
 
-int g_ncu = 0;
-// ticket counters: 8 per stream (two launches that may run concurrently must not share them; launches on one stream are ordered)
+// ticket counters: 8 per (device, stream) — two launches that may run concurrently must not share them; launches on one stream are ordered.
+// The CU count is cached per device (a process may hold contexts on several GPUs, each with its own default stream 0).
+constexpr int MAX_DEV = 16;
+int g_ncu[MAX_DEV] = {0};
 std::mutex g_ctr_mu;
-std::unordered_map<hipStream_t, int*> g_ctrs;
-int* counters_for(hipStream_t s) {
+struct CtrKey {
+    int dev; hipStream_t s;
+    bool operator==(const CtrKey& o) const { return dev == o.dev && s == o.s; }
+};
+struct CtrHash { size_t operator()(const CtrKey& k) const { return std::hash<const void*>()((const void*)k.s) * 31u + (size_t)k.dev; } };
+std::unordered_map<CtrKey, int*, CtrHash> g_ctrs;
+// nullptr: the counters do not exist yet and cannot be made now (the stream is capturing: no allocation / memset inside a capture) or HIP failed
+int* counters_for(hipStream_t s, int* ncu_out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
     std::lock_guard<std::mutex> lk(g_ctr_mu);
-    auto it = g_ctrs.find(s);
-    if (it != g_ctrs.end()) return it->second;
-    if (!g_ncu) {
-        int dev = 0;
+    if (!g_ncu[dev]) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
-        g_ncu = prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
+        g_ncu[dev] = prop.multiProcessorCount;
     }
+    if (ncu_out) *ncu_out = g_ncu[dev];
+    auto it = g_ctrs.find(CtrKey{dev, s});
+    if (it != g_ctrs.end()) return it->second;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
     int* c = nullptr;
     if (hipMalloc(&c, 8 * CTR_STRIDE * sizeof(int)) != hipSuccess) return nullptr;
     if (hipMemsetAsync(c, 0, 8 * CTR_STRIDE * sizeof(int), s) != hipSuccess) { (void)hipFree(c); return nullptr; }   // ordered before the launch
-    g_ctrs[s] = c;
+    g_ctrs[CtrKey{dev, s}] = c;
     return c;
 }
 
@@ -575,19 +587,33 @@ void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
 int g_gemm_pers_opt = 0;           // A/B builds of the K loop (trace_op_set_gemm_variant(300 + opt))
 int g_gemm_pers_static = 0;        // 1: tiles dealt round-robin instead of by ticket (A/B runs)
 
+int g_gemm_pers_grid_cap = 0;      // > 0: at most this many workgroups per launch (a stream confined to part of the CUs by a CU mask: the
+                                   // persistent grid must not exceed the CUs it can run on, or the surplus workgroups wait for a second round)
+
 // Creates the ticket counters of a stream ahead of its first launch (an allocation + a memset: not something to meet inside a timed or
 // captured region); launch_gemm_pers does it on demand otherwise.
-int gemm_pers_init(hipStream_t s) { return counters_for(s) ? TRACE_OK : TRACE_ERR_HIP; }
+int gemm_pers_init(hipStream_t s) { return counters_for(s, nullptr) ? TRACE_OK : TRACE_ERR_HIP; }
+// Frees the counters of every stream of `dev` (the last context on a device going away; the device must be idle)
+void gemm_pers_release(int dev) {
+    std::lock_guard<std::mutex> lk(g_ctr_mu);
+    for (auto it = g_ctrs.begin(); it != g_ctrs.end();) {
+        if (it->first.dev == dev) { (void)hipFree(it->second); it = g_ctrs.erase(it); }
+        else ++it;
+    }
+}
 
+// TRACE_ERR_STATE: no ticket counters for this stream and none can be made now (capturing): the caller falls back to gemm_ldr
 int launch_gemm_pers(const GemmArgs& p, int epi, hipStream_t s) {
     if (p.M < 1 || p.N % BN || p.K % BK || p.K < 2 * BK || p.fp8) return TRACE_ERR_ARG;
     if ((long)p.M * p.ldc >= (1L << 30) || (epi == EPI_RESIDUAL && (long)p.M * p.ldr >= (1L << 30))) return TRACE_ERR_ARG;   // 32-bit byte offsets
-    int* ctr = counters_for(s);
-    if (!ctr) return TRACE_ERR_HIP;
+    int ncu = 0;
+    int* ctr = counters_for(s, &ncu);
+    if (!ctr) return TRACE_ERR_STATE;
+    if (g_gemm_pers_grid_cap > 0 && g_gemm_pers_grid_cap < ncu) ncu = g_gemm_pers_grid_cap < 8 ? 8 : g_gemm_pers_grid_cap;   // every XCD keeps a workgroup: tiles are dealt per XCD
     const int total = ((p.M + BM - 1) / BM) * (p.N / BN);
     // g_gemm_pers_static == 2: one workgroup per tile (the dispatcher places them as CUs free up, nothing persists): this kernel's K loop and
     // register epilogue without the tile walk (A/B runs)
-    const int nblk = g_gemm_pers_static == 2 ? total : (total < g_ncu ? total : g_ncu);
+    const int nblk = g_gemm_pers_static == 2 ? total : (total < ncu ? total : ncu);
     const int dynamic = g_gemm_pers_static ? 0 : 1;
     g_opt = g_gemm_pers_opt;
     switch (epi) {

@@ -305,12 +305,13 @@ class TraceEngine:
         return list(buf)
 
     # ---- one-call convenience: what generate() does for one batch of videos ----------------------
-    def generate(self, videos: Sequence[torch.Tensor], timestamps: Sequence, input_ids: Sequence[Sequence[int]],
-                 heads: Sequence[int], max_new_tokens: int, eos: int = -1, use_graph: bool = True,
-                 forced: Optional[Sequence[Sequence[int]]] = None):
+    def encode_prefill(self, videos: Sequence[torch.Tensor], timestamps: Sequence, input_ids: Sequence[Sequence[int]], slot0: int = 0):
+        """Stage 1 of generate() for a batch: CLIP tower (over the batch's frame stream) -> slot pool + time rows -> splice -> prefill
+        into KV slots slot0 .. slot0 + B - 1.  Runs on the current stream; touches no decode state, so it may run on another stream
+        while an earlier batch (other slots) is being decoded (generate_stream)."""
         B = len(videos)
-        if B > self.max_batch:
-            raise ValueError(f"batch {B} exceeds engine max_batch {self.max_batch}")
+        if slot0 < 0 or slot0 + B > self.max_batch:
+            raise ValueError(f"slots {slot0}..{slot0 + B - 1} exceed the engine's {self.max_batch} KV slots")
         # prefill: neighbours whose spliced prompts have the same length share one pass (M = 2L fills the GEMM tile grid)
         held = None                                   # (slot, spliced embeds) waiting for a partner
         feats = None
@@ -336,18 +337,22 @@ class TraceEngine:
                 self.encode_video(videos[b], timestamps[b])
             if b + 1 < B or held is not None:
                 L, emb = self.splice(input_ids[b], want_output=True)
-                if held is not None and held[1].shape[0] == L and held[0] + 1 == b:
+                if held is not None and held[1].shape[0] == L and held[0] + 1 == slot0 + b:
                     self.prefill_pair(held[0], held[1], emb)
                     held = None
                     continue
                 if held is not None:
                     self.prefill(held[0], held[1].shape[0], embeds=held[1])
-                held = (b, emb)
+                held = (slot0 + b, emb)
             else:
-                self.prefill(b, self.splice(input_ids[b]))
+                self.prefill(slot0 + b, self.splice(input_ids[b]))
         if held is not None:
             self.prefill(held[0], held[1].shape[0], embeds=held[1])
-        self.decode_begin(list(range(B)), heads, max_new_tokens, eos, forced)
+
+    def decode(self, slots: Sequence[int], heads: Sequence[int], max_new_tokens: int, eos: int = -1, use_graph: bool = True,
+               forced: Optional[Sequence[Sequence[int]]] = None):
+        """Stage 2 of generate(): the greedy loop over prefilled KV slots, on the current stream -> (ids per sequence, final heads)."""
+        self.decode_begin(list(slots), heads, max_new_tokens, eos, forced)
         if max_new_tokens > 1:
             if eos < 0:
                 self.decode_steps(max_new_tokens - 1, use_graph)
@@ -361,6 +366,77 @@ class TraceEngine:
                     if all(len(x) and x[-1] == eos for x in ids):
                         break
         return self.decode_read()
+
+    def generate(self, videos: Sequence[torch.Tensor], timestamps: Sequence, input_ids: Sequence[Sequence[int]],
+                 heads: Sequence[int], max_new_tokens: int, eos: int = -1, use_graph: bool = True,
+                 forced: Optional[Sequence[Sequence[int]]] = None):
+        B = len(videos)
+        if B > min(self.max_batch, 64):
+            raise ValueError(f"batch {B} exceeds the engine's decode batch {min(self.max_batch, 64)}")
+        self.encode_prefill(videos, timestamps, input_ids, 0)
+        return self.decode(range(B), heads, max_new_tokens, eos, use_graph, forced)
+
+    # ---- two-stage pipeline over a stream of batches ---------------------------------------------------
+    def make_streams(self, decode_cus: int = 0):
+        """The pipeline's (encode stream, decode stream).  decode_cus > 0 confines the decode stream to that many CUs and the encode
+        stream to the rest (trace_stream_create: CU-masked HIP streams, spread evenly over the 8 XCDs) and caps the persistent GEMM's
+        grid at the encode stream's CU count (trace_set_gemm_cus): the MFMA-bound GEMMs
+        and the HBM-bound decode kernels then run side by side instead of taking turns on the whole chip."""
+        if decode_cus <= 0:
+            return torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
+        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if decode_cus % 8 or decode_cus >= ncu:
+            raise ValueError("decode_cus must be a multiple of 8 (the XCD count) below the CU count")
+        def masked(lo, n):
+            h = C.c_void_p()
+            _lib.check(self.lib.trace_stream_create(self.h, lo, n, C.byref(h)))
+            return torch.cuda.ExternalStream(h.value, device=self.device)
+        dec, enc = masked(0, decode_cus), masked(decode_cus, ncu - decode_cus)
+        _lib.check(self.lib.trace_set_gemm_cus(self.h, ncu - decode_cus))
+        return enc, dec
+
+    def generate_stream(self, batches: Iterable, max_new_tokens: int, eos: int = -1, use_graph: bool = True, streams=None):
+        """generate() over a stream of batches as a two-stage pipeline: while batch k decodes (HBM-bound) on one stream, batch k+1
+        runs its ViT + slot pool + prefill (MFMA-bound) on another, into the other half of the KV slots.  `batches` yields
+        (videos, timestamps, input_ids, heads, forced-or-None); yields generate()'s result per batch, in order.  Every batch holds at
+        most max_batch // 2 videos.  Results are identical to generate() batch by batch: the stages share no buffers (KV banks,
+        prefill / ViT scratch vs decode scratch) and every kernel's reductions have a fixed order."""
+        half = self.max_batch // 2
+        if half < 1:
+            raise ValueError("generate_stream needs an engine with max_batch >= 2 (two banks of KV slots)")
+        enc_s, dec_s = streams if streams is not None else self.make_streams()
+        cur = torch.cuda.current_stream(self.device)
+        enc_s.wait_stream(cur); dec_s.wait_stream(cur)
+        pending = None                                  # (bank, heads, forced, B) prefilled, waiting for its decode
+        bank = 0
+        ready = torch.cuda.Event()
+        for item in batches:
+            videos, timestamps, input_ids, heads, forced = item
+            if len(videos) > min(half, 64):
+                raise ValueError(f"batch of {len(videos)} exceeds max_batch // 2 = {half} (two KV banks)")
+            if pending is not None:                     # issue the decode of the previous batch first: it only queues work
+                pb, ph, pf, pB = pending
+                with torch.cuda.stream(dec_s):
+                    dec_s.wait_event(ready)
+                    self.decode_begin(list(range(pb * half, pb * half + pB)), ph, max_new_tokens, eos, pf)
+                    if max_new_tokens > 1:
+                        self.decode_steps(max_new_tokens - 1, use_graph)
+            with torch.cuda.stream(enc_s):
+                self.encode_prefill(videos, timestamps, input_ids, bank * half)
+                ready = torch.cuda.Event()
+                ready.record(enc_s)
+            if pending is not None:
+                with torch.cuda.stream(dec_s):
+                    yield self.decode_read()
+            pending = (bank, list(heads), forced, len(videos))
+            bank ^= 1
+        if pending is not None:
+            pb, ph, pf, pB = pending
+            with torch.cuda.stream(dec_s):
+                dec_s.wait_event(ready)
+                out = self.decode(range(pb * half, pb * half + pB), ph, max_new_tokens, eos, use_graph, pf)
+            cur.wait_stream(dec_s); cur.wait_stream(enc_s)
+            yield out
 
 
 # ---- kernel-level wrappers for unit tests / microbenchmarks -------------------------------------

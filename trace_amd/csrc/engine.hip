@@ -1052,7 +1052,7 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
         if (!*slot_g) {
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamSynchronize(s));
-            HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeGlobal));
+            HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));   // another thread may be launching the encode stage (generate_stream)
             const int rc = decode_step(c, nullptr, c->cap_stream);
             hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
             if (rc != TRACE_OK) { if (g) hipGraphDestroy(g); return rc; }

@@ -400,43 +400,48 @@ class TraceEngine:
         runs its ViT + slot pool + prefill (MFMA-bound) on another, into the other half of the KV slots.  `batches` yields
         (videos, timestamps, input_ids, heads, forced-or-None); yields generate()'s result per batch, in order.  Every batch holds at
         most max_batch // 2 videos.  Results are identical to generate() batch by batch: the stages share no buffers (KV banks,
-        prefill / ViT scratch vs decode scratch) and every kernel's reductions have a fixed order."""
+        prefill / ViT scratch vs decode scratch) and every kernel's reductions have a fixed order.
+
+        The decode stage is issued from a worker thread: one decode batch is ~75 k kernel dispatches, far more than a HIP stream's
+        queue holds, so the issuing thread blocks until the GPU has consumed most of them — issued from the caller's thread it would
+        hold back the encode stage's launches and the two stages would run one after the other (profiles/r03_overlap_probe_single_thread.jsonl)."""
+        import concurrent.futures as cf
         half = self.max_batch // 2
         if half < 1:
             raise ValueError("generate_stream needs an engine with max_batch >= 2 (two banks of KV slots)")
         enc_s, dec_s = streams if streams is not None else self.make_streams()
         cur = torch.cuda.current_stream(self.device)
         enc_s.wait_stream(cur); dec_s.wait_stream(cur)
-        pending = None                                  # (bank, heads, forced, B) prefilled, waiting for its decode
-        bank = 0
-        ready = torch.cuda.Event()
-        for item in batches:
-            videos, timestamps, input_ids, heads, forced = item
-            if len(videos) > min(half, 64):
-                raise ValueError(f"batch of {len(videos)} exceeds max_batch // 2 = {half} (two KV banks)")
-            if pending is not None:                     # issue the decode of the previous batch first: it only queues work
-                pb, ph, pf, pB = pending
-                with torch.cuda.stream(dec_s):
-                    dec_s.wait_event(ready)
-                    self.decode_begin(list(range(pb * half, pb * half + pB)), ph, max_new_tokens, eos, pf)
-                    if max_new_tokens > 1:
-                        self.decode_steps(max_new_tokens - 1, use_graph)
-            with torch.cuda.stream(enc_s):
-                self.encode_prefill(videos, timestamps, input_ids, bank * half)
-                ready = torch.cuda.Event()
-                ready.record(enc_s)
-            if pending is not None:
-                with torch.cuda.stream(dec_s):
-                    yield self.decode_read()
-            pending = (bank, list(heads), forced, len(videos))
-            bank ^= 1
-        if pending is not None:
-            pb, ph, pf, pB = pending
+
+        def dec_job(bank, heads, forced, B, ready):
+            torch.cuda.set_device(self.device)
             with torch.cuda.stream(dec_s):
                 dec_s.wait_event(ready)
-                out = self.decode(range(pb * half, pb * half + pB), ph, max_new_tokens, eos, use_graph, pf)
-            cur.wait_stream(dec_s); cur.wait_stream(enc_s)
-            yield out
+                return self.decode(range(bank * half, bank * half + B), heads, max_new_tokens, eos, use_graph, forced)
+
+        pending = None                                  # (bank, heads, forced, B, ready event): prefilled, waiting for its decode
+        bank = 0
+        with cf.ThreadPoolExecutor(max_workers=1, thread_name_prefix="trace-decode") as pool:
+            for item in batches:
+                videos, timestamps, input_ids, heads, forced = item
+                if len(videos) > min(half, 64):
+                    raise ValueError(f"batch of {len(videos)} exceeds max_batch // 2 = {half} (two KV banks)")
+                fut = pool.submit(dec_job, *pending) if pending is not None else None
+                try:
+                    with torch.cuda.stream(enc_s):
+                        self.encode_prefill(videos, timestamps, input_ids, bank * half)
+                        ready = torch.cuda.Event()
+                        ready.record(enc_s)
+                finally:
+                    out = fut.result() if fut is not None else None      # also drains the decode stage before an exception propagates
+                if out is not None:
+                    yield out
+                pending = (bank, list(heads), forced, len(videos), ready)
+                bank ^= 1
+            if pending is not None:
+                out = pool.submit(dec_job, *pending).result()
+                cur.wait_stream(dec_s); cur.wait_stream(enc_s)
+                yield out
 
 
 # ---- kernel-level wrappers for unit tests / microbenchmarks -------------------------------------

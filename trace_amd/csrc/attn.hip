@@ -303,6 +303,14 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// VROW = true (round 3): V is taken ROW-MAJOR straight from the QKV buffer — no transpose_v pass (64 us per layer at 170 frames, a pure
+// mover) and no V^T scratch.  The V half of a stage is then an image [d-half ht][key 0..63][32 d] (64-byte rows; a 1 KB LDS-DMA piece = 16
+// keys x 64 B, lane = (key, 16-byte chunk)), and a PV operand — 8 keys of one d per lane — is two ds_read_b64_tr_b16 (gfx950's LDS
+// transpose read: the 16 lanes of a group fetch a [4 keys][16 d] block, 8 bytes each, and lane i receives column i): group (cg, h) of
+// the wave reads keys 16 ks + 4h .. + 3 (and + 8) x d ht*32 + cg*16 .. + 15, i.e. the 32 lanes served together read 4 consecutive
+// 64-byte rows = every bank once.  The k-slot <-> key map is the one the S accumulators dictate, as before.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+template <bool VROW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_vit_dma_kernel(AttnArgs a) {
     constexpr int HD = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -316,9 +324,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int qabs = q0 + c32;
     const int rem = a.nkv_rows % BKV, nkv_main = a.nkv_rows - rem, nt = nkv_main / BKV;
     const bf16_t* kbase = a.K + (size_t)b * a.k_bs + (size_t)kvh * a.k_hs;
-    const bf16_t* vbase = a.V + (size_t)b * a.v_bs + (size_t)kvh * a.v_hs;
+    const bf16_t* vbase = VROW ? a.Vrow + (size_t)b * a.vr_bs + (size_t)kvh * a.vr_hs : a.V + (size_t)b * a.v_bs + (size_t)kvh * a.v_hs;
 
-    // ---- LDS-DMA: per tile the block moves 8 K pieces + 8 V^T pieces of 1 KB (8 rows x 128 B); wave w issues pieces 2w, 2w+1 of each
+    // ---- LDS-DMA: per tile the block moves 8 K pieces + 8 V pieces of 1 KB (K, V^T: 8 rows x 128 B; row-major V: 16 keys x 64 B of one
+    //      d-half); wave w issues pieces 2w, 2w+1 of each
     const bf16_t* ksrc[2];
     const bf16_t* vsrc[2];
 #pragma unroll
@@ -326,17 +335,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int r = (2 * wid + j) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         ksrc[j] = kbase + (size_t)r * a.k_rs + c * 8;
-        vsrc[j] = vbase + (size_t)r * a.v_rs + c * 8;
+        if (VROW) {
+            const int pi = 2 * wid + j;                  // piece (ht = pi >> 2, keys (pi & 3) * 16 ..): lane = (key, chunk)
+            vsrc[j] = vbase + (size_t)((pi & 3) * 16 + (lane >> 2)) * a.vr_rs + (pi >> 2) * 32 + (lane & 3) * 8;
+        } else vsrc[j] = vbase + (size_t)r * a.v_rs + c * 8;
     }
     const long kstep = (long)BKV * a.k_rs;
+    const long vstep = VROW ? (long)BKV * a.vr_rs : (long)BKV;
     auto issue = [&](int t, int stage) {
         char* st = smem + stage * DSTAGE + (2 * wid) * 1024;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             glds16(ksrc[j] + (size_t)t * kstep, st + j * 1024);
-            glds16(vsrc[j] + t * BKV, st + 8192 + j * 1024);
+            glds16(vsrc[j] + (size_t)t * vstep, st + 8192 + j * 1024);
         }
     };
+    // row-major V: this lane's byte offset inside a stage's V image for (ks = 0, ht = 0, first key quad): key 4h + (i >> 2), d cg*16 + (i & 3)*4
+    const int vtr_off = ((4 * h + ((lane & 15) >> 2)) * 64) + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
     issue(0, 0);
     if (nt > 1) issue(1, 1);
 
@@ -480,7 +495,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 for (int i = 0; i < 4; ++i) pf.u[i] = pack2bf(S[st][rb + 2 * i], S[st][rb + 2 * i + 1]);
 #pragma unroll
                 for (int ht = 0; ht < HD / 32; ++ht) {
-                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vb + kswz<HD>(ht * 32 + c32, ks * 2 + h));
+                    bf16x8_t vf;
+                    if (VROW) {
+                        typedef s16x4_t __attribute__((address_space(3))) * lds_s4;
+                        const char* vp = vb + vtr_off + ht * 4096 + ks * 1024;
+                        union { bf16x8_t v; s16x4_t q[2]; } u;
+                        u.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vp));
+                        u.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vp + 512));
+                        vf = u.v;
+                    } else vf = *reinterpret_cast<const bf16x8_t*>(vb + kswz<HD>(ht * 32 + c32, ks * 2 + h));
                     oacc[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, oacc[ht], 0, 0, 0);
                 }
             }
@@ -567,10 +590,12 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
 
 int g_attn_pf_debug = 0;   // microbenchmark-only knock-outs of the prefill-shaped kernels: 1 = no K/V loads after tile 0, 2 = no tile math
 
-// The LDS-DMA kernel takes V^T in transpose_v's permuted layout and needs whole key tiles plus at most TAILV trailing keys
+// The LDS-DMA kernel takes V^T in transpose_v's permuted layout (v_perm = 1) or V row-major (v_perm = 2, attn_vit_rowmajor_v()) and needs
+// whole key tiles plus at most TAILV trailing keys
+bool attn_vit_rowmajor_v() { return g_attn_pf_debug != 6; }    // trace_op_set_gemm_variant(116): the transposed-V path, for A/B runs
 bool attn_vit_wants_perm(int nkv_rows, bool has_vrow) {
     const int rem = nkv_rows % BKV;
-    return g_attn_pf_debug < 5 && nkv_rows >= 2 * BKV && (rem == 0 || (has_vrow && rem <= TAILV));
+    return (g_attn_pf_debug < 5 || g_attn_pf_debug == 6) && nkv_rows >= 2 * BKV && (rem == 0 || (has_vrow && rem <= TAILV));
 }
 
 int launch_attn_vit(const AttnArgs& a_, hipStream_t s) {
@@ -579,15 +604,18 @@ int launch_attn_vit(const AttnArgs& a_, hipStream_t s) {
     if (a.heads != a.kv_heads || a.nq_rows <= 0 || a.nkv_rows <= 0 || (a.v_rs % 64)) return TRACE_ERR_ARG;
     if (a.v_perm) {
         if (a.causal || !attn_vit_wants_perm(a.nkv_rows, a.Vrow != nullptr)) return TRACE_ERR_ARG;
+        if (a.v_perm == 2 && (!a.Vrow || (a.vr_rs % 8) || (a.vr_hs % 8) || (a.vr_bs % 8))) return TRACE_ERR_ARG;
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_vit_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DSTAGES * DSTAGE);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_vit_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DSTAGES * DSTAGE);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_vit_dma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DSTAGES * DSTAGE);
             done = true;
         }
         const int nqt = (a.nq_rows + 31) / 32;
         const long nblk = (long)((nqt + 3) / 4) * a.kv_heads * a.batch;
         if (nblk > 0x7fffffffL) return TRACE_ERR_ARG;
-        hipLaunchKernelGGL(attn_vit_dma_kernel, dim3((unsigned)nblk), dim3(256), DSTAGES * DSTAGE, s, a);
+        if (a.v_perm == 2) hipLaunchKernelGGL(attn_vit_dma_kernel<true>, dim3((unsigned)nblk), dim3(256), DSTAGES * DSTAGE, s, a);
+        else hipLaunchKernelGGL(attn_vit_dma_kernel<false>, dim3((unsigned)nblk), dim3(256), DSTAGES * DSTAGE, s, a);
         return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
     }
     return launch_attn<64, false>(a, s);

@@ -535,13 +535,14 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
     a.nq_rows = NT; a.nkv_rows = NT; a.batch = T; a.heads = c->vheads; a.kv_heads = c->vheads;
     a.scale = 0.125f; a.causal = 0;
     a.Vrow = c->vQKV + 2 * vh; a.vr_bs = a.q_bs; a.vr_hs = 64; a.vr_rs = 3 * vh;
-    a.v_perm = attn_vit_wants_perm(NT, true) ? 1 : 0;
+    a.v_perm = attn_vit_wants_perm(NT, true) ? (attn_vit_rowmajor_v() ? 2 : 1) : 0;     // 2: V read row-major from vQKV, no transpose pass
     for (int l = 0; l < c->vL; ++l) {
         const VitLayer& L = c->vit[l];
         LCHK(launch_layernorm(c->vX, vh, c->vH, vh, L.ln1w, L.ln1b, Mv, vh, c->c.v_eps, s));
         TRY(gemm(c->vH, vh, L.wqkv, vh, c->vQKV, 3 * vh, L.bqkv, nullptr, 0, Mv, 3 * vh, vh, EPI_NONE, s));
-        LCHK(launch_transpose_v(c->vQKV + 2 * vh, (long)NT * 3 * vh, 64, 3 * vh, c->vVT, a.v_bs, a.v_hs, c->tokpad, NT, 64,
-                                c->vheads, T, s, a.v_perm));
+        if (a.v_perm != 2)
+            LCHK(launch_transpose_v(c->vQKV + 2 * vh, (long)NT * 3 * vh, 64, 3 * vh, c->vVT, a.v_bs, a.v_hs, c->tokpad, NT, 64,
+                                    c->vheads, T, s, a.v_perm));
         LCHK(launch_attn_vit(a, s));
         TRY(gemm(c->vH, vh, L.wo, vh, c->vX, vh, L.bo, c->vX, vh, Mv, vh, vh, EPI_RESIDUAL, s));
         LCHK(launch_layernorm(c->vX, vh, c->vH, vh, L.ln2w, L.ln2b, Mv, vh, c->c.v_eps, s));
@@ -1211,9 +1212,10 @@ extern "C" int trace_op_attention(const void* Q, const void* K, const void* V, v
     a.o_bs = a.q_bs; a.o_hs = head_dim; a.o_rs = heads * head_dim;
     a.nq_rows = nq; a.nkv_rows = nkv; a.batch = batch; a.heads = heads; a.kv_heads = kv_heads; a.scale = scale; a.causal = causal;
     a.Vrow = (const bf16_t*)V; a.vr_bs = a.k_bs; a.vr_hs = head_dim; a.vr_rs = kv_heads * head_dim;
-    a.v_perm = (head_dim == 64 && !causal && heads == kv_heads && attn_vit_wants_perm(nkv, true)) ? 1 : 0;
-    LCHK(launch_transpose_v((const bf16_t*)V, a.k_bs, head_dim, kv_heads * head_dim, (bf16_t*)vt_scratch, a.v_bs, a.v_hs, pad, nkv,
-                            head_dim, kv_heads, batch, s, a.v_perm));
+    a.v_perm = (head_dim == 64 && !causal && heads == kv_heads && attn_vit_wants_perm(nkv, true)) ? (attn_vit_rowmajor_v() ? 2 : 1) : 0;
+    if (a.v_perm != 2)
+        LCHK(launch_transpose_v((const bf16_t*)V, a.k_bs, head_dim, kv_heads * head_dim, (bf16_t*)vt_scratch, a.v_bs, a.v_hs, pad, nkv,
+                                head_dim, kv_heads, batch, s, a.v_perm));
     if (head_dim == 64) { LCHK(launch_attn_vit(a, s)); }
     else if (head_dim == 128) { LCHK(launch_attn_prefill(a, s)); }
     else return fail(TRACE_ERR_ARG, "head_dim must be 64 or 128");

@@ -59,7 +59,8 @@ struct AttnArgs {
     // keys (nkv % 64 <= 8) in on the VALU instead of running a mostly-masked tile; null = masked tile
     const bf16_t* Vrow; long vr_bs, vr_hs; int vr_rs;
     int dbg;                        // microbenchmark knock-outs (0 = full kernel)
-    int v_perm;                     // V^T was written by launch_transpose_v(..., perm = 1): selects the LDS-DMA ViT kernel
+    int v_perm;                     // 1: V^T was written by launch_transpose_v(..., perm = 1): selects the LDS-DMA ViT kernel;
+                                    // 2: the same kernel reading V row-major through Vrow (LDS transpose reads) — V / transpose_v unused
 };
 // NB: V is passed PRE-TRANSPOSED: V^T[d, kv] with row stride v_rs (multiple of 64, >= nkv_rows, zero padded)
 int launch_attn_vit(const AttnArgs& a, hipStream_t s);       // head_dim 64, non-causal, heads == kv_heads
@@ -69,6 +70,8 @@ int launch_transpose_v(const bf16_t* src, long src_bs, long src_hs, int src_rs, 
                        int dst_rs, int n, int hd, int heads, int batch, hipStream_t s, int perm = 0);
 // true: launch_attn_vit can run its LDS-DMA kernel for this key count -> transpose V with perm = 1 and set AttnArgs::v_perm
 bool attn_vit_wants_perm(int nkv_rows, bool has_vrow);
+// true: with attn_vit_wants_perm(), set v_perm = 2 and skip launch_transpose_v altogether (false only under an A/B debug switch)
+bool attn_vit_rowmajor_v();
 
 // ---- SpatialSlotPool (slot_pool.hip) ----
 // feats rows: frame t patch p at feats + (t*frame_stride + p*row_stride); out RES [T*S, D] bf16 (pre-readout)

@@ -172,6 +172,20 @@ def test_attention_vit(Bn, n, heads):
     check("attn vit", ops.attention(q, k, v, False, 0.125), _attn_ref(q, k, v, False, 0.125), 2e-2, 2e-2)
 
 
+def test_attention_vit_rowmajor_v_equals_transposed_v():
+    """Round 3: the LDS-DMA ViT attention reads V row-major (ds_read_b64_tr_b16) instead of a transposed, permuted copy: the same values
+    in the same MFMA k-slots, so the two paths agree bit for bit (trace_op_set_gemm_variant(116) = the transposed-V path)."""
+    q, k, v = rnd(3, 577, 16, 64, seed=4), rnd(3, 577, 16, 64, seed=5), rnd(3, 577, 16, 64, seed=6)
+    a = ops.attention(q, k, v, False, 0.125)
+    try:
+        ops.set_gemm_variant(116)
+        b = ops.attention(q, k, v, False, 0.125)
+    finally:
+        ops.set_gemm_variant(110)
+    assert torch.equal(a, b)
+    check("attn vit 577 keys", a, _attn_ref(q, k, v, False, 0.125), 2e-2, 2e-2)
+
+
 def test_attention_vit_spiked_scores():
     # forces large running-max jumps between kv tiles (online-softmax rescale path)
     Bn, n, heads = 1, 200, 2

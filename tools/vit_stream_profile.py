@@ -4,7 +4,9 @@ of exactly the launch shape bench.py brackets with HIP events (`roofline.avg_lau
 import dataclasses, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trace_amd import config as tcfg, synth
-from trace_amd.engine import TraceEngine
+from trace_amd.engine import TraceEngine, ops
+if os.environ.get("TRACE_ATTN_TRANSPOSED_V"):
+    ops.set_gemm_variant(116)          # A/B: the round-2 path (transpose_v + permuted V^T) instead of row-major V through LDS transpose reads
 cfg = dataclasses.replace(tcfg.trace_7b(128), num_hidden_layers=1)
 eng = TraceEngine(cfg, max_batch=2, max_ctx=2304, max_frames=128, max_new_tokens=8)
 eng.load_weights(synth.iter_weights(cfg, device="cuda:0"))

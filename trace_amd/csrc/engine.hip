@@ -82,6 +82,7 @@ struct trace_ctx {
     void* pp_buf = nullptr; size_t pp_bytes = 0;       // frame preprocessing: tap tables + staged rows (grow-only)
     float* sk_ws = nullptr; unsigned int* sk_tickets = nullptr; size_t sk_ws_floats = 0; int sk_ntickets = 0;   // decode GEMV K-chunk partials
     float* part_val; int32_t* part_idx;
+    float* hl_val; int32_t* hl_idx;        // trace_llm_head_logits' own partial buffers
     int32_t *d_slots, *d_pos, *d_heads, *d_done, *d_out_ids, *d_out_len, *d_step, *d_forced, *d_params;
     int32_t* d_heads_tmp;                // head id per row for trace_llm_head_logits
     int B = 0, max_new = 0, eos = -1, has_forced = 0, ntiles = 0, nsplit = 32;
@@ -240,13 +241,23 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
         f = std::max(f, skinny_ws_floats(2 * I, H, EPI_SWIGLU));
         f = std::max(f, skinny_ws_floats(2 * I, H, EPI_PARTIAL));
         f = std::max(f, skinny_ws_floats(H, I, EPI_PARTIAL));
+        if (c->fp8)      // the fp8 GEMV picks its own K-chunk count (128-k units): size the partial rows for it as well
+            for (int B : {1, 16, 17, 32, 33, 64}) {
+                f = std::max(f, (size_t)skinny_fp8_ks(c->QKV, (int)H, B) * SK_ROWS * c->QKV);
+                f = std::max(f, (size_t)skinny_fp8_ks((int)H, (int)H, B) * SK_ROWS * H);
+                f = std::max(f, (size_t)skinny_fp8_ks(2 * (int)I, (int)H, B) * SK_ROWS * 2 * I);
+                f = std::max(f, (size_t)skinny_fp8_ks((int)H, (int)I, B) * SK_ROWS * H);
+            }
         c->sk_ws_floats = std::max<size_t>(f, 64);
         c->sk_ntickets = (int)std::max<size_t>(std::max<size_t>((size_t)c->QKV, (size_t)H), (size_t)(2 * I)) / 16;
         A(c->sk_ws, c->sk_ws_floats); A(c->sk_tickets, c->sk_ntickets);
     }
     c->ntiles = c->NVpad / 16;
     A(c->part_val, (size_t)SK_ROWS * c->ntiles); A(c->part_idx, (size_t)SK_ROWS * c->ntiles);
-    A(c->d_heads_tmp, SK_ROWS); A(c->d_slots, SK_ROWS); A(c->d_pos, SK_ROWS); A(c->d_heads, SK_ROWS); A(c->d_done, SK_ROWS); A(c->d_out_len, SK_ROWS); A(c->d_step, 4); A(c->d_params, 4);
+    // trace_llm_head_logits: its own arg-max partials and three constant head-id rows (all 0 / all 1 / all 2), so that it shares nothing with a
+    // decode batch in flight on another stream and needs no host copy or synchronisation per call
+    A(c->hl_val, (size_t)SK_ROWS * c->ntiles); A(c->hl_idx, (size_t)SK_ROWS * c->ntiles);
+    A(c->d_heads_tmp, 3 * SK_ROWS); A(c->d_slots, SK_ROWS); A(c->d_pos, SK_ROWS); A(c->d_heads, SK_ROWS); A(c->d_done, SK_ROWS); A(c->d_out_len, SK_ROWS); A(c->d_step, 4); A(c->d_params, 4);
     A(c->d_out_ids, (size_t)SK_ROWS * cfg->max_new_tokens); A(c->d_forced, (size_t)SK_ROWS * cfg->max_new_tokens);
 #undef A
     if (rc == TRACE_OK && hipHostMalloc((void**)&c->h_kind, Lm * 8) != hipSuccess) rc = fail(TRACE_ERR_HIP, "hipHostMalloc");
@@ -485,6 +496,11 @@ extern "C" int trace_ctx_finalize(trace_ctx* c) {
             LCHK(launch_tile_pack_fp8(l.wgu8, c->H, l.wgu8_d, 2 * c->I, c->H, 0));
             LCHK(launch_tile_pack_fp8(l.wd8, c->I, l.wd8_d, c->H, c->I, 0));
         }
+    }
+    {
+        int32_t h[3 * SK_ROWS];
+        for (int i = 0; i < 3 * SK_ROWS; ++i) h[i] = i / SK_ROWS;
+        HIPCHK(hipMemcpy(c->d_heads_tmp, h, sizeof(h), hipMemcpyHostToDevice));
     }
     // ticket counters of the persistent GEMM for the streams this context launches on by itself (an allocation + a memset: not something to
     // meet inside a timed or captured region); a caller's own stream gets its counters at its first launch
@@ -896,13 +912,9 @@ extern "C" int trace_llm_head_logits(trace_ctx* c, const void* hidden, int R, in
     if (!hidden || !logits_out || R < 1) return fail(TRACE_ERR_ARG, "bad hidden / logits_out / R");
     if (head < 0 || head > 2) return fail(TRACE_ERR_ARG, "head must be 0, 1 or 2");
     hipStream_t s = (hipStream_t)stream;
-    int32_t h[SK_ROWS];
-    for (int i = 0; i < SK_ROWS; ++i) h[i] = head;
-    HIPCHK(hipMemcpyAsync(c->d_heads_tmp, h, sizeof(h), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
     const bf16_t* x = (const bf16_t*)hidden;
     for (int r0 = 0; r0 < R; r0 += SK_ROWS)
-        LCHK(launch_head_logits(x + (size_t)r0 * c->H, c->H, c->wheads, c->H, c->d_heads_tmp, c->V, c->Tv, c->Sv, c->part_val, c->part_idx,
+        LCHK(launch_head_logits(x + (size_t)r0 * c->H, c->H, c->wheads, c->H, c->d_heads_tmp + head * SK_ROWS, c->V, c->Tv, c->Sv, c->hl_val, c->hl_idx,
                                 logits_out + (size_t)r0 * c->NV, std::min(SK_ROWS, R - r0), s));
     return TRACE_OK;
 }

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void slot_pool_part_kernel(const bf16_t* __res
     const int H2 = D >> 1, NL = D >> 4;          // lane l < NL owns d in [8l, 8l+8) and H2 + [8l, 8l+8): the RoPE pairs (d, d + H2)
     float* s_logit = reinterpret_cast<float*>(smem);                  // [RP][8]
     float* s_stat = s_logit + (size_t)RP * NS;                        // [RP][2] mean, rstd
-    float* s_red = s_stat + (size_t)RP * 2;                           // [8] local max
+    float* s_red = s_stat + (size_t)((RP + 1) & ~1) * 2;              // [8] local max (RP rounded up to even: s_res below is read as float4)
     float* s_res = s_red + 16;                                        // [8][D]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = blockIdx.x, t = blockIdx.y;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void slot_pool_part_kernel(const bf16_t* __res
                 sp[j][2 * q + 1] = (A[q] >> 16) | (Bv[q] & 0xffff0000u);
             }
         }
-        RowIn nxt = load_row(p_beg + min(wid, max(np - 1, 0)));
+        RowIn nxt = load_row(min(p_beg + min(wid, max(np - 1, 0)), n - 1));   // (an empty part — p_beg >= n — preloads a valid row it never uses)
         for (int i = wid; i < np; i += 4) {
             const RowIn cur = nxt;
             if (i + 4 < np) nxt = load_row(p_beg + i + 4);
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void slot_pool_part_kernel(const bf16_t* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e) { a1[k][e] = f2_t{0.f, 0.f}; a2[k][e] = f2_t{0.f, 0.f}; }
     if (on) {
-        RowIn nxt = load_row(p_beg + min(wid, max(np - 1, 0)));
+        RowIn nxt = load_row(min(p_beg + min(wid, max(np - 1, 0)), n - 1));   // (an empty part — p_beg >= n — preloads a valid row it never uses)
         for (int i = wid; i < np; i += 4) {
             const RowIn cur = nxt;
             if (i + 4 < np) nxt = load_row(p_beg + i + 4);
@@ -237,7 +237,7 @@ int launch_slot_pool(const bf16_t* feats, long frame_stride, int row_stride, con
     if (S != NS || D % 16 || D > 1024 || T <= 0 || n <= 0 || (row_stride % 8)) return TRACE_ERR_ARG;
     if (!ws || ws_floats < launch_slot_pool_ws_floats(T, D)) return TRACE_ERR_ARG;
     const int RP = (n + NPART - 1) / NPART;
-    const size_t lds = (size_t)RP * NS * 4 + (size_t)RP * 8 + 64 + (size_t)NS * D * 4;
+    const size_t lds = (size_t)RP * NS * 4 + (size_t)((RP + 1) & ~1) * 8 + 64 + (size_t)NS * D * 4;
     if (lds > 160 * 1024) return TRACE_ERR_ARG;
     static size_t set_for = 0;
     if (lds > set_for) {

@@ -255,10 +255,19 @@ class TraceMistralForCausalLM:
         logits = torch.stack(rows, 0)
         if heads is None:
             logits = logits[..., : cfg.vocab_size + 1]
-        # arm the decode form: token selection stays with the caller (host mode), the cache stays in the engine
-        eng.host_mode(True)
-        eng.decode_begin(list(range(B)), hd, eng.max_new_tokens, eos=-1)
-        self._live_kv = _KVHandle(B)
+        # arm the decode form: token selection stays with the caller (host mode), the cache stays in the engine.  The number of steps the
+        # KV slots still have room for bounds the arming; a prompt that fills the context gets its logits and no decode form
+        # (past_key_values=None) instead of an error after all the work is done.
+        room = min(eng.max_new_tokens, eng.max_ctx - logits.shape[1])
+        self._live_kv = None
+        if room >= 1:
+            eng.host_mode(True)
+            try:
+                eng.decode_begin(list(range(B)), hd, room, eos=-1)
+            except Exception:
+                eng.host_mode(False)
+                raise
+            self._live_kv = _KVHandle(B)
         return SimpleNamespace(logits=logits, past_key_values=self._live_kv, loss=None, hidden_states=None, attentions=None)
 
     __call__ = forward

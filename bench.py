@@ -101,9 +101,9 @@ def mr_schedule(cfg, n_new, seed):
 
 # BASELINE.json configs with a GPU workload (C1 is the reference's CPU plumbing case, C3 = C2 under --gpus 8)
 CONFIGS = {
-    "c2": dict(frames=128, max_new=256, n_text=176, video_pos=150, schedule="dvc", videos_per_step=64,
+    "c2": dict(frames=128, max_new=256, n_text=176, video_pos=150, schedule="dvc", videos_per_step=128,
                name="C2: TRACE-7B bf16 (CLIP-ViT-L/14-336 23 layers + SpatialSlotPool + Mistral-7B)"),
-    "c4": dict(frames=64, max_new=32, n_text=191, video_pos=150, schedule="mr", videos_per_step=64,
+    "c4": dict(frames=64, max_new=32, n_text=191, video_pos=150, schedule="mr", videos_per_step=128,
                name="C4: Charades-STA moment retrieval shape, TRACE-7B bf16"),
     "c5": dict(frames=256, max_new=16, n_text=251, video_pos=200, schedule="dvc", videos_per_step=32, fp8=True,
                name="C5: VideoMME long video (256 frames, past MAX_FRAMES), TRACE-7B, fp8 (e4m3 W8A8) decoder projections"),
@@ -308,7 +308,18 @@ def main():
                          "avg_launch_ms": g_ms, "samples": g_n},
         }
         # dominant HBM-bound kernel of the decode phase
-        line["roofline_hbm"] = {"bound": "hbm", "kernel": "skinny_lds_kernel<EPI_PARTIAL,NB,NT=2> (decode gate|up GEMV, 1 bracketed launch per decode step)",
+        # whole decode step: algorithmic bytes = the decoder weights once + the heads on the steps that stream them (not counted) + every sequence's KV rows
+        kv_step = B * (Ls + n_new / 2.0) * cfg.num_key_value_heads * 128 * 2 * 2 * cfg.num_hidden_layers
+        w_step = 2.0 * cfg.num_hidden_layers * (cfg.hidden_size * (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * 128 + cfg.hidden_size * cfg.hidden_size
+                                                 + 3 * cfg.hidden_size * cfg.intermediate_size) * (0.5 if args.fp8 else 1.0)
+        line["decode_step"] = {"algorithmic_gb": (kv_step + w_step) / 1e9, "weights_gb": w_step / 1e9, "kv_gb": kv_step / 1e9,
+                               "tb_per_s": (kv_step + w_step) / (t_dec / (n_new - 1) * 1e-3) / 1e12, "gb_per_token": (kv_step + w_step) / B / 1e9}
+        hbm_kernel = ("attn_decode_kernel (decode attention over the batch's KV cache, layer 0, 1 bracketed launch per decode step; wide decode step: "
+                      "projections as small-M MFMA GEMMs)" if B > 64 else
+                      "skinny_lds_kernel<EPI_PARTIAL,NB,NT=2> (decode gate|up GEMV, 1 bracketed launch per decode step)")
+        if B > 64:
+            traffic = None                                  # the committed PMC pass measured the GEMV
+        line["roofline_hbm"] = {"bound": "hbm", "kernel": hbm_kernel,
                                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
                                 "traffic": traffic, "algorithmic_bytes_per_launch": k_bytes, "avg_launch_ms": k_ms, "samples": k_n}
         if world > 1:

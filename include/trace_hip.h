@@ -159,10 +159,15 @@ int trace_op_attention(const void* Q, const void* K, const void* V, void* O, voi
                        int kv_heads, int nq, int nkv, int head_dim, int causal, float scale, void* stream);
 /* Decode GEMV out[b,n] = sum_k X[b,k] W[n,k], B <= 64.  w_tiled: W in the decode tile layout written by
    trace_op_tile_pack ([N/16][K/64][64][16]) instead of row-major.  epilogue 0 none, 1 +R, 3 SwiGLU (16-row interleaved
-   gate|up), 4 partial: `out` = fp32 k-chunk partial rows [trace_op_skinny_ks()][64][N] for trace_op_add_rmsnorm. */
+   gate|up), 4 partial: `out` = fp32 k-chunk partial rows [trace_op_skinny_ks()][trace_op_sk_rows()][N] for trace_op_add_rmsnorm. */
 int trace_op_skinny_gemm(const void* X, const void* W, void* out, const void* R, int B, int N, int K, int epilogue,
                          int w_tiled, void* stream);
 int trace_op_skinny_ks(int N, int K, int epilogue, int B);
+int trace_op_sk_rows(void);                 /* row stride of every fp32 partial-row buffer = the largest decode batch (128) */
+/* Decode batches above 64 rows: out = X[M <= 128, K] . W[N, K]^T (row-major W) as fp32 k-chunk partial rows
+   [trace_op_gemm_partial_ks(N, K)][trace_op_sk_rows()][N] for trace_op_add_rmsnorm (split-K MFMA GEMM, 128x128 tiles) */
+int trace_op_gemm_partial_ks(int N, int K);
+int trace_op_gemm_partial(const void* A, const void* W, float* part, int M, int N, int K, void* stream);
 int trace_op_tile_pack(const void* W, void* Wt, int N, int K, void* stream);
 /* fp8 path pieces: row quantiser (X bf16 [rows,K] -> e4m3 bytes + scale[row] = amax/448), the W8A8 GEMM
    C = (A8 . W8^T) * sa[m] * sw[n] (+ residual / SwiGLU epilogue as trace_op_gemm), and the decode GEMV (fp32 out [B,N]) */

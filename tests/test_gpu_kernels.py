@@ -238,6 +238,25 @@ def test_skinny_gemm(Bn, N, K):
         check("add_rmsnorm", y, yr, 2e-2, 1e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 6144, 4096), (100, 4096, 4096), (65, 4096, 14336), (128, 4096, 256), (77, 512, 4096)])
+def test_gemm_partial_rows(M, N, K):
+    """Decode batches above 64 rows: the split-K MFMA GEMM leaves fp32 k-chunk partial rows [ks][sk_rows][N]; their sum is the product,
+    and the decode consumer (sum + residual + RMSNorm) takes them exactly as it takes the GEMV's."""
+    X, W = rnd(M, K, seed=3), rnd(N, K, scale=0.05, seed=4)
+    part = ops.gemm_partial(X, W)
+    lin = X.float() @ W.float().t()
+    assert part.shape[1] == 128 and part.shape[0] >= 1
+    check("partial gemm", part[:, :M].sum(0), lin, 3e-2, 1e-2)
+    assert float(part[:, M:].abs().max()) == 0.0 if M < 128 else True          # rows beyond M are never written
+    if N <= 4096:
+        R, w = rnd(M, N, seed=5), rnd(N, seed=6)
+        x, y = ops.add_rmsnorm(part, R, w, 1e-5)
+        xr = part[:, :M].sum(0).to(torch.bfloat16).float() + R.float()
+        check("partial gemm + add", x, xr, 3e-2, 1e-2)
+        xb = x.float()
+        check("partial gemm + rmsnorm", y, xb * torch.rsqrt((xb * xb).mean(-1, keepdim=True) + 1e-5) * w.float(), 4e-2, 2e-2)
+
+
 @pytest.mark.parametrize("Bn,ctxs", [(1, [80]), (3, [1, 200, 2047]), (2, [16, 17])])
 def test_attn_decode(Bn, ctxs):
     nq, nkv, max_ctx = 32, 8, 2048

@@ -189,11 +189,12 @@ def test_errors_are_python_exceptions(setup):
         eng.time_ids([[1.0], [2.0, 3.0]])       # unequal time-token length (trace_arch.py:285)
 
 
-@pytest.mark.parametrize("nb", [20, 40, 64])
+@pytest.mark.parametrize("nb", [20, 40, 64, 65, 100, 128])
 def test_big_batch_equals_single(setup, nb):
-    """B > 16 / B > 32 exercise the two- and four-group decode GEMV (NB = 2, 4) and the second head pass: nb sequences
-    (two distinct videos, alternating) must reproduce the B = 1 streams — through the captured hipGraph (one per batch size,
-    up to the 64-row maximum) and through eager launches."""
+    """B > 16 / B > 32 exercise the two- and four-group decode GEMV (NB = 2, 4) and the second head pass; B > 64 the wide decode step
+    (projections as small-M MFMA GEMMs: gate|up with the SwiGLU epilogue, qkv / o / down as split-K partial rows; four head passes at
+    128): nb sequences (two distinct videos, alternating) must reproduce the B = 1 streams — through the captured hipGraph (one per
+    batch size, up to the 128-row maximum) and through eager launches."""
     cfg, eng, ora, E, frames = setup
     f2 = synth.synth_frames(cfg, 1).to(torch.bfloat16)
     ts, ids = E["timestamps"].tolist(), E["input_ids"].tolist()
@@ -314,7 +315,7 @@ def test_real_width_decoder_layer_vs_reference_fixture(golden_dir):
     import dataclasses
     cfg = dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336, num_hidden_layers=1)
     M = np.load(os.path.join(golden_dir, "medium_llm.npz"))
-    eng = TraceEngine(cfg, max_batch=40, max_ctx=192, max_frames=4, max_new_tokens=64)
+    eng = TraceEngine(cfg, max_batch=128, max_ctx=192, max_frames=4, max_new_tokens=64)
     eng.load_weights(synth.state_dict(cfg).items())
     frames = synth.synth_frames(cfg, 0).to(torch.bfloat16)
     forced, ref_lg, ref_ids = M["forced_ids"].tolist(), torch.from_numpy(M["tf_logits"]), M["tf_argmax"].tolist()
@@ -322,7 +323,7 @@ def test_real_width_decoder_layer_vs_reference_fixture(golden_dir):
     fin = torch.isfinite(ref_lg)
     srt = torch.sort(torch.where(fin, ref_lg, torch.full_like(ref_lg, -1e30)), dim=-1, descending=True).values
     margin = (srt[:, 0] - srt[:, 1]).tolist()
-    for nb in (1, 20, 40):
+    for nb in (1, 20, 40, 128):        # 128: the wide decode step (K = 14336 down-projection as an 8-chunk split-K GEMM, fused-SwiGLU gate|up GEMM)
         for b in range(nb):
             eng.encode_video(frames, M["timestamps"].tolist())
             eng.prefill(b, eng.splice(M["input_ids"].tolist()))
@@ -349,7 +350,7 @@ def test_deep_real_width_stack_vs_reference_fixture(golden_dir):
     import dataclasses
     cfg = dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336, num_hidden_layers=8)
     M = np.load(os.path.join(golden_dir, "deep_llm.npz"))
-    eng = TraceEngine(cfg, max_batch=40, max_ctx=192, max_frames=4, max_new_tokens=64)
+    eng = TraceEngine(cfg, max_batch=100, max_ctx=192, max_frames=4, max_new_tokens=64)
     eng.load_weights(synth.iter_weights(cfg))
     frames = synth.synth_frames(cfg, 0).to(torch.bfloat16)
     forced, ref_lg, ref_ids = M["forced_ids"].tolist(), torch.from_numpy(M["tf_logits"]), M["tf_argmax"].tolist()
@@ -357,7 +358,7 @@ def test_deep_real_width_stack_vs_reference_fixture(golden_dir):
     fin = torch.isfinite(ref_lg)
     srt = torch.sort(torch.where(fin, ref_lg, torch.full_like(ref_lg, -1e30)), dim=-1, descending=True).values
     margin = (srt[:, 0] - srt[:, 1]).tolist()
-    for nb in (1, 40):
+    for nb in (1, 40, 100):            # 100: the wide decode step (batches above 64) through eight layers
         for b in range(nb):
             eng.encode_video(frames, M["timestamps"].tolist())
             eng.prefill(b, eng.splice(M["input_ids"].tolist()))

@@ -916,7 +916,7 @@ static int skinny_lds_launch(const SkinnyPlan& p, const bf16_t* X, int ldx, cons
 int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R, int ldr,
                        int B, int N, int K, int epi, int tiled, float* ws, size_t ws_floats, unsigned int* tickets, int ntickets,
                        hipStream_t s) {
-    if (B < 1 || B > SK_ROWS || K % 64 || (ldx % 8) || (ldw % 8) || (ldo % 4)) return TRACE_ERR_ARG;
+    if (B < 1 || B > SKINNY_ROWS || K % 64 || (ldx % 8) || (ldw % 8) || (ldo % 4)) return TRACE_ERR_ARG;
     if (epi != EPI_NONE && epi != EPI_RESIDUAL && epi != EPI_SWIGLU && epi != EPI_PARTIAL) return TRACE_ERR_ARG;
     if (N % (epi == EPI_SWIGLU ? 32 : 16) || (epi == EPI_RESIDUAL && (!R || ldr % 4))) return TRACE_ERR_ARG;
     const SkinnyPlan p = skinny_plan(N, K, epi, B);

@@ -90,6 +90,9 @@ struct trace_ctx {
     int fp8 = 0;                       // decoder projections on the fp8 path
     uint8_t *pA8 = nullptr, *dA8 = nullptr, *dH8 = nullptr;      // quantised activations: prefill [2 max_ctx][max(H, I)], decode [64][I]; dH8 = the normed hidden rows
     float *psa = nullptr, *dsa = nullptr, *dsh = nullptr;        // their per-row scales
+    int step_in_call = 0;              // decode steps taken since trace_decode_begin at the time decode_step runs (host copy)
+    long pos_sum = 0;                  // sum over the batch of the prefill lengths (host copy: algorithmic KV bytes of a decode step's attention)
+    double kbytes_sum = 0.0;           // algorithmic bytes of the bracketed launches (profile == 2)
     int host_mode = 0, fed = 0;        // host-driven token selection (sampling): head logits only, ids fed back by the host
     int steps_done = 0;                // decode steps taken since trace_decode_begin (bounded by max_new - 1: the KV slot and the RoPE tables end at max_ctx)
     hipGraphExec_t graphs[SK_ROWS + 1] = {nullptr};   // one captured decode step per batch size
@@ -248,6 +251,10 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
                 f = std::max(f, (size_t)skinny_fp8_ks(2 * (int)I, (int)H, B) * SK_ROWS * 2 * I);
                 f = std::max(f, (size_t)skinny_fp8_ks((int)H, (int)I, B) * SK_ROWS * H);
             }
+        // batches above SKINNY_ROWS: the split-K partial-row GEMM's chunks (qkv, o, down)
+        f = std::max(f, (size_t)gemm_partial_ks(c->QKV, (int)H) * SK_ROWS * c->QKV);
+        f = std::max(f, (size_t)gemm_partial_ks((int)H, (int)H) * SK_ROWS * H);
+        f = std::max(f, (size_t)gemm_partial_ks((int)H, (int)I) * SK_ROWS * H);
         c->sk_ws_floats = std::max<size_t>(f, 64);
         c->sk_ntickets = (int)std::max<size_t>(std::max<size_t>((size_t)c->QKV, (size_t)H), (size_t)(2 * I)) / 16;
         A(c->sk_ws, c->sk_ws_floats); A(c->sk_tickets, c->sk_ntickets);
@@ -948,6 +955,55 @@ static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* l
 // B=32 1 -> 45 us; B=32 with 16 splits: 79 us)
 static int decode_nsplit(int B) { const int n = (40 + B / 2) / B; return n < 1 ? 1 : n > 16 ? 16 : n; }
 
+static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* logits_out, hipStream_t s);
+
+// One decode step for SKINNY_ROWS < B <= SK_ROWS sequences.  A GEMV that parks its activations in LDS cannot hold more than 64 rows x 1024 k, and
+// its fp32 partial rows would grow with the row count; above 64 rows the four projections are small-M GEMMs on the MFMA tile kernel instead
+// (gemm.hip, 128x128 tiles, weights from the row-major prefill copies): gate|up with the SwiGLU epilogue straight to bf16 — no partial rows,
+// no combine kernel — and qkv / o / down cut along K into gemm_partial_ks() chunks whose fp32 partial rows the same consumers as below sum on
+// load.  The weights (14 GB per step) are then streamed once per 128 tokens instead of once per 64: bytes per token 0.50 -> 0.39 GB at
+// ctx ~2100, where the KV stream (0.27 GB per token) is the larger part.
+static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
+    const int H = c->H, I = c->I, HD = c->HD, QKV = c->QKV, B = c->B;
+    if (c->fp8) return fail(TRACE_ERR_STATE, "the fp8 weight path decodes at most 64 sequences together");
+    const int ks_q = gemm_partial_ks(QKV, H), ks_o = gemm_partial_ks(H, H), ks_d = gemm_partial_ks(H, I);
+    auto pgemm = [&](const bf16_t* A, int lda, const bf16_t* W, int ldw, int N, int K, int ks) -> int {
+        GemmArgs g{A, lda, W, ldw, nullptr, 0, nullptr, nullptr, 0, B, N, K, nullptr, 0, nullptr, nullptr, 0, c->sk_ws, ks};
+        if ((size_t)ks * SK_ROWS * N > c->sk_ws_floats) return fail(TRACE_ERR_STATE, "partial-row workspace too small");
+        const int rc = launch_gemm_bf16(g, EPI_PARTIAL, s);
+        if (rc != TRACE_OK) return fail(rc, "partial GEMM launch failed (N=" + std::to_string(N) + " K=" + std::to_string(K) + ")");
+        return TRACE_OK;
+    };
+    LCHK(launch_rmsnorm(c->dX, H, c->dH, H, c->llm[0].rms1, B, H, c->c.rms_eps, s));
+    for (int l = 0; l < c->NL; ++l) {
+        const LlmLayer& W = c->llm[l];
+        bf16_t* kc = c->kcache + (size_t)l * c->layer_stride;
+        bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
+        TRY(pgemm(c->dH, H, W.wqkv, H, QKV, H, ks_q));
+        LCHK(launch_qkv_finish(c->sk_ws, ks_q, QKV, c->dQKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots,
+                               c->d_pos, B, c->NQ, c->NKV, c->rope_cos, c->rope_sin, s));
+        // roofline probe (profile == 2, eager launches): HIP events around ONE launch of the step's dominant kernel — the layer-0 decode
+        // attention, which streams the batch's whole KV cache of that layer
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (l == 0 && c->profile == 2 && s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) {
+            e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2;
+            c->kbytes_sum += (double)(c->pos_sum + (long)B * (c->step_in_call + 1)) * c->NKV * HD * 2 * 2;   // K + V^T rows of every sequence, bf16
+        }
+        if (e0) hipEventRecord(e0, s);
+        LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots, c->d_pos, c->dO,
+                                H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, decode_nsplit(B), 1.0f / sqrtf((float)HD), 0,
+                                nullptr, nullptr, nullptr, 0, s));
+        if (e1) hipEventRecord(e1, s);
+        TRY(pgemm(c->dO, H, W.wo, H, H, H, ks_o));
+        LCHK(launch_add_rmsnorm(c->sk_ws, ks_o, c->dX, H, c->dX, H, W.rms2, c->dH, H, B, H, c->c.rms_eps, s));
+        TRY(gemm(c->dH, H, W.wgu, H, c->dACT, I, nullptr, nullptr, 0, B, 2 * I, H, EPI_SWIGLU, s));
+        TRY(pgemm(c->dACT, I, W.wd, I, H, I, ks_d));
+        const bf16_t* nw = l + 1 < c->NL ? c->llm[l + 1].rms1 : c->final_norm;
+        LCHK(launch_add_rmsnorm(c->sk_ws, ks_d, c->dX, H, c->dX, H, nw, c->dH, H, B, H, c->c.rms_eps, s));
+    }
+    return head_and_select(c, c->dH, 1, logits_out, s);
+}
+
 int g_decode_unfused = 0;   // RoPE + cache append as a kernel of its own before the decode attention: 0 = from batch 32 up (bit-identical to the fused
                             // prologue, 1 % faster per 64-sequence step, one launch more — which batch 1 would feel), 1 = always, 2 = never
                             // (trace_op_set_gemm_variant(120 + x), tools/decode_ab.py)
@@ -957,6 +1013,7 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
     // Every GEMV leaves fp32 k-chunk partial rows in sk_ws and its consumer sums them on load (an in-kernel merge costs
     // 5-8 us of dependent round trips per GEMV): qkv -> attention (RoPE + cache append + attention) -> o -> [sum + residual
     // -> new residual, RMSNorm] -> gate|up -> [sum, SwiGLU] -> down -> [sum + residual, next layer's / the final RMSNorm].
+    if (B > SKINNY_ROWS) return decode_step_wide(c, logits_out, s);
     const bool f8 = c->fp8;
     const int ks_q = f8 ? skinny_fp8_ks(QKV, H, B) : skinny_ks(QKV, H, EPI_PARTIAL, B), ks_o = f8 ? skinny_fp8_ks(H, H, B) : skinny_ks(H, H, EPI_PARTIAL, B);
     const int ks_g = f8 ? skinny_fp8_ks(2 * I, H, B) : skinny_ks(2 * I, H, EPI_PARTIAL, B), ks_d = f8 ? skinny_fp8_ks(H, I, B) : skinny_ks(H, I, EPI_PARTIAL, B);
@@ -1014,7 +1071,7 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
 extern "C" int trace_decode_begin(trace_ctx* c, const int32_t* slots, int B, const int32_t* heads, int max_new, int eos,
                                   const int32_t* forced, float* logits_out, void* stream) {
     if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
-    if (!slots || !heads || B < 1 || B > c->max_B || B > SK_ROWS) return fail(TRACE_ERR_ARG, "bad batch (at most 64 sequences decode together)");
+    if (!slots || !heads || B < 1 || B > c->max_B || B > (c->fp8 ? SKINNY_ROWS : SK_ROWS)) return fail(TRACE_ERR_ARG, "bad batch (at most " + std::to_string(c->fp8 ? SKINNY_ROWS : SK_ROWS) + " sequences decode together)");
     if (max_new < 1 || max_new > c->c.max_new_tokens) return fail(TRACE_ERR_ARG, "max_new exceeds capacity");
     hipStream_t s = (hipStream_t)stream;
     int32_t pos[SK_ROWS], zero[SK_ROWS] = {0};
@@ -1026,6 +1083,8 @@ extern "C" int trace_decode_begin(trace_ctx* c, const int32_t* slots, int B, con
         for (int b2 = 0; b2 < b; ++b2) if (slots[b2] == slots[b]) return fail(TRACE_ERR_ARG, "duplicate slot");
     }
     c->B = B; c->max_new = max_new; c->eos = eos; c->has_forced = forced != nullptr;
+    c->pos_sum = 0;
+    for (int b = 0; b < B; ++b) c->pos_sum += pos[b];
     HIPCHK(hipMemcpyAsync(c->d_slots, slots, B * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_pos, pos, B * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_heads, heads, B * 4, hipMemcpyHostToDevice, s));
@@ -1054,11 +1113,12 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
     if (c->steps_done + n > c->max_new - 1)
         return fail(TRACE_ERR_STATE, "decode steps exceed max_new - 1 since trace_decode_begin (" + std::to_string(c->steps_done) + " taken, " +
                                      std::to_string(n) + " requested, max_new " + std::to_string(c->max_new) + ")");
+    const int steps_before = c->steps_done;
     c->steps_done += n;
     hipStream_t s = (hipStream_t)stream;
     if (c->profile) hipEventRecord(c->ev0, s);
     if (!use_graph) {
-        for (int i = 0; i < n; ++i) TRY(decode_step(c, logits_out, s));
+        for (int i = 0; i < n; ++i) { c->step_in_call = steps_before + i; TRY(decode_step(c, logits_out, s)); }
     } else {
         const int key = c->B;
         hipGraphExec_t* slot_g = &c->graphs[key];
@@ -1094,6 +1154,7 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
         c->prof[2] = c->ksamples ? (float)(c->ksum_ms / c->ksamples) : 0.f;
         c->prof[3] = (float)c->ksamples;
         c->prof[4] = (float)(2.0 * c->I * c->H * (c->fp8 ? 1.0 : 2.0));      // algorithmic bytes of the bracketed launch (gate|up weights; fp8: the bracket also spans the activation quantiser)
+        if (c->B > SKINNY_ROWS && c->ksamples) c->prof[4] = (float)(c->kbytes_sum / c->ksamples);   // wide step: the bracket is the layer-0 attention (its KV bytes, averaged)
     }
     return TRACE_OK;
 }
@@ -1169,7 +1230,7 @@ extern "C" int trace_set_gemm_cus(trace_ctx* c, int n) {
 
 extern "C" int trace_set_profile(trace_ctx* c, int on) {
     if (!c) return fail(TRACE_ERR_ARG, "null ctx");
-    c->profile = on; c->ksum_ms = 0.0; c->ksamples = 0; c->kev_used = 0; c->msum_ms = 0.0; c->msamples = 0; c->mM = 0;
+    c->profile = on; c->ksum_ms = 0.0; c->ksamples = 0; c->kev_used = 0; c->kbytes_sum = 0.0; c->msum_ms = 0.0; c->msamples = 0; c->mM = 0;
     return TRACE_OK;
 }
 extern "C" int trace_get_profile(trace_ctx* c, float* out, int n) {
@@ -1259,6 +1320,15 @@ extern "C" int trace_op_skinny_gemm(const void* X, const void* W, void* out, con
     return TRACE_OK;
 }
 extern "C" int trace_op_skinny_ks(int N, int K, int epilogue, int B) { return skinny_ks(N, K, epilogue, B); }
+extern "C" int trace_op_sk_rows(void) { return SK_ROWS; }
+// [M <= 128, K] x [N, K]^T as fp32 k-chunk partial rows [trace_op_gemm_partial_ks(N, K)][trace_op_sk_rows()][N] (decode batches above 64 rows)
+extern "C" int trace_op_gemm_partial_ks(int N, int K) { return gemm_partial_ks(N, K); }
+extern "C" int trace_op_gemm_partial(const void* A, const void* W, float* part, int M, int N, int K, void* stream) {
+    GemmArgs g{(const bf16_t*)A, K, (const bf16_t*)W, K, nullptr, 0, nullptr, nullptr, 0, M, N, K, nullptr, 0, nullptr, nullptr, 0, part, gemm_partial_ks(N, K)};
+    const int rc = launch_gemm_bf16(g, EPI_PARTIAL, (hipStream_t)stream);
+    if (rc != TRACE_OK) return fail(rc, "partial GEMM launch failed");
+    return TRACE_OK;
+}
 // ---- fp8 path hooks (tests/test_gpu_fp8.py) ----
 extern "C" int trace_op_quant_rows_fp8(const void* X, void* X8, float* sx, int rows, int K, void* stream) {
     LCHK(launch_quant_rows_fp8((const bf16_t*)X, K, (uint8_t*)X8, K, sx, rows, K, (hipStream_t)stream));

@@ -291,7 +291,7 @@ int skinny_fp8_ks(int N, int K, int B) { return fp8_plan(N, K, B).KS; }
 // partial rows [skinny_fp8_ks()][SK_ROWS][N] fp32 in ws (>= KS * SK_ROWS * N floats): the consumers of decode.hip sum them
 int launch_skinny_fp8(const uint8_t* X8, long ldx, const float* sx, const uint8_t* Wtiled, const float* sw, int B, int N, int K, float* ws,
                       size_t ws_floats, hipStream_t s) {
-    if (B < 1 || B > SK_ROWS || K % 128 || N % 16 || (ldx % 16)) return TRACE_ERR_ARG;
+    if (B < 1 || B > SKINNY_ROWS || K % 128 || N % 16 || (ldx % 16)) return TRACE_ERR_ARG;
     const Fp8Plan p = fp8_plan(N, K, B);
     if (!ws || ws_floats < (size_t)p.KS * SK_ROWS * N) return TRACE_ERR_ARG;
 #define FL(NT_) (B <= 16 ? fp8_launch<1, NT_>(p, X8, ldx, sx, Wtiled, sw, B, N, K, ws, s) \

@@ -7,6 +7,8 @@
 // applied in fp32 registers first, the residual is added at the coalesced stage).
 // Two tile shapes: 256x256 (1 workgroup/CU) for the big ViT / gate|up GEMMs — run by gemm_ldr.hip's loader-wave version of this
 // file's kernel since the end of round 1 — and 128x128 (4 waves) when a 256-tiling would leave CUs idle (LLM prefill M ~ 2k with N = 4096).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -76,7 +78,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     const int r = lane & 15, g = lane >> 4;
     const int wm = wid / WN, wn = wid % WN;
     const int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM;
-    int t = xcd_remap(blockIdx.x, ntm * ntn);
+    // EPI_PARTIAL: blockIdx = chunk * tiles + tile — the tiles of one K-chunk are neighbours, so the 8 XCDs stream 8 different weight panels
+    const int kchunk = EPI == EPI_PARTIAL ? blockIdx.x / (ntm * ntn) : 0;
+    int t = xcd_remap(EPI == EPI_PARTIAL ? blockIdx.x - kchunk * (ntm * ntn) : blockIdx.x, ntm * ntn);
     int tm, tn;
     {
         constexpr int GM = 8;
@@ -153,9 +157,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) woff[j] = swz(wn * (BN / WN) + j * 16 + r, g);
 
-    const int nk = p.K * ESZ / 128;
-    issue_a(0); issue_w(0);
-    for (int kt = 0; kt < nk; ++kt) {
+    const int nk_all = p.K * ESZ / 128;
+    const int kt0 = EPI == EPI_PARTIAL ? kchunk * (nk_all / p.ks) : 0;
+    const int nk = EPI == EPI_PARTIAL ? kt0 + nk_all / p.ks : nk_all;          // this workgroup's K-tiles [kt0, nk)
+    issue_a(kt0); issue_w(kt0);
+    for (int kt = kt0; kt < nk; ++kt) {
         __syncthreads();                                   // tile kt landed (vmcnt(0) + barrier); everyone is done with tile kt-1
         if (tr && kt == 0 && threadIdx.x == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
         if (!SPREAD && kt + 1 < nk) { issue_a(kt + 1); issue_w(kt + 1); }
@@ -194,6 +200,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
                 if (ip + 1 < TM / 2) { ac[0] = an[0]; ac[1] = an[1]; }
             }
         }
+    }
+    if constexpr (EPI == EPI_PARTIAL) {
+        // fp32 accumulators straight to the chunk's partial rows: lane (r, g) holds 4 consecutive columns of row wm*.. + i*16 + r
+        float* pr = p.part + (size_t)kchunk * SK_ROWS * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (BM / WM) + i * 16 + r;
+            if (m < p.M) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    *reinterpret_cast<f32x4_t*>(pr + (size_t)m * p.N + n0 + wn * (BN / WN) + j * 16 + g * 4) = acc[i][j];
+            }
+        }
+        return;
     }
     constexpr int OUTW = GLU ? BN / 2 : BN;
     constexpr int CPR = OUTW / 8;
@@ -324,7 +344,31 @@ int g_gemm_variant = 0;   // 0 = auto, 2 = 128^2 tiles, 3 = this file's 256^2 ke
                           // (gemm_pers.hip; 6 = static tile deal) — tests / microbench
 extern int g_gemm_pers_static;
 
+// split-K partial-row GEMM for decode batches above SKINNY_ROWS: M <= 128 rows (one row panel), 128x128 tiles, ks chunks of K
+static int launch_partial(const GemmArgs& p, hipStream_t s) {
+    constexpr int STAGE = (128 + 128) * 128, LDSB = 2 * STAGE;
+    if (p.M < 1 || p.M > 128 || p.M > SK_ROWS || p.N % 128 || p.K % BK || p.fp8 || !p.part || p.ks < 1 || (p.K / BK) % p.ks) return TRACE_ERR_ARG;
+    if ((p.lda % 8) || (p.ldw % 8)) return TRACE_ERR_ARG;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<128, 128, 2, 2, EPI_PARTIAL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, EPI_PARTIAL, false>), dim3((p.N / 128) * p.ks), dim3(256), LDSB, s, p);
+    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+}
+// K-chunks for the partial-row GEMM: enough workgroups ((N / 128) x ks) to put at least one on every CU, chunks of whole K-tiles, at least 4
+// K-tiles per chunk (a shorter K loop is all prologue).  TRACE_PARTIAL_WGS overrides the workgroup target (tuning runs).
+int gemm_partial_ks(int N, int K) {
+    static const int target = getenv("TRACE_PARTIAL_WGS") ? atoi(getenv("TRACE_PARTIAL_WGS")) : 256;
+    const int tiles = N / 128, nk = K / BK;
+    int ks = 1;
+    while (tiles * ks < target && nk % (ks * 2) == 0 && nk / (ks * 2) >= 4) ks *= 2;
+    return ks;
+}
+
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
+    if (epi == EPI_PARTIAL) return launch_partial(p, s);
     if (p.M <= 0 || p.N % BN || p.K % BK || p.K < BK) return TRACE_ERR_ARG;
     if (p.fp8 && (p.K % 128 || (p.lda % 16) || (p.ldw % 16) || !p.sa || !p.sw || p.bias || epi == EPI_QUICKGELU)) return TRACE_ERR_ARG;
     if ((p.lda % 8) || (p.ldw % 8) || (p.ldc % 8)) return TRACE_ERR_ARG;

@@ -5,7 +5,8 @@
 #include <stdint.h>
 #include "common.h"
 
-constexpr int SK_ROWS = 64;   // row stride of the decode GEMV's fp32 partial buffers [ks][SK_ROWS][N] = max decode batch
+constexpr int SK_ROWS = 128;     // largest decode batch = row stride of the fp32 k-chunk partial buffers [ks][SK_ROWS][N]
+constexpr int SKINNY_ROWS = 64;  // rows one skinny (activations-parked-in-LDS) GEMV takes; larger batches run the split-K MFMA GEMM (gemm.hip)
 enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_QUICKGELU = 2, EPI_SWIGLU = 3, EPI_PARTIAL = 4 };   // PARTIAL: decode GEMV only
 
 struct GemmArgs {
@@ -19,8 +20,13 @@ struct GemmArgs {
     // fp8 = 1: A and W point at e4m3 BYTES (lda / ldw in bytes, K % 128 == 0); C = (A8 . W8^T) * sa[m] * sw[n] (+ epilogue)
     int fp8; const float* sa; const float* sw;
     int opt;                        // A/B switches of a kernel (0 = shipped behaviour)
+    // EPI_PARTIAL (decode batches above SKINNY_ROWS, 128x128 tiles only): K is cut in `ks` equal chunks of whole K-tiles, one workgroup per
+    // (tile, chunk); chunk c leaves its fp32 accumulators in part[c][m][n] (row stride SK_ROWS x N) — the partial rows the decode consumers
+    // (qkv_finish, add_rmsnorm) sum on load.  C / bias / R unused.
+    float* part; int ks;
 };
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s);
+int gemm_partial_ks(int N, int K);                                // K-chunks launch_gemm_bf16(EPI_PARTIAL) should be given for an [<= 128, K] x [N, K]^T product
 int launch_gemm_ldr(const GemmArgs& p, int epi, hipStream_t s);    // gemm_ldr.hip: 256x256 tiles, 8 MFMA + 4 loader waves (N % 256 == 0)
 int launch_gemm_pers(const GemmArgs& p, int epi, hipStream_t s);   // gemm_pers.hip: the same tile, persistent workgroups, register epilogue (bf16, K >= 128)
 int gemm_pers_init(hipStream_t s);                                 // creates the (current device, stream) ticket counters ahead of its first launch (optional)

@@ -61,6 +61,11 @@ class TraceEngine:
         self._B = 0
         self._max_new = 0
 
+    @property
+    def decode_batch_max(self) -> int:
+        """sequences one decode batch can hold: the KV slots, at most 128 (64 on the fp8 weight path)"""
+        return min(self.max_batch, 64 if self.llm_fp8 else 128)
+
     @staticmethod
     def full_round_frames(cfg: TraceConfig) -> int:
         """Frames per ViT call when several videos are encoded together: the largest count whose token rows fill 384 row
@@ -371,8 +376,8 @@ class TraceEngine:
                  heads: Sequence[int], max_new_tokens: int, eos: int = -1, use_graph: bool = True,
                  forced: Optional[Sequence[Sequence[int]]] = None):
         B = len(videos)
-        if B > min(self.max_batch, 64):
-            raise ValueError(f"batch {B} exceeds the engine's decode batch {min(self.max_batch, 64)}")
+        if B > self.decode_batch_max:
+            raise ValueError(f"batch {B} exceeds the engine's decode batch {self.decode_batch_max}")
         self.encode_prefill(videos, timestamps, input_ids, 0)
         return self.decode(range(B), heads, max_new_tokens, eos, use_graph, forced)
 
@@ -424,7 +429,7 @@ class TraceEngine:
         with cf.ThreadPoolExecutor(max_workers=1, thread_name_prefix="trace-decode") as pool:
             for item in batches:
                 videos, timestamps, input_ids, heads, forced = item
-                if len(videos) > min(half, 64):
+                if len(videos) > min(half, self.decode_batch_max):
                     raise ValueError(f"batch of {len(videos)} exceeds max_batch // 2 = {half} (two KV banks)")
                 fut = pool.submit(dec_job, *pending) if pending is not None else None
                 try:
@@ -498,17 +503,27 @@ class ops:
 
     @staticmethod
     def skinny_gemm(X, W, R=None, epilogue=EPI_NONE, tiled=False, want_partial=True):
-        """decode GEMV; `tiled`: W was passed through tile_pack.  EPI_PARTIAL returns the fp32 partial rows [KS, 64, N]."""
+        """decode GEMV; `tiled`: W was passed through tile_pack.  EPI_PARTIAL returns the fp32 partial rows [KS, sk_rows, N]."""
         lib = _lib.load()
         Bn, K = X.shape
         N = W.shape[0]
         if epilogue == EPI_PARTIAL:
             ks = lib.trace_op_skinny_ks(N, K, epilogue, Bn)
-            out = torch.zeros((ks, 64, N), dtype=torch.float32, device=X.device) if want_partial else None
+            out = torch.zeros((ks, lib.trace_op_sk_rows(), N), dtype=torch.float32, device=X.device) if want_partial else None
         else:
             No = N // 2 if epilogue == EPI_SWIGLU else N
             out = torch.empty((Bn, No), dtype=torch.bfloat16, device=X.device)
         _lib.check(lib.trace_op_skinny_gemm(_ptr(X), _ptr(W), _ptr(out), _ptr(R), Bn, N, K, epilogue, int(tiled), _stream()))
+        return out
+
+    @staticmethod
+    def gemm_partial(X, W):
+        """decode batches above 64 rows: X [M <= 128, K] . W [N, K]^T as fp32 k-chunk partial rows [ks, sk_rows, N] (split-K MFMA GEMM)"""
+        lib = _lib.load()
+        M, K = X.shape
+        N = W.shape[0]
+        out = torch.zeros((lib.trace_op_gemm_partial_ks(N, K), lib.trace_op_sk_rows(), N), dtype=torch.float32, device=X.device)
+        _lib.check(lib.trace_op_gemm_partial(_ptr(X), _ptr(W), _ptr(out), M, N, K, _stream()))
         return out
 
     @staticmethod

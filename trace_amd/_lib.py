@@ -67,7 +67,8 @@ SIGNATURES = {
     "trace_op_skinny_ks": (I, [I, I, I, I]),
     "trace_op_sk_rows": (I, []),
     "trace_op_gemm_partial_ks": (I, [I, I]),
-    "trace_op_gemm_partial": (I, [P, P, P, I, I, I, P]),
+    "trace_op_gemm_partial": (I, [P, P, P, I, I, I, I, P]),
+    "trace_op_gemm_swiglu_tiled": (I, [P, P, P, I, I, I, I, P]),
     "trace_op_tile_pack": (I, [P, P, I, I, P]),
     "trace_op_quant_rows_fp8": (I, [P, P, P, I, I, P]),
     "trace_op_gemm_fp8": (I, [P, P, P, P, P, P, I, I, I, I, P]),

@@ -956,6 +956,8 @@ static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* l
 static int decode_nsplit(int B) { const int n = (40 + B / 2) / B; return n < 1 ? 1 : n > 16 ? 16 : n; }
 
 static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* logits_out, hipStream_t s);
+int g_decode_gemm_tiled = 3;   // wide decode step: 1 = weights from the decode tile copies, 3 = + non-temporal loads, 0 = row-major prefill copies (A/B:
+                               // trace_op_set_gemm_variant(130 + x))
 
 // One decode step for SKINNY_ROWS < B <= SK_ROWS sequences.  A GEMV that parks its activations in LDS cannot hold more than 64 rows x 1024 k, and
 // its fp32 partial rows would grow with the row count; above 64 rows the four projections are small-M GEMMs on the MFMA tile kernel instead
@@ -967,8 +969,9 @@ static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
     const int H = c->H, I = c->I, HD = c->HD, QKV = c->QKV, B = c->B;
     if (c->fp8) return fail(TRACE_ERR_STATE, "the fp8 weight path decodes at most 64 sequences together");
     const int ks_q = gemm_partial_ks(QKV, H), ks_o = gemm_partial_ks(H, H), ks_d = gemm_partial_ks(H, I);
-    auto pgemm = [&](const bf16_t* A, int lda, const bf16_t* W, int ldw, int N, int K, int ks) -> int {
-        GemmArgs g{A, lda, W, ldw, nullptr, 0, nullptr, nullptr, 0, B, N, K, nullptr, 0, nullptr, nullptr, 0, c->sk_ws, ks};
+    const int wt = g_decode_gemm_tiled;      // bit 0: weights from the decode tile copies, bit 1: non-temporal weight loads
+    auto pgemm = [&](const bf16_t* A, int lda, const bf16_t* Wrow, const bf16_t* Wtile, int ldw, int N, int K, int ks) -> int {
+        GemmArgs g{A, lda, (wt & 1) ? Wtile : Wrow, ldw, nullptr, 0, nullptr, nullptr, 0, B, N, K, nullptr, 0, nullptr, nullptr, 0, c->sk_ws, ks, (wt & 1) ? wt : 0};
         if ((size_t)ks * SK_ROWS * N > c->sk_ws_floats) return fail(TRACE_ERR_STATE, "partial-row workspace too small");
         const int rc = launch_gemm_bf16(g, EPI_PARTIAL, s);
         if (rc != TRACE_OK) return fail(rc, "partial GEMM launch failed (N=" + std::to_string(N) + " K=" + std::to_string(K) + ")");
@@ -979,7 +982,7 @@ static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
         const LlmLayer& W = c->llm[l];
         bf16_t* kc = c->kcache + (size_t)l * c->layer_stride;
         bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
-        TRY(pgemm(c->dH, H, W.wqkv, H, QKV, H, ks_q));
+        TRY(pgemm(c->dH, H, W.wqkv, W.wqkv_d, H, QKV, H, ks_q));
         LCHK(launch_qkv_finish(c->sk_ws, ks_q, QKV, c->dQKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots,
                                c->d_pos, B, c->NQ, c->NKV, c->rope_cos, c->rope_sin, s));
         // roofline probe (profile == 2, eager launches): HIP events around ONE launch of the step's dominant kernel — the layer-0 decode
@@ -994,10 +997,13 @@ static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
                                 H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, decode_nsplit(B), 1.0f / sqrtf((float)HD), 0,
                                 nullptr, nullptr, nullptr, 0, s));
         if (e1) hipEventRecord(e1, s);
-        TRY(pgemm(c->dO, H, W.wo, H, H, H, ks_o));
+        TRY(pgemm(c->dO, H, W.wo, W.wo_d, H, H, H, ks_o));
         LCHK(launch_add_rmsnorm(c->sk_ws, ks_o, c->dX, H, c->dX, H, W.rms2, c->dH, H, B, H, c->c.rms_eps, s));
-        TRY(gemm(c->dH, H, W.wgu, H, c->dACT, I, nullptr, nullptr, 0, B, 2 * I, H, EPI_SWIGLU, s));
-        TRY(pgemm(c->dACT, I, W.wd, I, H, I, ks_d));
+        if (wt & 1) {
+            GemmArgs g{c->dH, H, W.wgu_d, H, c->dACT, I, nullptr, nullptr, 0, B, 2 * I, H, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, wt};
+            if (launch_gemm_bf16(g, EPI_SWIGLU, s) != TRACE_OK) return fail(TRACE_ERR_HIP, "gate|up GEMM launch failed");
+        } else TRY(gemm(c->dH, H, W.wgu, H, c->dACT, I, nullptr, nullptr, 0, B, 2 * I, H, EPI_SWIGLU, s));
+        TRY(pgemm(c->dACT, I, W.wd, W.wd_d, I, H, I, ks_d));
         const bf16_t* nw = l + 1 < c->NL ? c->llm[l + 1].rms1 : c->final_norm;
         LCHK(launch_add_rmsnorm(c->sk_ws, ks_d, c->dX, H, c->dX, H, nw, c->dH, H, B, H, c->c.rms_eps, s));
     }
@@ -1256,6 +1262,7 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 100 && variant < 104) { g_attn_debug = variant - 100; return TRACE_OK; }
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
+    if (variant >= 130 && variant <= 133) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
     if (variant >= 400 && variant < 404) { g_gemm_ldr_opt = variant - 400; return TRACE_OK; }   // microbench: attention phase cut-offs
@@ -1321,10 +1328,17 @@ extern "C" int trace_op_skinny_gemm(const void* X, const void* W, void* out, con
 }
 extern "C" int trace_op_skinny_ks(int N, int K, int epilogue, int B) { return skinny_ks(N, K, epilogue, B); }
 extern "C" int trace_op_sk_rows(void) { return SK_ROWS; }
+// gate|up of a wide decode step: X [M <= 128, K] . Wt (the 16-row interleaved gate|up matrix in the decode tile layout) -> SwiGLU -> out [M, N/2] bf16
+extern "C" int trace_op_gemm_swiglu_tiled(const void* X, const void* Wt, void* out, int M, int N, int K, int nt, void* stream) {
+    GemmArgs g{(const bf16_t*)X, K, (const bf16_t*)Wt, K, (bf16_t*)out, N / 2, nullptr, nullptr, 0, M, N, K, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nt ? 3 : 1};
+    const int rc = launch_gemm_bf16(g, EPI_SWIGLU, (hipStream_t)stream);
+    if (rc != TRACE_OK) return fail(rc, "tiled SwiGLU GEMM launch failed");
+    return TRACE_OK;
+}
 // [M <= 128, K] x [N, K]^T as fp32 k-chunk partial rows [trace_op_gemm_partial_ks(N, K)][trace_op_sk_rows()][N] (decode batches above 64 rows)
 extern "C" int trace_op_gemm_partial_ks(int N, int K) { return gemm_partial_ks(N, K); }
-extern "C" int trace_op_gemm_partial(const void* A, const void* W, float* part, int M, int N, int K, void* stream) {
-    GemmArgs g{(const bf16_t*)A, K, (const bf16_t*)W, K, nullptr, 0, nullptr, nullptr, 0, M, N, K, nullptr, 0, nullptr, nullptr, 0, part, gemm_partial_ks(N, K)};
+extern "C" int trace_op_gemm_partial(const void* A, const void* W, float* part, int M, int N, int K, int w_tiled, void* stream) {
+    GemmArgs g{(const bf16_t*)A, K, (const bf16_t*)W, K, nullptr, 0, nullptr, nullptr, 0, M, N, K, nullptr, 0, nullptr, nullptr, 0, part, gemm_partial_ks(N, K), w_tiled};
     const int rc = launch_gemm_bf16(g, EPI_PARTIAL, (hipStream_t)stream);
     if (rc != TRACE_OK) return fail(rc, "partial GEMM launch failed");
     return TRACE_OK;

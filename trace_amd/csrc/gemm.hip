@@ -64,8 +64,13 @@ __device__ __forceinline__ f32x4_t mma_step(const bf16x8_t& w, const bf16x8_t& a
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool FP8>
+// WT: the W operand comes from the decode tile copy [N/16][K/64][64 lanes][16] (GemmArgs::w_tiled): a 16-row x 64-k block is one contiguous 2 KB,
+// lane-linear in MFMA-fragment order — lane (r, g) holds W[r][g*16 .. +16], its two fragments (k-steps 0 / 1 of the K-tile) back to back — so the
+// LDS image of a K-tile is [tile][k-step][lane][16 B], read with plain lane-linear ds_read_b128, and the A fragments take the matching k-slots
+// (16-byte chunk 2g + ks of the row instead of 4 ks + g: an MFMA only needs both operands to agree on which k a slot means).
+template <int BM, int BN, int WM, int WN, int EPI, bool FP8, bool WT = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
+    static_assert(!WT || (!FP8 && BN % 16 == 0), "tiled weights: bf16 only");
     constexpr int ESZ = FP8 ? 1 : 2, CE = 16 / ESZ;       // element bytes, elements per 16-byte chunk
     constexpr int NW = WM * WN, NTHR = NW * 64;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -106,9 +111,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
-        const int slot = i * NTHR + tid, row = slot >> 3, kc = (slot & 7) ^ ((row >> 1) & 7);
-        wsrc[i] = reinterpret_cast<const char*>(p.W) + ((size_t)(n0 + row) * p.ldw + kc * CE) * ESZ;
+        if constexpr (WT) {
+            const int q = i * NW + wid;                    // 1 KB piece (16-row tile q >> 1, k-step q & 1) of the K-tile's BN / 16 blocks
+            wsrc[i] = reinterpret_cast<const char*>(p.W) + (((size_t)(n0 / 16 + (q >> 1)) * (p.K / 64)) * 1024 + lane * 16 + (q & 1) * 8) * 2;
+        } else {
+            const int slot = i * NTHR + tid, row = slot >> 3, kc = (slot & 7) ^ ((row >> 1) & 7);
+            wsrc[i] = reinterpret_cast<const char*>(p.W) + ((size_t)(n0 + row) * p.ldw + kc * CE) * ESZ;
+        }
     }
+    const int w_aux = WT && (p.w_tiled & 2) ? 2 : 0;     // nt: the weights are read once by one workgroup
     // SPREAD: issue the next tile's LDS-DMA pieces between the MFMA groups (pays on the 8-wave 256^2 tile: +3..5 %;
     // on the 4-wave 128^2 tile with 2-3 workgroups per CU it measured -19 %, so that one issues them up front)
     constexpr bool SPREAD = (BM == 256);
@@ -139,11 +150,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     };
     auto issue_w = [&](int kt) {
         char* sw = w_stage(kt & 1);
-        const int ko = kt * 128;                       // bytes: one K-tile = 128-byte rows
+        const int ko = kt * (WT ? 2048 : 128);         // bytes: one K-tile = 128-byte rows / one 2 KB block per 16-row tile
 #pragma unroll
-        for (int i = 0; i < W_IT; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + ko),
-                                             (__attribute__((address_space(3))) void*)(sw + (i * NTHR + wid * 64) * 16), 16, 0, 0);
+        for (int i = 0; i < W_IT; ++i) {
+            if (WT && w_aux)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + ko),
+                                                 (__attribute__((address_space(3))) void*)(sw + (i * NTHR + wid * 64) * 16), 16, 0, 2);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + ko),
+                                                 (__attribute__((address_space(3))) void*)(sw + (i * NTHR + wid * 64) * 16), 16, 0, 0);
+        }
     };
 
     f32x4_t acc[TM][TN];
@@ -153,9 +169,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     int aoff[TM], woff[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) aoff[i] = swz(wm * (BM / WM) + i * 16 + r, g);
+    for (int i = 0; i < TM; ++i) aoff[i] = swz(wm * (BM / WM) + i * 16 + r, WT ? 2 * g : g);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) woff[j] = swz(wn * (BN / WN) + j * 16 + r, g);
+    for (int j = 0; j < TN; ++j) woff[j] = WT ? ((wn * (BN / WN) / 16 + j) * 2) * 1024 + lane * 16 : swz(wn * (BN / WN) + j * 16 + r, g);
+    constexpr int A_KS = WT ? 4 : 6, W_KS = WT ? 10 : 6;      // k-step 1: chunk 2g + 1 (byte 16) / the tile's second 1 KB image; else chunk g + 4 (byte 64)
 
     const int nk_all = p.K * ESZ / 128;
     const int kt0 = EPI == EPI_PARTIAL ? kchunk * (nk_all / p.ks) : 0;
@@ -174,15 +191,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
             // pinned with sched_group_barrier so the LDS latency of pair p+1 hides under the 2*TN MFMAs of pair p
             bf16x8_t wf[TN], ac[2], an[2];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(sw + (woff[j] ^ (ks << 6)));
-            ac[0] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[0] ^ (ks << 6)));
-            ac[1] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[1] ^ (ks << 6)));
+            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(sw + (woff[j] ^ (ks << W_KS)));
+            ac[0] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[0] ^ (ks << A_KS)));
+            ac[1] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[1] ^ (ks << A_KS)));
             __builtin_amdgcn_sched_group_barrier(0x100, TN + 2, 0);
 #pragma unroll
             for (int ip = 0; ip < TM / 2; ++ip) {
                 if (ip + 1 < TM / 2) {
-                    an[0] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[2 * ip + 2] ^ (ks << 6)));
-                    an[1] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[2 * ip + 3] ^ (ks << 6)));
+                    an[0] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[2 * ip + 2] ^ (ks << A_KS)));
+                    an[1] = *reinterpret_cast<const bf16x8_t*>(sa + (aoff[2 * ip + 3] ^ (ks << A_KS)));
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 }
 #pragma unroll
@@ -352,9 +369,23 @@ static int launch_partial(const GemmArgs& p, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<128, 128, 2, 2, EPI_PARTIAL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<128, 128, 2, 2, EPI_PARTIAL, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, EPI_PARTIAL, false>), dim3((p.N / 128) * p.ks), dim3(256), LDSB, s, p);
+    if (p.w_tiled) hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, EPI_PARTIAL, false, true>), dim3((p.N / 128) * p.ks), dim3(256), LDSB, s, p);
+    else hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, EPI_PARTIAL, false>), dim3((p.N / 128) * p.ks), dim3(256), LDSB, s, p);
+    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+}
+// gate|up of a wide decode step: [M <= 128, K] x tiled W -> SwiGLU -> bf16, one row panel of 128x128 tiles
+static int launch_swiglu_tiled(const GemmArgs& p, hipStream_t s) {
+    constexpr int STAGE = (128 + 128) * 128, LOOPB = 2 * STAGE, OBYTES = 128 * (128 * 2 + 16), LDSB = LOOPB > OBYTES ? LOOPB : OBYTES;
+    if (p.M < 1 || p.M > 128 || p.N % 128 || p.K % BK || p.fp8 || (p.lda % 8) || (p.ldc % 8)) return TRACE_ERR_ARG;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<128, 128, 2, 2, EPI_SWIGLU, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, EPI_SWIGLU, false, true>), dim3(p.N / 128), dim3(256), LDSB, s, p);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 // K-chunks for the partial-row GEMM: enough workgroups ((N / 128) x ks) to put at least one on every CU, chunks of whole K-tiles, at least 4
@@ -369,6 +400,7 @@ int gemm_partial_ks(int N, int K) {
 
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
     if (epi == EPI_PARTIAL) return launch_partial(p, s);
+    if (p.w_tiled) return epi == EPI_SWIGLU ? launch_swiglu_tiled(p, s) : TRACE_ERR_ARG;
     if (p.M <= 0 || p.N % BN || p.K % BK || p.K < BK) return TRACE_ERR_ARG;
     if (p.fp8 && (p.K % 128 || (p.lda % 16) || (p.ldw % 16) || !p.sa || !p.sw || p.bias || epi == EPI_QUICKGELU)) return TRACE_ERR_ARG;
     if ((p.lda % 8) || (p.ldw % 8) || (p.ldc % 8)) return TRACE_ERR_ARG;

@@ -24,6 +24,10 @@ struct GemmArgs {
     // (tile, chunk); chunk c leaves its fp32 accumulators in part[c][m][n] (row stride SK_ROWS x N) — the partial rows the decode consumers
     // (qkv_finish, add_rmsnorm) sum on load.  C / bias / R unused.
     float* part; int ks;
+    // w_tiled (128x128 tiles, bf16 only; the decode GEMMs): W is the decode copy made by launch_tile_pack ([N/16][K/64][64 lanes][16]) — a
+    // workgroup's weight stream is then 8 contiguous runs of 2 KB blocks instead of 128 row pieces of 128 B at an 8 KB stride (DRAM page
+    // locality, as for the GEMV).  Bit 1: non-temporal weight loads.
+    int w_tiled;
 };
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s);
 int gemm_partial_ks(int N, int K);                                // K-chunks launch_gemm_bf16(EPI_PARTIAL) should be given for an [<= 128, K] x [N, K]^T product

@@ -517,13 +517,24 @@ class ops:
         return out
 
     @staticmethod
-    def gemm_partial(X, W):
-        """decode batches above 64 rows: X [M <= 128, K] . W [N, K]^T as fp32 k-chunk partial rows [ks, sk_rows, N] (split-K MFMA GEMM)"""
+    def gemm_partial(X, W, tiled: int = 0):
+        """decode batches above 64 rows: X [M <= 128, K] . W [N, K]^T as fp32 k-chunk partial rows [ks, sk_rows, N] (split-K MFMA GEMM);
+        tiled: W went through tile_pack (1; 3 = + non-temporal weight loads)"""
         lib = _lib.load()
         M, K = X.shape
         N = W.shape[0]
         out = torch.zeros((lib.trace_op_gemm_partial_ks(N, K), lib.trace_op_sk_rows(), N), dtype=torch.float32, device=X.device)
-        _lib.check(lib.trace_op_gemm_partial(_ptr(X), _ptr(W), _ptr(out), M, N, K, _stream()))
+        _lib.check(lib.trace_op_gemm_partial(_ptr(X), _ptr(W), _ptr(out), M, N, K, int(tiled), _stream()))
+        return out
+
+    @staticmethod
+    def gemm_swiglu_tiled(X, Wt, nt: bool = True):
+        """gate|up of a wide decode step: X [M <= 128, K], Wt = tile_pack(16-row interleaved gate|up [N, K]) -> [M, N/2] bf16"""
+        lib = _lib.load()
+        M, K = X.shape
+        N = Wt.shape[0]
+        out = torch.empty((M, N // 2), dtype=torch.bfloat16, device=X.device)
+        _lib.check(lib.trace_op_gemm_swiglu_tiled(_ptr(X), _ptr(Wt), _ptr(out), M, N, K, int(nt), _stream()))
         return out
 
     @staticmethod

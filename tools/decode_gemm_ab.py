@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--ctx", type=int, default=1968)
 ap.add_argument("--steps", type=int, default=16)
+ap.add_argument("--wide-min", type=int, default=0, help="1 / 2: batches from 33 / 17 up take the wide decode step (default: from 65)")
 a = ap.parse_args()
 cfg = tcfg.trace_7b()
 eng = TraceEngine(cfg, max_batch=a.batch, max_ctx=a.ctx + 320, max_frames=128, max_new_tokens=256)
@@ -19,6 +20,7 @@ for b in range(a.batch):
     eng.prefill(b, a.ctx, embeds=emb)
 torch.cuda.synchronize()
 slots = list(range(a.batch))
+ops.set_gemm_variant(140 + a.wide_min)
 names = {0: "row-major weights", 1: "decode tile copies", 3: "tile copies + nt loads"}
 lg = {}
 for v in names:

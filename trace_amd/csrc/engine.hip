@@ -956,6 +956,7 @@ static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* l
 static int decode_nsplit(int B) { const int n = (40 + B / 2) / B; return n < 1 ? 1 : n > 16 ? 16 : n; }
 
 static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* logits_out, hipStream_t s);
+int g_decode_wide_min = SKINNY_ROWS + 1;   // smallest batch that takes the wide (GEMM) decode step (A/B: trace_op_set_gemm_variant(140 + x): 65 / 33 / 17)
 int g_decode_gemm_tiled = 3;   // wide decode step: 1 = weights from the decode tile copies, 3 = + non-temporal loads, 0 = row-major prefill copies (A/B:
                                // trace_op_set_gemm_variant(130 + x))
 
@@ -1019,7 +1020,7 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
     // Every GEMV leaves fp32 k-chunk partial rows in sk_ws and its consumer sums them on load (an in-kernel merge costs
     // 5-8 us of dependent round trips per GEMV): qkv -> attention (RoPE + cache append + attention) -> o -> [sum + residual
     // -> new residual, RMSNorm] -> gate|up -> [sum, SwiGLU] -> down -> [sum + residual, next layer's / the final RMSNorm].
-    if (B > SKINNY_ROWS) return decode_step_wide(c, logits_out, s);
+    if (B > SKINNY_ROWS || (B >= g_decode_wide_min && !c->fp8)) return decode_step_wide(c, logits_out, s);
     const bool f8 = c->fp8;
     const int ks_q = f8 ? skinny_fp8_ks(QKV, H, B) : skinny_ks(QKV, H, EPI_PARTIAL, B), ks_o = f8 ? skinny_fp8_ks(H, H, B) : skinny_ks(H, H, EPI_PARTIAL, B);
     const int ks_g = f8 ? skinny_fp8_ks(2 * I, H, B) : skinny_ks(2 * I, H, EPI_PARTIAL, B), ks_d = f8 ? skinny_fp8_ks(H, I, B) : skinny_ks(H, I, EPI_PARTIAL, B);
@@ -1263,6 +1264,7 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 130 && variant <= 133) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
+    if (variant >= 140 && variant <= 142) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : 17; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
     if (variant >= 400 && variant < 404) { g_gemm_ldr_opt = variant - 400; return TRACE_OK; }   // microbench: attention phase cut-offs

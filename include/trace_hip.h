@@ -168,9 +168,9 @@ int trace_op_sk_rows(void);                 /* row stride of every fp32 partial-
    [trace_op_gemm_partial_ks(N, K)][trace_op_sk_rows()][N] for trace_op_add_rmsnorm (split-K MFMA GEMM, 128x128 tiles) */
 int trace_op_gemm_partial_ks(int N, int K);
 int trace_op_gemm_partial(const void* A, const void* W, float* part, int M, int N, int K, int w_tiled, void* stream);
-/* w_tiled: W is the trace_op_tile_pack copy (bit 1: non-temporal weight loads).  The gate|up product of such a step: tiled 16-row interleaved
+/* w_tiled: W is the trace_op_tile_pack copy (1; 5 = with the 4-stage K-tile ring the engine uses).  The gate|up product of such a step: tiled 16-row interleaved
    gate|up matrix, SwiGLU epilogue, out [M, N/2] bf16 */
-int trace_op_gemm_swiglu_tiled(const void* X, const void* Wt, void* out, int M, int N, int K, int nt, void* stream);
+int trace_op_gemm_swiglu_tiled(const void* X, const void* Wt, void* out, int M, int N, int K, int ring, void* stream);
 int trace_op_tile_pack(const void* W, void* Wt, int N, int K, void* stream);
 /* fp8 path pieces: row quantiser (X bf16 [rows,K] -> e4m3 bytes + scale[row] = amax/448), the W8A8 GEMM
    C = (A8 . W8^T) * sa[m] * sw[n] (+ residual / SwiGLU epilogue as trace_op_gemm), and the decode GEMV (fp32 out [B,N]) */

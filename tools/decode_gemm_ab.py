@@ -1,5 +1,5 @@
 """A/B of the wide decode step's GEMM weight source on the 7B engine (random embeddings prefilled, no ViT): row-major prefill copies (130) vs decode
-tile copies (131) vs tile copies + non-temporal loads (133).  Interleaved rounds, median.   python tools/decode_gemm_ab.py [--batch 128]"""
+tile copies (131) vs tile copies + a 4-stage K-tile ring (135).  Interleaved rounds, median.   python tools/decode_gemm_ab.py [--batch 128]"""
 import argparse, os, sys, time, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,7 +21,7 @@ for b in range(a.batch):
 torch.cuda.synchronize()
 slots = list(range(a.batch))
 ops.set_gemm_variant(140 + a.wide_min)
-names = {0: "row-major weights", 1: "decode tile copies", 3: "tile copies + nt loads"}
+names = {0: "row-major weights", 1: "decode tile copies", 5: "tile copies, 4-stage ring"}
 lg = {}
 for v in names:
     ops.set_gemm_variant(130 + v)
@@ -30,7 +30,7 @@ for v in names:
         steps.append(eng.decode_steps(1, use_graph=False, want_logits=True).clone())
     lg[v] = torch.stack(steps)
 fin = torch.isfinite(lg[0])
-for v in (1, 3):
+for v in (1, 5):
     print(f"logits vs row-major, {names[v]}: max|d| {(lg[v][fin] - lg[0][fin]).abs().max().item():.4f}")
 ts = {v: [] for v in names}
 for rnd in range(5):
@@ -43,6 +43,6 @@ for rnd in range(5):
         eng.decode_steps(a.steps, use_graph=False)
         torch.cuda.synchronize()
         ts[v].append((time.perf_counter() - t0) / a.steps * 1e3)
-ops.set_gemm_variant(133)
+ops.set_gemm_variant(135)
 for v, name in names.items():
     print(f"batch {a.batch} ctx {a.ctx}: {name:28s} {statistics.median(ts[v][1:]):.3f} ms/step  (rounds: {' '.join('%.3f' % t for t in ts[v])})")

@@ -956,9 +956,9 @@ static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* l
 static int decode_nsplit(int B) { const int n = (40 + B / 2) / B; return n < 1 ? 1 : n > 16 ? 16 : n; }
 
 static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* logits_out, hipStream_t s);
-int g_decode_wide_min = SKINNY_ROWS + 1;   // smallest batch that takes the wide (GEMM) decode step (A/B: trace_op_set_gemm_variant(140 + x): 65 / 33 / 17)
-int g_decode_gemm_tiled = 3;   // wide decode step: 1 = weights from the decode tile copies, 3 = + non-temporal loads, 0 = row-major prefill copies (A/B:
-                               // trace_op_set_gemm_variant(130 + x))
+int g_decode_wide_min = SKINNY_ROWS;   // smallest batch that takes the wide (GEMM) decode step: at 64 rows it measured 7.68 vs the GEMV path's 7.88 ms per step (r03_decode_gemm_ab_b64.txt); A/B: trace_op_set_gemm_variant(140 + x): 65 / 33 / 17 / 64
+int g_decode_gemm_tiled = 5;   // wide decode step, GemmArgs::w_tiled: bit 0 = weights from the decode tile copies (0 = row-major prefill copies), bit 2 = 4-stage
+                               // K-tile ring (A/B: trace_op_set_gemm_variant(130 + x))
 
 // One decode step for SKINNY_ROWS < B <= SK_ROWS sequences.  A GEMV that parks its activations in LDS cannot hold more than 64 rows x 1024 k, and
 // its fp32 partial rows would grow with the row count; above 64 rows the four projections are small-M GEMMs on the MFMA tile kernel instead
@@ -1263,8 +1263,8 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 100 && variant < 104) { g_attn_debug = variant - 100; return TRACE_OK; }
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
-    if (variant >= 130 && variant <= 133) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
-    if (variant >= 140 && variant <= 142) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : 17; return TRACE_OK; }
+    if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
+    if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : SKINNY_ROWS; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
     if (variant >= 400 && variant < 404) { g_gemm_ldr_opt = variant - 400; return TRACE_OK; }   // microbench: attention phase cut-offs
@@ -1331,8 +1331,8 @@ extern "C" int trace_op_skinny_gemm(const void* X, const void* W, void* out, con
 extern "C" int trace_op_skinny_ks(int N, int K, int epilogue, int B) { return skinny_ks(N, K, epilogue, B); }
 extern "C" int trace_op_sk_rows(void) { return SK_ROWS; }
 // gate|up of a wide decode step: X [M <= 128, K] . Wt (the 16-row interleaved gate|up matrix in the decode tile layout) -> SwiGLU -> out [M, N/2] bf16
-extern "C" int trace_op_gemm_swiglu_tiled(const void* X, const void* Wt, void* out, int M, int N, int K, int nt, void* stream) {
-    GemmArgs g{(const bf16_t*)X, K, (const bf16_t*)Wt, K, (bf16_t*)out, N / 2, nullptr, nullptr, 0, M, N, K, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nt ? 3 : 1};
+extern "C" int trace_op_gemm_swiglu_tiled(const void* X, const void* Wt, void* out, int M, int N, int K, int ring, void* stream) {
+    GemmArgs g{(const bf16_t*)X, K, (const bf16_t*)Wt, K, (bf16_t*)out, N / 2, nullptr, nullptr, 0, M, N, K, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, ring ? 5 : 1};
     const int rc = launch_gemm_bf16(g, EPI_SWIGLU, (hipStream_t)stream);
     if (rc != TRACE_OK) return fail(rc, "tiled SwiGLU GEMM launch failed");
     return TRACE_OK;

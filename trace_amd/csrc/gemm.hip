@@ -68,7 +68,10 @@ __device__ __forceinline__ f32x4_t mma_step(const bf16x8_t& w, const bf16x8_t& a
 // lane-linear in MFMA-fragment order — lane (r, g) holds W[r][g*16 .. +16], its two fragments (k-steps 0 / 1 of the K-tile) back to back — so the
 // LDS image of a K-tile is [tile][k-step][lane][16 B], read with plain lane-linear ds_read_b128, and the A fragments take the matching k-slots
 // (16-byte chunk 2g + ks of the row instead of 4 ks + g: an MFMA only needs both operands to agree on which k a slot means).
-template <int BM, int BN, int WM, int WN, int EPI, bool FP8, bool WT = false>
+// NSTAGE > 2 (the decode GEMMs: M <= 128 rows, weights streamed once from HBM, nothing to re-use): a ring of NSTAGE K-tiles with NSTAGE - 1 in
+// flight behind counted vmcnt waits and one raw s_barrier per K-tile — the double buffer keeps ONE 16 KB weight tile per workgroup under way, and
+// with a single workgroup on most CUs (224-256 of them) that is a few GB/s per CU of a stream that wants 25.
+template <int BM, int BN, int WM, int WN, int EPI, bool FP8, bool WT = false, int NSTAGE = 2>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     static_assert(!WT || (!FP8 && BN % 16 == 0), "tiled weights: bf16 only");
     constexpr int ESZ = FP8 ? 1 : 2, CE = 16 / ESZ;       // element bytes, elements per 16-byte chunk
@@ -119,14 +122,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
             wsrc[i] = reinterpret_cast<const char*>(p.W) + ((size_t)(n0 + row) * p.ldw + kc * CE) * ESZ;
         }
     }
-    const int w_aux = WT && (p.w_tiled & 2) ? 2 : 0;     // nt: the weights are read once by one workgroup
     // SPREAD: issue the next tile's LDS-DMA pieces between the MFMA groups (pays on the 8-wave 256^2 tile: +3..5 %;
     // on the 4-wave 128^2 tile with 2-3 workgroups per CU it measured -19 %, so that one issues them up front)
     constexpr bool SPREAD = (BM == 256);
     auto a_stage = [&](int i) -> char* { return smem + i * STAGE; };              // [A0 W0 | A1 W1]
     auto w_stage = [&](int i) -> char* { return smem + i * STAGE + A_BYTES; };
     auto issue_a = [&](int kt) {
-        char* sa = a_stage(kt & 1);
+        char* sa = a_stage(NSTAGE > 2 ? kt % NSTAGE : kt & 1);
         const int ko = kt * 128;                       // bytes: one K-tile = 128-byte rows
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
@@ -149,17 +151,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
         }
     };
     auto issue_w = [&](int kt) {
-        char* sw = w_stage(kt & 1);
+        char* sw = w_stage(NSTAGE > 2 ? kt % NSTAGE : kt & 1);
         const int ko = kt * (WT ? 2048 : 128);         // bytes: one K-tile = 128-byte rows / one 2 KB block per 16-row tile
 #pragma unroll
-        for (int i = 0; i < W_IT; ++i) {
-            if (WT && w_aux)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + ko),
-                                                 (__attribute__((address_space(3))) void*)(sw + (i * NTHR + wid * 64) * 16), 16, 0, 2);
-            else
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + ko),
-                                                 (__attribute__((address_space(3))) void*)(sw + (i * NTHR + wid * 64) * 16), 16, 0, 0);
-        }
+        for (int i = 0; i < W_IT; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + ko),
+                                             (__attribute__((address_space(3))) void*)(sw + (i * NTHR + wid * 64) * 16), 16, 0, 0);
     };
 
     f32x4_t acc[TM][TN];
@@ -177,14 +174,31 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
     const int nk_all = p.K * ESZ / 128;
     const int kt0 = EPI == EPI_PARTIAL ? kchunk * (nk_all / p.ks) : 0;
     const int nk = EPI == EPI_PARTIAL ? kt0 + nk_all / p.ks : nk_all;          // this workgroup's K-tiles [kt0, nk)
-    issue_a(kt0); issue_w(kt0);
+    if constexpr (NSTAGE > 2) {
+#pragma unroll
+        for (int d = 0; d < NSTAGE - 1; ++d)
+            if (kt0 + d < nk) { issue_a(kt0 + d); issue_w(kt0 + d); }
+    } else { issue_a(kt0); issue_w(kt0); }
     for (int kt = kt0; kt < nk; ++kt) {
-        __syncthreads();                                   // tile kt landed (vmcnt(0) + barrier); everyone is done with tile kt-1
+        if constexpr (NSTAGE > 2) {
+            // tile kt landed: this thread's pieces by its own counted wait (the later tiles' A_IT + W_IT pieces each may stay in flight), everybody's
+            // by the barrier — which also says every wave is done reading tile kt - 1, whose stage the DMA issued next overwrites
+            constexpr int PPT = A_IT + W_IT;
+            const int ahead = min(nk - 1 - kt, NSTAGE - 2);
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + NSTAGE - 1 < nk) { issue_a(kt + NSTAGE - 1); issue_w(kt + NSTAGE - 1); }
+        } else {
+            __syncthreads();                               // tile kt landed (vmcnt(0) + barrier); everyone is done with tile kt-1
+        }
         if (tr && kt == 0 && threadIdx.x == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
-        if (!SPREAD && kt + 1 < nk) { issue_a(kt + 1); issue_w(kt + 1); }
+        if (NSTAGE == 2 && !SPREAD && kt + 1 < nk) { issue_a(kt + 1); issue_w(kt + 1); }
         const bool more = SPREAD && kt + 1 < nk;
-        const char* sa = a_stage(kt & 1);
-        const char* sw = w_stage(kt & 1);
+        const char* sa = a_stage(NSTAGE > 2 ? kt % NSTAGE : kt & 1);
+        const char* sw = w_stage(NSTAGE > 2 ? kt % NSTAGE : kt & 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             // fragment reads run one pair of m-tiles AHEAD of the MFMAs that consume them (register double buffer),
@@ -362,31 +376,28 @@ int g_gemm_variant = 0;   // 0 = auto, 2 = 128^2 tiles, 3 = this file's 256^2 ke
 extern int g_gemm_pers_static;
 
 // split-K partial-row GEMM for decode batches above SKINNY_ROWS: M <= 128 rows (one row panel), 128x128 tiles, ks chunks of K
-static int launch_partial(const GemmArgs& p, hipStream_t s) {
-    constexpr int STAGE = (128 + 128) * 128, LDSB = 2 * STAGE;
-    if (p.M < 1 || p.M > 128 || p.M > SK_ROWS || p.N % 128 || p.K % BK || p.fp8 || !p.part || p.ks < 1 || (p.K / BK) % p.ks) return TRACE_ERR_ARG;
-    if ((p.lda % 8) || (p.ldw % 8)) return TRACE_ERR_ARG;
+template <int EPI, bool WT, int NSTAGE>
+static int launch_dec(const GemmArgs& p, int nblk, hipStream_t s) {
+    constexpr int STAGE = (128 + 128) * 128, LOOPB = NSTAGE * STAGE, OBYTES = 128 * (128 * 2 + 16), LDSB = LOOPB > OBYTES ? LOOPB : OBYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<128, 128, 2, 2, EPI_PARTIAL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<128, 128, 2, 2, EPI_PARTIAL, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<128, 128, 2, 2, EPI, false, WT, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
         attr_done = true;
     }
-    if (p.w_tiled) hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, EPI_PARTIAL, false, true>), dim3((p.N / 128) * p.ks), dim3(256), LDSB, s, p);
-    else hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, EPI_PARTIAL, false>), dim3((p.N / 128) * p.ks), dim3(256), LDSB, s, p);
+    hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, EPI, false, WT, NSTAGE>), dim3(nblk), dim3(256), LDSB, s, p);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+}
+static int launch_partial(const GemmArgs& p, hipStream_t s) {
+    if (p.M < 1 || p.M > 128 || p.M > SK_ROWS || p.N % 128 || p.K % BK || p.fp8 || !p.part || p.ks < 1 || (p.K / BK) % p.ks) return TRACE_ERR_ARG;
+    if ((p.lda % 8) || (p.ldw % 8)) return TRACE_ERR_ARG;
+    const int nblk = (p.N / 128) * p.ks;
+    if (!p.w_tiled) return launch_dec<EPI_PARTIAL, false, 2>(p, nblk, s);
+    return (p.w_tiled & 4) ? launch_dec<EPI_PARTIAL, true, 4>(p, nblk, s) : launch_dec<EPI_PARTIAL, true, 2>(p, nblk, s);
 }
 // gate|up of a wide decode step: [M <= 128, K] x tiled W -> SwiGLU -> bf16, one row panel of 128x128 tiles
 static int launch_swiglu_tiled(const GemmArgs& p, hipStream_t s) {
-    constexpr int STAGE = (128 + 128) * 128, LOOPB = 2 * STAGE, OBYTES = 128 * (128 * 2 + 16), LDSB = LOOPB > OBYTES ? LOOPB : OBYTES;
     if (p.M < 1 || p.M > 128 || p.N % 128 || p.K % BK || p.fp8 || (p.lda % 8) || (p.ldc % 8)) return TRACE_ERR_ARG;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<128, 128, 2, 2, EPI_SWIGLU, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, EPI_SWIGLU, false, true>), dim3(p.N / 128), dim3(256), LDSB, s, p);
-    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+    return (p.w_tiled & 4) ? launch_dec<EPI_SWIGLU, true, 4>(p, p.N / 128, s) : launch_dec<EPI_SWIGLU, true, 2>(p, p.N / 128, s);
 }
 // K-chunks for the partial-row GEMM: enough workgroups ((N / 128) x ks) to put at least one on every CU, chunks of whole K-tiles, at least 4
 // K-tiles per chunk (a shorter K loop is all prologue).  TRACE_PARTIAL_WGS overrides the workgroup target (tuning runs).

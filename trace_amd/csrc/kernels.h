@@ -26,7 +26,8 @@ struct GemmArgs {
     float* part; int ks;
     // w_tiled (128x128 tiles, bf16 only; the decode GEMMs): W is the decode copy made by launch_tile_pack ([N/16][K/64][64 lanes][16]) — a
     // workgroup's weight stream is then 8 contiguous runs of 2 KB blocks instead of 128 row pieces of 128 B at an 8 KB stride (DRAM page
-    // locality, as for the GEMV).  Bit 1: non-temporal weight loads.
+    // locality, as for the GEMV).  Bit 2: a 4-stage K-tile ring (three tiles in flight) instead of the double buffer.  (Bit 1 was a non-temporal
+    // hint on the weight DMA: 11.58 vs 11.15 ms per 128-sequence step, profiles/r03_decode_gemm_ab_b128.txt — removed.)
     int w_tiled;
 };
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s);

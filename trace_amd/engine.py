@@ -519,7 +519,7 @@ class ops:
     @staticmethod
     def gemm_partial(X, W, tiled: int = 0):
         """decode batches above 64 rows: X [M <= 128, K] . W [N, K]^T as fp32 k-chunk partial rows [ks, sk_rows, N] (split-K MFMA GEMM);
-        tiled: W went through tile_pack (1; 3 = + non-temporal weight loads)"""
+        tiled: W went through tile_pack (1; 5 = + the 4-stage K-tile ring)"""
         lib = _lib.load()
         M, K = X.shape
         N = W.shape[0]
@@ -528,13 +528,13 @@ class ops:
         return out
 
     @staticmethod
-    def gemm_swiglu_tiled(X, Wt, nt: bool = True):
+    def gemm_swiglu_tiled(X, Wt, ring: bool = True):
         """gate|up of a wide decode step: X [M <= 128, K], Wt = tile_pack(16-row interleaved gate|up [N, K]) -> [M, N/2] bf16"""
         lib = _lib.load()
         M, K = X.shape
         N = Wt.shape[0]
         out = torch.empty((M, N // 2), dtype=torch.bfloat16, device=X.device)
-        _lib.check(lib.trace_op_gemm_swiglu_tiled(_ptr(X), _ptr(Wt), _ptr(out), M, N, K, int(nt), _stream()))
+        _lib.check(lib.trace_op_gemm_swiglu_tiled(_ptr(X), _ptr(Wt), _ptr(out), M, N, K, int(ring), _stream()))
         return out
 
     @staticmethod

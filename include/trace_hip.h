@@ -41,9 +41,11 @@ typedef struct trace_config {
     int32_t vit_batch_frames; /* frames one trace_vit_forward call may take (ViT workspaces); 0 = max_frames.  Larger than
                                * max_frames lets a caller push the frames of several videos through the tower together (the
                                * tower is per-frame: results do not depend on the grouping) */
-    int32_t llm_weights_fp8;  /* 1 = the four decoder projections per layer run on the fp8 path (BASELINE config 5): e4m3 weights with a
-                               * scale per output row made at load from the bf16 tensors, activations quantised per token row on the
-                               * fly, fp8 MFMA with fp32 accumulation.  No reference counterpart; parity anchor = the bf16 path */
+    int32_t llm_weights_fp8;  /* the four decoder projections per layer on the fp8 path (BASELINE config 5): e4m3 weights with a scale per output
+                               * row made at load from the bf16 tensors.  1 = W8A8 everywhere: activations quantised per token row on the
+                               * fly, fp8 MFMA with fp32 accumulation.  2 = W8A8 prefill GEMMs, WEIGHT-ONLY decode GEMVs (bf16 activations,
+                               * weights widened to bf16 in registers, bf16 MFMA): the same weight bytes per step, half the rounding-noise
+                               * variance where the tokens are chosen.  No reference counterpart; parity anchor = the bf16 path */
 } trace_config;
 
 const char* trace_last_error(void);
@@ -178,6 +180,8 @@ int trace_op_quant_rows_fp8(const void* X, void* X8, float* sx, int rows, int K,
 int trace_op_gemm_fp8(const void* A8, const float* sa, const void* W8, const float* sw, void* C, const void* R, int M, int N, int K,
                       int epilogue, void* stream);
 int trace_op_skinny_fp8(const void* X8, const float* sx, const void* W8, const float* sw, float* out, int B, int N, int K, void* stream);
+/* the weight-only decode GEMV: X bf16 [B,K] . (e4m3 W8 [N,K] widened to bf16)^T * sw[n] -> fp32 out [B,N] */
+int trace_op_skinny_w8(const void* X, const void* W8, const float* sw, float* out, int B, int N, int K, void* stream);
 /* out[b][j] = bf16(silu(sum_ks gate) * sum_ks up) from partial rows [KS][64][N2] of the 16-row interleaved gate|up GEMV */
 int trace_op_swiglu_combine(const float* part, int KS, int N2, void* out, int B, void* stream);
 /* x = bf16(sum_ks part[ks][b][:]) + R[b][:] -> xout;  y = RMSNorm(x) * w   (decode residual add + norm, N <= 4096) */

@@ -73,6 +73,7 @@ SIGNATURES = {
     "trace_op_quant_rows_fp8": (I, [P, P, P, I, I, P]),
     "trace_op_gemm_fp8": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "trace_op_skinny_fp8": (I, [P, P, P, P, P, I, I, I, P]),
+    "trace_op_skinny_w8": (I, [P, P, P, P, I, I, I, P]),
     "trace_op_swiglu_combine": (I, [P, I, I, P, I, P]),
     "trace_op_add_rmsnorm": (I, [P, I, P, P, P, P, I, I, F, P]),
     "trace_op_attn_decode": (I, [P, P, P, P, P, P, I, I, I, I, I, F, P]),

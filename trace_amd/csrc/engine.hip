@@ -88,6 +88,7 @@ struct trace_ctx {
     int B = 0, max_new = 0, eos = -1, has_forced = 0, ntiles = 0, nsplit = 32;
     int slot_len[MAX_SLOTS] = {0};
     int fp8 = 0;                       // decoder projections on the fp8 path
+    int fp8_wonly = 0;                 // llm_weights_fp8 == 2: the decode GEMVs keep bf16 activations (weight-only; the prefill GEMMs stay W8A8)
     uint8_t *pA8 = nullptr, *dA8 = nullptr, *dH8 = nullptr;      // quantised activations: prefill [2 max_ctx][max(H, I)], decode [64][I]; dH8 = the normed hidden rows
     float *psa = nullptr, *dsa = nullptr, *dsh = nullptr;        // their per-row scales
     int step_in_call = 0;              // decode steps taken since trace_decode_begin at the time decode_step runs (host copy)
@@ -153,6 +154,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     if (c->H > 4096) return bad("hidden_size > 4096: the decode row kernels (norms, residual add) hold one 4096-wide row per workgroup");
     c->stc = cfg->projector_type == 1;
     c->fp8 = cfg->llm_weights_fp8 != 0;
+    c->fp8_wonly = cfg->llm_weights_fp8 == 2;
     if (c->fp8 && (c->H % 128 || c->I % 128 || c->I > 16384)) return bad("fp8 weight path needs hidden / intermediate sizes that are multiples of 128 (intermediate <= 16384)");
     if (!c->stc && (c->S != 8 || c->vh > 1024)) return bad("slot pool kernel needs 8 slots and mm_hidden <= 1024");
     if (c->max_B < 1 || c->max_B > MAX_SLOTS) return bad("max_batch (KV slots) must be in [1,128]");
@@ -246,6 +248,10 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
         f = std::max(f, skinny_ws_floats(H, I, EPI_PARTIAL));
         if (c->fp8)      // the fp8 GEMV picks its own K-chunk count (128-k units): size the partial rows for it as well
             for (int B : {1, 16, 17, 32, 33, 64}) {
+                f = std::max(f, (size_t)skinny_w8_ks(c->QKV, (int)H, B) * SK_ROWS * c->QKV);
+                f = std::max(f, (size_t)skinny_w8_ks((int)H, (int)H, B) * SK_ROWS * H);
+                f = std::max(f, (size_t)skinny_w8_ks(2 * (int)I, (int)H, B) * SK_ROWS * 2 * I);
+                f = std::max(f, (size_t)skinny_w8_ks((int)H, (int)I, B) * SK_ROWS * H);
                 f = std::max(f, (size_t)skinny_fp8_ks(c->QKV, (int)H, B) * SK_ROWS * c->QKV);
                 f = std::max(f, (size_t)skinny_fp8_ks((int)H, (int)H, B) * SK_ROWS * H);
                 f = std::max(f, (size_t)skinny_fp8_ks(2 * (int)I, (int)H, B) * SK_ROWS * 2 * I);
@@ -1020,10 +1026,12 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
     // Every GEMV leaves fp32 k-chunk partial rows in sk_ws and its consumer sums them on load (an in-kernel merge costs
     // 5-8 us of dependent round trips per GEMV): qkv -> attention (RoPE + cache append + attention) -> o -> [sum + residual
     // -> new residual, RMSNorm] -> gate|up -> [sum, SwiGLU] -> down -> [sum + residual, next layer's / the final RMSNorm].
-    if (B > SKINNY_ROWS || (B >= g_decode_wide_min && !c->fp8)) return decode_step_wide(c, logits_out, s);
-    const bool f8 = c->fp8;
-    const int ks_q = f8 ? skinny_fp8_ks(QKV, H, B) : skinny_ks(QKV, H, EPI_PARTIAL, B), ks_o = f8 ? skinny_fp8_ks(H, H, B) : skinny_ks(H, H, EPI_PARTIAL, B);
-    const int ks_g = f8 ? skinny_fp8_ks(2 * I, H, B) : skinny_ks(2 * I, H, EPI_PARTIAL, B), ks_d = f8 ? skinny_fp8_ks(H, I, B) : skinny_ks(H, I, EPI_PARTIAL, B);
+    if (B > SKINNY_ROWS || (B >= g_decode_wide_min && !c->fp8)) return decode_step_wide(c, logits_out, s);      // (fp8 contexts: at most 64 rows, checked at begin)
+    const bool wo = c->fp8 && c->fp8_wonly;          // weight-only decode GEMVs: bf16 activations straight from dH / dO / dACT, no quantiser launches
+    const bool f8 = c->fp8 && !wo;
+    auto ksf = [&](int N, int K) { return wo ? skinny_w8_ks(N, K, B) : f8 ? skinny_fp8_ks(N, K, B) : skinny_ks(N, K, EPI_PARTIAL, B); };
+    const int ks_q = ksf(QKV, H), ks_o = ksf(H, H), ks_g = ksf(2 * I, H), ks_d = ksf(H, I);
+#define GEMVW(X_, W8D_, SW_, N_, K_) LCHK(launch_skinny_w8((X_), (K_), (W8D_), (SW_), B, (N_), (K_), c->sk_ws, c->sk_ws_floats, s));
     // fp8: the GEMV's activations are quantised row-wise first (quant_rows_fp8: [B, K] bf16 -> e4m3 + per-row scale), the weights come
     // from the e4m3 tile copy; partial rows, their consumers and the attention are the bf16 path's
 #define GEMV8(X_, W8D_, SW_, N_, K_)                                                                           \
@@ -1039,7 +1047,8 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
         bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
         // (fusing the RMSNorm into the GEMV itself was tried: re-scaling the same activations in every workgroup cost
         //  more than a row kernel — 65 us vs 52 + 6 us for the gate|up GEMV)
-        if (f8) { GEMV8H(W.wqkv8_d, W.sqkv, QKV) }
+        if (wo) { GEMVW(c->dH, W.wqkv8_d, W.sqkv, QKV, H) }
+        else if (f8) { GEMV8H(W.wqkv8_d, W.sqkv, QKV) }
         else LCHK(launch_skinny_gemm(c->dH, H, W.wqkv_d, H, nullptr, QKV, nullptr, 0, B, QKV, H, EPI_PARTIAL, 1, SKWS(c), s));
         if (g_decode_unfused == 1 || (g_decode_unfused == 0 && B >= 32)) {
             LCHK(launch_qkv_finish(c->sk_ws, ks_q, QKV, c->dQKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots,
@@ -1051,7 +1060,8 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
         LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots, c->d_pos, c->dO,
                                 H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, decode_nsplit(B), 1.0f / sqrtf((float)HD), 1,
                                 c->rope_cos, c->rope_sin, c->sk_ws, ks_q, s));
-        if (f8) { GEMV8(c->dO, W.wo8_d, W.so, H, H) }
+        if (wo) { GEMVW(c->dO, W.wo8_d, W.so, H, H) }
+        else if (f8) { GEMV8(c->dO, W.wo8_d, W.so, H, H) }
         else LCHK(launch_skinny_gemm(c->dO, H, W.wo_d, H, nullptr, H, nullptr, 0, B, H, H, EPI_PARTIAL, 1, SKWS(c), s));
         LCHK(launch_add_rmsnorm(c->sk_ws, ks_o, c->dX, H, c->dX, H, W.rms2, c->dH, H, B, H, c->c.rms_eps, s, f8 ? c->dH8 : nullptr, f8 ? c->dsh : nullptr));
         // roofline probe: HIP events around ONE launch of the dominant kernel (layer 0 gate|up GEMV) per step
@@ -1061,17 +1071,20 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
             if (s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) { e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2; }
         }
         if (e0) hipEventRecord(e0, s);
-        if (f8) { GEMV8H(W.wgu8_d, W.sgu, 2 * I) }
+        if (wo) { GEMVW(c->dH, W.wgu8_d, W.sgu, 2 * I, H) }
+        else if (f8) { GEMV8H(W.wgu8_d, W.sgu, 2 * I) }
         else LCHK(launch_skinny_gemm(c->dH, H, W.wgu_d, H, nullptr, 2 * I, nullptr, 0, B, 2 * I, H, EPI_PARTIAL, 1, SKWS(c), s));
         if (e1) hipEventRecord(e1, s);
         LCHK(launch_swiglu_combine(c->sk_ws, ks_g, 2 * I, c->dACT, I, B, s));
-        if (f8) { GEMV8(c->dACT, W.wd8_d, W.sd, H, I) }
+        if (wo) { GEMVW(c->dACT, W.wd8_d, W.sd, H, I) }
+        else if (f8) { GEMV8(c->dACT, W.wd8_d, W.sd, H, I) }
         else LCHK(launch_skinny_gemm(c->dACT, I, W.wd_d, I, nullptr, H, nullptr, 0, B, H, I, EPI_PARTIAL, 1, SKWS(c), s));
         const bf16_t* nw = l + 1 < c->NL ? c->llm[l + 1].rms1 : c->final_norm;
         LCHK(launch_add_rmsnorm(c->sk_ws, ks_d, c->dX, H, c->dX, H, nw, c->dH, H, B, H, c->c.rms_eps, s, f8 ? c->dH8 : nullptr, f8 ? c->dsh : nullptr));
     }
 #undef GEMV8
 #undef GEMV8H
+#undef GEMVW
     return head_and_select(c, c->dH, 1, logits_out, s);
 }
 
@@ -1369,6 +1382,27 @@ extern "C" int trace_op_skinny_fp8(const void* X8, const float* sx, const void* 
     LCHK(launch_tile_pack_fp8((const uint8_t*)W8, K, wt, N, K, s));
     LCHK(launch_skinny_fp8((const uint8_t*)X8, K, sx, wt, sw, B, N, K, ws, ws_floats, s));
     const int KS = skinny_fp8_ks(N, K, B);
+    std::vector<float> h((size_t)KS * SK_ROWS * N), o((size_t)B * N, 0.f);
+    HIPCHK(hipMemcpyAsync(h.data(), ws, h.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int ks = 0; ks < KS; ++ks)
+        for (int b = 0; b < B; ++b)
+            for (int n = 0; n < N; ++n) o[(size_t)b * N + n] += h[((size_t)ks * SK_ROWS + b) * N + n];
+    HIPCHK(hipMemcpy(out, o.data(), o.size() * 4, hipMemcpyHostToDevice));
+    return TRACE_OK;
+}
+
+// weight-only form: X bf16 [B,K], W8 [N,K] e4m3 row-major + sw -> out fp32 [B,N] (the k-chunk partial rows summed here, in chunk order)
+extern "C" int trace_op_skinny_w8(const void* X, const void* W8, const float* sw, float* out, int B, int N, int K, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    static uint8_t* wt = nullptr; static size_t wt_bytes = 0;
+    static float* ws = nullptr; static size_t ws_floats = 0;
+    const int KS = skinny_w8_ks(N, K, B);
+    const size_t need_w = (size_t)N * K, need_ws = (size_t)KS * SK_ROWS * N;
+    if (need_w > wt_bytes) { HIPCHK(hipDeviceSynchronize()); if (wt) hipFree(wt); HIPCHK(hipMalloc((void**)&wt, need_w)); wt_bytes = need_w; }
+    if (need_ws > ws_floats) { HIPCHK(hipDeviceSynchronize()); if (ws) hipFree(ws); HIPCHK(hipMalloc((void**)&ws, need_ws * 4)); ws_floats = need_ws; }
+    LCHK(launch_tile_pack_fp8((const uint8_t*)W8, K, wt, N, K, s));
+    LCHK(launch_skinny_w8((const bf16_t*)X, K, wt, sw, B, N, K, ws, ws_floats, s));
     std::vector<float> h((size_t)KS * SK_ROWS * N), o((size_t)B * N, 0.f);
     HIPCHK(hipMemcpyAsync(h.data(), ws, h.size() * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

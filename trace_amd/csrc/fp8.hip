@@ -96,15 +96,31 @@ __device__ __forceinline__ long hi64(const uint4& u) { return (long)(((unsigned 
 // weights streamed once from the tile-contiguous copy straight into the MFMA A operand, fp32 k-chunk partial rows out) with
 // 128-k units: a lane's 32 contiguous weight bytes are FOUR fragments, and a chunk that fits 128 KB of LDS is twice as many k wide,
 // so K is cut into half as many chunks (half the partial-row traffic).  partial[ks][m][n] = acc * sx[m] * sw[n].
-template <int NB, int NT>
+// WONLY (round 3, the "weight-only" scheme, W8A16): the same e4m3 weight stream, but the activations stay bf16 — X8 then points at bf16 rows
+// (ldx in elements), a 128-k unit parks FOUR 1 KB images per row group (the lane's 32 k as 4 x 8 bf16) instead of two, and each 8-byte
+// weight fragment is widened to bf16 in registers (v_cvt_scalef32_pk_bf16_fp8, exact: every e4m3 value is a bf16 value) for the bf16
+// MFMA.  Half the quantisation noise of W8A8 in variance (only one operand is rounded), the same weight bytes; a chunk that fits LDS is
+// half as many k wide again (twice the partial rows of the W8A8 GEMV, as many as the bf16 GEMV).  partial[ks][m][n] = acc * sw[n].
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ bf16x8_t widen8(long w) {
+    const unsigned int d0 = (unsigned int)((unsigned long long)w & 0xffffffffull), d1 = (unsigned int)((unsigned long long)w >> 32);
+    union { bf16x8_t v; bf16x2_t p[4]; } u;
+    u.p[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, 1.0f, false);
+    u.p[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, 1.0f, true);
+    u.p[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, 1.0f, false);
+    u.p[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, 1.0f, true);
+    return u.v;
+}
+template <int NB, int NT, bool WONLY = false>
 __global__ __launch_bounds__(512) void skinny_fp8_kernel(const uint8_t* __restrict__ X8, long ldx, const float* __restrict__ sx,
                                                          const uint8_t* __restrict__ W, const float* __restrict__ sw, int B, int K,
                                                          int chunk_units, int KS, int T, int WPT, int ntiles, float* __restrict__ ws, int N) {
     constexpr int UN = 2;                                // 128-k units per load batch: 4 KB (NT = 1) / 8 KB (NT = 2) of weights per wave
     constexpr int NF = NT * NB;
+    constexpr int IPU = WONLY ? 4 : 2;                   // 1 KB activation images per unit and row group
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem);                                       // [unit][half][nb][lane]
-    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem + (size_t)chunk_units * 2 * NB * 1024);  // [task][wsub][NF][lane]
+    u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem);                                       // [unit][half / quarter][nb][lane]
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem + (size_t)chunk_units * IPU * NB * 1024);  // [task][wsub][NF][lane]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nwaves = blockDim.x >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int ks = blockIdx.x % KS, rg = blockIdx.x / KS;
@@ -138,11 +154,14 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(const uint8_t* __restri
     if (work) loadw(wa, ua);
     // park X8[:, chunk]: combo c = (unit*2 + half)*NB + nb, lane (r, g) holds X8[16 nb + r][(u_beg + unit)*128 + g*32 + half*16 .. +16]
     if (!parked) {                                       // by LDS-DMA, one lane-linear 1 KB image per combo (see decode.hip); rows >= B read row B-1
-        const int combos = nu * 2 * NB;
+        const int combos = nu * IPU * NB;
         for (int c = wid; c < combos; c += nwaves) {
-            const int nb = c % NB, uh = c / NB, hh = uh & 1, u = uh >> 1;
+            const int nb = c % NB, uh = c / NB, hh = uh % IPU, u = uh / IPU;
             const int m = min(16 * nb + r, B - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X8 + (size_t)m * ldx + (size_t)(u_beg + u) * 128 + g * 32 + hh * 16),
+            // W8A8: 16 e4m3 bytes of the lane's 32-k group; weight-only: 8 bf16 (quarter hh) of it
+            const uint8_t* src = WONLY ? X8 + ((size_t)m * ldx + (size_t)(u_beg + u) * 128 + g * 32 + hh * 8) * 2
+                                       : X8 + (size_t)m * ldx + (size_t)(u_beg + u) * 128 + g * 32 + hh * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(smem + (size_t)c * 1024), 16, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -156,6 +175,25 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(const uint8_t* __restri
     auto mma = [&](uint4 (&wf)[UN][NT][2], int u) {
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
+            if (WONLY) {
+                if (u + j < ub) {
+                    bf16x8_t wq[NT][4];                  // the lane's 32 weights per tile, widened once, used by every row group
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        wq[t][0] = widen8(lo64(wf[j][t][0])); wq[t][1] = widen8(hi64(wf[j][t][0]));
+                        wq[t][2] = widen8(lo64(wf[j][t][1])); wq[t][3] = widen8(hi64(wf[j][t][1]));
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bf16x8_t xq = __builtin_bit_cast(bf16x8_t, xs[(((u + j) * 4 + q) * NB + nb) * 64 + lane]);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[t][q], xq, acc[t][nb], 0, 0, 0);
+                        }
+                }
+                continue;
+            }
             if (u + j < ub) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
@@ -210,7 +248,7 @@ __global__ __launch_bounds__(512) void skinny_fp8_kernel(const uint8_t* __restri
         for (int nb = 0; nb < NB; ++nb) {
             const int m = 16 * nb + r;
             if (m < B) {
-                const float a = sx[m];
+                const float a = WONLY ? 1.f : sx[m];
                 *reinterpret_cast<f32x4_t*>(pr + (size_t)m * N + n0 + t * 16 + g * 4) =
                     f32x4_t{acc[t][nb][0] * a * wsc[0], acc[t][nb][1] * a * wsc[1], acc[t][nb][2] * a * wsc[2], acc[t][nb][3] * a * wsc[3]};
             }
@@ -231,12 +269,12 @@ int fp8_num_cus() {
     return n;
 }
 // same partition rule as decode.hip's skinny_plan, in 128-k units (a unit is the same 2 KB of weights per 16 rows)
-Fp8Plan fp8_plan(int N, int K, int B) {
+Fp8Plan fp8_plan(int N, int K, int B, bool wonly = false) {
     Fp8Plan p{};
     p.NT = (N >= 16384 && N % 32 == 0) ? 2 : 1;
     p.NB = B > 32 ? 4 : B > 16 ? 2 : 1;
     const int U = K / 128;
-    const int cap = 64 / p.NB;
+    const int cap = (wonly ? 32 : 64) / p.NB;            // 128-k units of activations that fit 128 KB of LDS (bf16 rows: half as many)
     const int ks_min = (U + cap - 1) / cap, ks_max = std::min(U, ks_min + 4);
     p.ntiles = N / (16 * p.NT);
     const int ncu = fp8_num_cus();
@@ -256,18 +294,18 @@ Fp8Plan fp8_plan(int N, int K, int B) {
     return p;
 }
 
-template <int NB, int NT>
+template <int NB, int NT, bool WONLY = false>
 int fp8_launch(const Fp8Plan& p, const uint8_t* X8, long ldx, const float* sx, const uint8_t* W, const float* sw, int B, int N, int K, float* ws,
                hipStream_t s) {
-    const size_t lds = (size_t)p.chunk_units * 2 * NB * 1024 + (p.WPT > 1 ? (size_t)p.T * p.WPT * NT * NB * 1024 : 0);
+    const size_t lds = (size_t)p.chunk_units * (WONLY ? 4 : 2) * NB * 1024 + (p.WPT > 1 ? (size_t)p.T * p.WPT * NT * NB * 1024 : 0);
     static size_t granted = 0;
     if (lds > granted) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_fp8_kernel<NB, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_fp8_kernel<NB, NT, WONLY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
             return TRACE_ERR_HIP;
         granted = lds;
     }
-    hipLaunchKernelGGL((skinny_fp8_kernel<NB, NT>), dim3(p.grid), dim3(p.threads), lds, s, X8, ldx, sx, W, sw, B, K, p.chunk_units, p.KS, p.T,
+    hipLaunchKernelGGL((skinny_fp8_kernel<NB, NT, WONLY>), dim3(p.grid), dim3(p.threads), lds, s, X8, ldx, sx, W, sw, B, K, p.chunk_units, p.KS, p.T,
                        p.WPT, p.ntiles, ws, N);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
@@ -287,6 +325,21 @@ int launch_tile_pack_fp8(const uint8_t* src, long ldw, uint8_t* dst, int N, int 
 }
 
 int skinny_fp8_ks(int N, int K, int B) { return fp8_plan(N, K, B).KS; }
+int skinny_w8_ks(int N, int K, int B) { return fp8_plan(N, K, B, true).KS; }
+
+// the weight-only form: X bf16 [B][K] (ldx elements), e4m3 tile-layout weights + row scales; partial rows [skinny_w8_ks()][SK_ROWS][N]
+int launch_skinny_w8(const bf16_t* X, long ldx, const uint8_t* Wtiled, const float* sw, int B, int N, int K, float* ws, size_t ws_floats,
+                     hipStream_t s) {
+    if (B < 1 || B > SKINNY_ROWS || K % 128 || N % 16 || (ldx % 8)) return TRACE_ERR_ARG;
+    const Fp8Plan p = fp8_plan(N, K, B, true);
+    if (!ws || ws_floats < (size_t)p.KS * SK_ROWS * N) return TRACE_ERR_ARG;
+    const uint8_t* X8 = reinterpret_cast<const uint8_t*>(X);
+#define WL(NT_) (B <= 16 ? fp8_launch<1, NT_, true>(p, X8, ldx, nullptr, Wtiled, sw, B, N, K, ws, s) \
+               : B <= 32 ? fp8_launch<2, NT_, true>(p, X8, ldx, nullptr, Wtiled, sw, B, N, K, ws, s) \
+                         : fp8_launch<4, NT_, true>(p, X8, ldx, nullptr, Wtiled, sw, B, N, K, ws, s))
+    return p.NT == 2 ? WL(2) : WL(1);
+#undef WL
+}
 
 // partial rows [skinny_fp8_ks()][SK_ROWS][N] fp32 in ws (>= KS * SK_ROWS * N floats): the consumers of decode.hip sum them
 int launch_skinny_fp8(const uint8_t* X8, long ldx, const float* sx, const uint8_t* Wtiled, const float* sw, int B, int N, int K, float* ws,

@@ -160,6 +160,11 @@ int launch_tile_pack_fp8(const uint8_t* src, long ldw, uint8_t* dst, int N, int 
 int launch_skinny_fp8(const uint8_t* X8, long ldx, const float* sx, const uint8_t* Wtiled, const float* sw, int B, int N, int K, float* ws,
                       size_t ws_floats, hipStream_t s);
 int skinny_fp8_ks(int N, int K, int B);
+// weight-only (W8A16) form of the same GEMV: bf16 activations, e4m3 weights widened to bf16 in registers, bf16 MFMA; partial rows
+// [skinny_w8_ks(N,K,B)][SK_ROWS][N] = (X . W8^T) * sw[n]
+int launch_skinny_w8(const bf16_t* X, long ldx, const uint8_t* Wtiled, const float* sw, int B, int N, int K, float* ws, size_t ws_floats,
+                     hipStream_t s);
+int skinny_w8_ks(int N, int K, int B);
 
 // ---- STC connector support (stc.hip): channels-last [n][h][w][C] row kernels ----
 int launch_dwconv3x3(const bf16_t* x, const bf16_t* w /*[C][9]*/, bf16_t* y, int N, int H, int W, int C, hipStream_t s);

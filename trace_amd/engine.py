@@ -52,8 +52,9 @@ class TraceEngine:
             cfg.vision_hidden_size, cfg.vision_intermediate_size, cfg.vision_layers_used, cfg.vision_num_heads,
             cfg.vision_image_size, cfg.vision_patch_size, cfg.vision_layer_norm_eps, cfg.num_slots, cfg.slot_ln_eps,
             cfg.slot_rope_base, max_frames, max_ctx, max_batch, max_new_tokens,
-            1 if cfg.mm_projector_type == "stc_connector" else 0, self.vit_batch_frames, 1 if llm_fp8 else 0)
-        self.llm_fp8 = bool(llm_fp8)
+            1 if cfg.mm_projector_type == "stc_connector" else 0, self.vit_batch_frames,
+            {"w8a8": 1, "weight_only": 2}.get(llm_fp8, 1 if llm_fp8 else 0) if llm_fp8 else 0)
+        self.llm_fp8 = bool(llm_fp8)          # False / True = "w8a8" / "weight_only" (W8A8 prefill GEMMs, weight-only decode GEMVs)
         h = C.c_void_p()
         _lib.check(self.lib.trace_ctx_create(C.byref(c), device, C.byref(h)))
         self.h = h
@@ -594,6 +595,16 @@ class ops:
         Cc = torch.empty((M, No), dtype=torch.bfloat16, device=A8.device)
         _lib.check(lib.trace_op_gemm_fp8(_ptr(A8), _ptr(sa), _ptr(W8), _ptr(sw), _ptr(Cc), _ptr(R), M, N, K, epilogue, _stream()))
         return Cc
+
+    @staticmethod
+    def skinny_w8(X, W8, sw):
+        """weight-only decode GEMV: X bf16 [B, K], W8 uint8 e4m3 [N, K] + row scales -> fp32 [B, N]"""
+        lib = _lib.load()
+        Bn, K = X.shape
+        N = W8.shape[0]
+        out = torch.empty((Bn, N), dtype=torch.float32, device=X.device)
+        _lib.check(lib.trace_op_skinny_w8(_ptr(X), _ptr(W8), _ptr(sw), _ptr(out), Bn, N, K, _stream()))
+        return out
 
     @staticmethod
     def skinny_fp8(X8, sx, W8, sw):

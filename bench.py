@@ -156,10 +156,15 @@ def main():
     ap.add_argument("--max-new", type=int, default=None)
     ap.add_argument("--fp8", dest="fp8", action="store_true", default=None, help="decoder projections on the fp8 (e4m3 W8A8) path (default: on for --config c5)")
     ap.add_argument("--no-fp8", dest="fp8", action="store_false")
+    ap.add_argument("--fp8-scheme", choices=["w8a8", "weight_only"], default="weight_only",
+                    help="fp8 path: W8A8 everywhere, or W8A8 prefill GEMMs + weight-only (bf16 activations) decode GEMVs (default; tests/test_gpu_fp8.py: fewer 13-way arg-max flips)")
     ap.add_argument("--plumbing-check", action="store_true", help="launcher / rendezvous / gather only, no kernels (CPU-testable)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the captured hipGraph for decode steps (default: eager launches, which run at the same speed "
                          "— the step is GPU-bound — and allow the per-launch HIP-event roofline probe in the timed region)")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", default=True,
+                    help="run the timed steps strictly one after the other (default: two-stage pipeline over the steps — batch k decodes on one "
+                         "stream while batch k+1 runs its ViT + prefill on another, TraceEngine.generate_stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="tiny geometry (plumbing check)")
     ap.add_argument("--vit-batch", type=int, default=None, help="frames per ViT call (default: TraceEngine.full_round_frames)")
@@ -194,8 +199,9 @@ def main():
     n_text = 24 if args.tiny else preset["n_text"]
     ids = synth.synth_prompt_ids(cfg, n_text=n_text, video_pos=10 if args.tiny else preset["video_pos"]).tolist()
     L = n_text - 1 + args.frames * cfg.tokens_per_frame
-    eng = TraceEngine(cfg, device=local, max_batch=B, max_ctx=(L + n_new + 63) // 64 * 64, max_frames=args.frames,
-                      max_new_tokens=n_new, vit_batch_frames=args.vit_batch, llm_fp8=args.fp8)
+    pipelined = args.pipeline and 2 * B <= 256 and args.steps > 1
+    eng = TraceEngine(cfg, device=local, max_batch=2 * B if pipelined else B, max_ctx=(L + n_new + 63) // 64 * 64, max_frames=args.frames,
+                      max_new_tokens=n_new, vit_batch_frames=args.vit_batch or TraceEngine.full_round_frames(cfg), llm_fp8=(args.fp8_scheme if args.fp8 else False))
     t0 = time.perf_counter()
     eng.load_weights(synth.iter_weights(cfg, device=str(dev)))
     torch.cuda.synchronize()
@@ -218,14 +224,27 @@ def main():
                 raise SystemExit(f"bench: the all-gather returned {len(g)} ranks, expected {world}")
         return out
 
-    for _ in range(args.warmup):
-        step()
+    def gather(out):
+        if world > 1 or torch.distributed.is_initialized():
+            g = tdist.gather_outputs(out, n_new, B, dev)
+            ranks_seen[0] = len(g)
+            if len(g) != world or any(len(x) != B for x in g):
+                raise SystemExit(f"bench: the all-gather returned {len(g)} ranks, expected {world}")
+        return out
+
+    def run(k):
+        """k steps: strictly one after the other, or as a two-stage pipeline over the steps (every step's work, the pipeline's fill and drain
+        included, is inside the caller's timed region; the ids of step i are gathered as soon as its decode has finished)"""
+        if not pipelined or k < 2:
+            return [step() for _ in range(k)]
+        batch = (videos, ts, prompt, heads, forced)
+        return [gather(o[0]) for o in eng.generate_stream([batch] * k, n_new, eos=-1, use_graph=args.graph)]
+
+    run(args.warmup)
     eng.set_profile(2)
     tdist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    outs = []
-    for _ in range(args.steps):
-        outs.append(step())
+    outs = run(args.steps)
     tdist.barrier(); torch.cuda.synchronize()
     dt = tdist.max_over_ranks(time.perf_counter() - t0)
     out = outs[-1]
@@ -287,13 +306,17 @@ def main():
             "metric": "videos/sec + decode tok/s, TRACE-7B 128-frame, 1/2/4/8 MI355X",
             "value": vps, "unit": "videos/s", "n_gpus": world, "rccl_ranks": ranks_seen[0], "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("fp8 e4m3 (W8A8, fp32 accumulate) in the decoder projections; bf16 elsewhere (ViT, attention, KV cache, norms, heads)"
-                      if args.fp8 else "bf16"), "data": "synthetic",
+            "dtype": (("fp8 e4m3 weights in the decoder projections: W8A8 (fp8 MFMA, fp32 accumulate) in the prefill GEMMs, " +
+                       ("weight-only (bf16 activations, bf16 MFMA) in the decode GEMVs" if args.fp8_scheme == "weight_only" else "W8A8 in the decode GEMVs") +
+                       "; bf16 elsewhere (ViT, attention, KV cache, norms, heads)") if args.fp8 else "bf16"), "data": "synthetic",
             "config": {"workload": ("tiny plumbing check" if args.tiny else
                                     f"{preset['name']}, {args.frames}x336^2 frames, prefill L={Ls}, {n_new} greedy tokens, heads=[1]"),
                        "baseline_config": args.config,
                        "videos_per_step_per_gpu": B, "frames": args.frames, "prefill_len": Ls, "new_tokens": n_new, "head_schedule": ("forced MR pattern: 14 time + 4 score + 14 text steps per 32 tokens" if preset["schedule"] == "mr" else "forced DVC pattern per event: 14 time + 4 score + 33 text steps") + " (argmax still computed every step)",
                        "decode_launch": "hipGraph" if args.graph else "eager", "parallelism": f"dp{world} (replica per GPU)",
+                       "step_schedule": ("two-stage pipeline over the timed steps: step k's decode on one HIP stream under step k+1's ViT + prefill on another "
+                                         "(fill and drain inside the timed region; the roofline brackets are taken in the fill / drain phases only)"
+                                         if pipelined else "steps strictly one after the other"),
                        "weights": "random-init (device RNG), reference architecture"},
             "decode_tok_s": world * B * (n_new - 1) / (t_dec * 1e-3),
             "stages_ms": {"vit_slotpool_per_video": t_enc, "prefill_per_video": t_pre, f"decode_{n_new - 1}_steps_batch{B}": t_dec,

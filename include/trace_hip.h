@@ -34,7 +34,7 @@ typedef struct trace_config {
     float slot_eps, slot_rope_base;
     int32_t max_frames;      /* largest T per video                                    */
     int32_t max_ctx;         /* KV-cache length per sequence slot (prefill + new tokens) */
-    int32_t max_batch;       /* KV-cache sequence slots, <= 128; one decode batch takes at most 64 of them (the rest can be
+    int32_t max_batch;       /* KV-cache sequence slots, <= 256; one decode batch takes at most 128 of them (64 on the fp8 path; the rest can be
                               * prefilled meanwhile: trace_amd.engine.TraceEngine.generate_stream) */
     int32_t max_new_tokens;  /* capacity of the on-device output id buffer               */
     int32_t projector_type;  /* 0 = spatial_slot (TRACE), 1 = stc_connector (legacy API) */
@@ -147,6 +147,9 @@ int trace_set_gemm_cus(trace_ctx* ctx, int n);
  * per step, and of its skinny-GEMM launches if profiling was enabled with trace_set_profile(ctx, 1). */
 int trace_set_profile(trace_ctx* ctx, int on);
 int trace_get_profile(trace_ctx* ctx, float* out, int n);
+/* Which per-launch brackets profiling mode 2 takes: bit 0 = the ViT fc1 GEMM, bit 1 = the decode step's dominant kernel.  A pipelined caller
+ * (two stages on two streams) leaves a stage's bracket on only while that stage has the GPU to itself (pipeline fill / drain). */
+int trace_set_profile_brackets(trace_ctx* ctx, int mask);
 
 /* ---- kernel-level entry points (unit tests / microbenchmarks; raw device pointers) ---- */
 int trace_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* R,

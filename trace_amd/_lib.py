@@ -57,6 +57,7 @@ SIGNATURES = {
     "trace_set_gemm_cus": (I, [P, I]),
     "trace_set_profile": (I, [P, I]),
     "trace_get_profile": (I, [P, P, I]),
+    "trace_set_profile_brackets": (I, [P, I]),
     "trace_op_gemm": (I, [P, I, P, I, P, I, P, P, I, I, I, I, I, P]),
     "trace_op_set_gemm_variant": (I, [I]),
     "trace_op_layernorm": (I, [P, P, P, P, I, I, F, P]),

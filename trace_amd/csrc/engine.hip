@@ -34,7 +34,7 @@ struct LlmLayer {
 };
 struct StcBlock { bf16_t *w1, *n1w, *n1b, *wdw, *n2w, *n2b, *fc1w, *fc1b, *fc2w, *fc2b, *w3, *n3w, *n3b, *wd, *ndw, *ndb; int cin, rd; };
 
-constexpr int MAX_SLOTS = 128;   // KV-cache sequence slots per context (a decode batch is at most SK_ROWS of them)
+constexpr int MAX_SLOTS = 256;   // KV-cache sequence slots per context (a decode batch is at most SK_ROWS of them)
 static int g_ctx_per_dev[16] = {0};
 
 struct trace_ctx {
@@ -101,6 +101,9 @@ struct trace_ctx {
     std::vector<hipStream_t> streams;   // trace_stream_create
     // profiling
     int profile = 0;                  // 1: time decode_steps calls; 2: also bracket the layer-0 gate|up GEMV launch
+    int bracket_mask = 3;             // which per-launch brackets profile == 2 takes: bit 0 = the ViT fc1 GEMM, bit 1 = the decode step's kernel
+                                      // (trace_set_profile_brackets: a pipelined caller switches a stage's bracket off while the other stage's
+                                      // kernels share the GPU with it — an event pair then times the queueing, not the kernel)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;      // event pool for per-launch brackets (eager mode)
     int kev_used = 0;
@@ -157,7 +160,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     c->fp8_wonly = cfg->llm_weights_fp8 == 2;
     if (c->fp8 && (c->H % 128 || c->I % 128 || c->I > 16384)) return bad("fp8 weight path needs hidden / intermediate sizes that are multiples of 128 (intermediate <= 16384)");
     if (!c->stc && (c->S != 8 || c->vh > 1024)) return bad("slot pool kernel needs 8 slots and mm_hidden <= 1024");
-    if (c->max_B < 1 || c->max_B > MAX_SLOTS) return bad("max_batch (KV slots) must be in [1,128]");
+    if (c->max_B < 1 || c->max_B > MAX_SLOTS) return bad("max_batch (KV slots) must be in [1,256]");
     c->nsplit = 32;                                           // upper bound (workspace size); per-batch value below
     {
         const int g2 = c->G / 2 + 1;
@@ -577,14 +580,15 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
         LCHK(launch_layernorm(c->vX, vh, c->vH, vh, L.ln2w, L.ln2b, Mv, vh, c->c.v_eps, s));
         // MFMA roofline probe: HIP events around ONE fc1 GEMM launch per call — of the largest shape seen since
         // trace_set_profile only (the short tail call of a frame stream would mix two shapes into one average)
-        if (l == 0 && c->profile == 2 && Mv > c->mM) { c->mM = Mv; c->msum_ms = 0.0; c->msamples = 0; }
-        const bool probe = (l == 0 && c->profile == 2 && Mv == c->mM);
+        const bool vprof = c->profile == 2 && (c->bracket_mask & 1);
+        if (l == 0 && vprof && Mv > c->mM) { c->mM = Mv; c->msum_ms = 0.0; c->msamples = 0; }
+        const bool probe = (l == 0 && vprof && Mv == c->mM);
         if (probe) hipEventRecord(c->mev0, s);
         TRY(gemm(c->vH, vh, L.w1, vh, c->vMLP, vi, L.b1, nullptr, 0, Mv, vi, vh, EPI_QUICKGELU, s));
         if (probe) { hipEventRecord(c->mev1, s); c->mflops = 2.0 * Mv * (double)vi * vh; }
         TRY(gemm(c->vMLP, vi, L.w2, vi, c->vX, vh, L.b2, c->vX, vh, Mv, vh, vi, EPI_RESIDUAL, s));
     }
-    if (c->profile == 2 && c->vL > 0 && Mv == c->mM) {
+    if (c->profile == 2 && (c->bracket_mask & 1) && c->vL > 0 && Mv == c->mM) {
         hipEventSynchronize(c->mev1);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->mev0, c->mev1) == hipSuccess) { c->msum_ms += ms; c->msamples += 1; }
@@ -962,7 +966,8 @@ static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* l
 static int decode_nsplit(int B) { const int n = (40 + B / 2) / B; return n < 1 ? 1 : n > 16 ? 16 : n; }
 
 static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* logits_out, hipStream_t s);
-int g_decode_wide_min = SKINNY_ROWS;   // smallest batch that takes the wide (GEMM) decode step: at 64 rows it measured 7.68 vs the GEMV path's 7.88 ms per step (r03_decode_gemm_ab_b64.txt); A/B: trace_op_set_gemm_variant(140 + x): 65 / 33 / 17 / 64
+int g_decode_wide_min = 32;   // smallest batch that takes the wide (GEMM) decode step — ms per step, GEMV path vs wide step (r03_decode_gemm_ab.txt): 32 rows 5.39 / 5.30, 48 rows
+                                 // 7.19 / 6.51, 64 rows 7.88 / 7.11; A/B: trace_op_set_gemm_variant(140 + x): 65 / 33 / 17 / 32
 int g_decode_gemm_tiled = 5;   // wide decode step, GemmArgs::w_tiled: bit 0 = weights from the decode tile copies (0 = row-major prefill copies), bit 2 = 4-stage
                                // K-tile ring (A/B: trace_op_set_gemm_variant(130 + x))
 
@@ -995,7 +1000,7 @@ static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
         // roofline probe (profile == 2, eager launches): HIP events around ONE launch of the step's dominant kernel — the layer-0 decode
         // attention, which streams the batch's whole KV cache of that layer
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (l == 0 && c->profile == 2 && s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) {
+        if (l == 0 && c->profile == 2 && (c->bracket_mask & 2) && s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) {
             e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2;
             c->kbytes_sum += (double)(c->pos_sum + (long)B * (c->step_in_call + 1)) * c->NKV * HD * 2 * 2;   // K + V^T rows of every sequence, bf16
         }
@@ -1066,7 +1071,7 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
         LCHK(launch_add_rmsnorm(c->sk_ws, ks_o, c->dX, H, c->dX, H, W.rms2, c->dH, H, B, H, c->c.rms_eps, s, f8 ? c->dH8 : nullptr, f8 ? c->dsh : nullptr));
         // roofline probe: HIP events around ONE launch of the dominant kernel (layer 0 gate|up GEMV) per step
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (l == 0 && c->profile == 2) {
+        if (l == 0 && c->profile == 2 && (c->bracket_mask & 2)) {
             // (event-record nodes captured into a hipGraph do not yield usable timestamps on ROCm 7.2: eager launches only)
             if (s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) { e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2; }
         }
@@ -1253,6 +1258,11 @@ extern "C" int trace_set_profile(trace_ctx* c, int on) {
     c->profile = on; c->ksum_ms = 0.0; c->ksamples = 0; c->kev_used = 0; c->kbytes_sum = 0.0; c->msum_ms = 0.0; c->msamples = 0; c->mM = 0;
     return TRACE_OK;
 }
+extern "C" int trace_set_profile_brackets(trace_ctx* c, int mask) {
+    if (!c) return fail(TRACE_ERR_ARG, "null ctx");
+    c->bracket_mask = mask & 3;
+    return TRACE_OK;
+}
 extern "C" int trace_get_profile(trace_ctx* c, float* out, int n) {
     if (!c || !out) return fail(TRACE_ERR_ARG, "null argument");
     for (int i = 0; i < n && i < 8; ++i) out[i] = c->prof[i];
@@ -1277,7 +1287,7 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
-    if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : SKINNY_ROWS; return TRACE_OK; }
+    if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : 32; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
     if (variant >= 400 && variant < 404) { g_gemm_ldr_opt = variant - 400; return TRACE_OK; }   // microbench: attention phase cut-offs

@@ -427,11 +427,15 @@ class TraceEngine:
 
         pending = None                                  # (bank, heads, forced, B, ready event): prefilled, waiting for its decode
         bank = 0
+        # profiling mode 2 brackets single launches with HIP events: meaningful only while a stage has the GPU to itself — the first batch's
+        # encode (pipeline fill) and the last batch's decode (drain); in between the brackets are off
+        brackets = lambda m: _lib.check(self.lib.trace_set_profile_brackets(self.h, m))
         with cf.ThreadPoolExecutor(max_workers=1, thread_name_prefix="trace-decode") as pool:
             for item in batches:
                 videos, timestamps, input_ids, heads, forced = item
                 if len(videos) > min(half, self.decode_batch_max):
                     raise ValueError(f"batch of {len(videos)} exceeds max_batch // 2 = {half} (two KV banks)")
+                brackets(1 if pending is None else 0)
                 fut = pool.submit(dec_job, *pending) if pending is not None else None
                 try:
                     with torch.cuda.stream(enc_s):
@@ -445,7 +449,11 @@ class TraceEngine:
                 pending = (bank, list(heads), forced, len(videos), ready)
                 bank ^= 1
             if pending is not None:
-                out = pool.submit(dec_job, *pending).result()
+                brackets(2)
+                try:
+                    out = pool.submit(dec_job, *pending).result()
+                finally:
+                    brackets(3)
                 cur.wait_stream(dec_s); cur.wait_stream(enc_s)
                 yield out
 

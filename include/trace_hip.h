@@ -159,6 +159,12 @@ int trace_op_set_gemm_variant(int variant);
 /* profiling: device buffer of 8 x uint64 per workgroup receiving phase time stamps of every later GEMM launch (NULL = off) */
 int trace_op_set_gemm_trace(void* buf);
 int trace_op_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, float eps, void* stream);
+/* The ViT's LayerNorm fold, piece by piece: C = act(LayerNorm(X) . W^T + bias) as one GEMM on the raw rows (epilogue 0 / 2 = QuickGELU; N % 256 == 0,
+   K % 64 == 0), and C = A . W^T + bias + R with the row statistics (rstd, -mean * rstd) of C [M][2] that the next such GEMM takes */
+int trace_op_gemm_lnfold(const void* X, const void* W, const void* gamma, const void* beta, const void* bias, void* C, int M, int N, int K, float eps,
+                         int epilogue, void* stream);
+int trace_op_gemm_residual_stats(const void* A, const void* W, const void* bias, const void* R, void* C, float* stats_out, int M, int N, int K, float eps,
+                                 void* stream);
 int trace_op_rmsnorm(const void* x, void* y, const void* w, int rows, int D, float eps, void* stream);
 int trace_op_attention(const void* Q, const void* K, const void* V, void* O, void* vt_scratch, int batch, int heads,
                        int kv_heads, int nq, int nkv, int head_dim, int causal, float scale, void* stream);

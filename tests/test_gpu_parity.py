@@ -306,6 +306,36 @@ def test_vit_large_geometry_vs_reference_fixture(golden_dir):
     print("slots: max err", es.max().item(), "ref max", rs.abs().max().item())
     assert es.max().item() < 0.05 * max(1.0, rs.abs().max().item()), (es.max().item(), rs.abs().max().item())
     eng.close()
+    # Round 3 — the LayerNorm fold: from ~20 frames up every shape of the tower runs on the 256x256 kernels and no LayerNorm is a pass of its
+    # own (qkv / fc1 on raw rows with pre-scaled weights + a row-statistics epilogue).  The fixture's frame 24 times over takes that path;
+    # every copy must stay inside the same budget against the reference's fp32 features, the unfolded run of the same call (LayerNorm
+    # kernels, trace_op_set_gemm_variant(150)) is the A/B, and the copies of a frame agree with each other bit for bit.
+    from trace_amd.engine import ops
+    eng = TraceEngine(cfg, max_batch=1, max_ctx=512, max_frames=24, max_new_tokens=8)
+    eng.load_weights(sd.items())
+    many = frames.expand(24, -1, -1, -1).contiguous()
+    folded = eng.vit_forward(many).float().cpu()
+    try:
+        ops.set_gemm_variant(150)
+        plain = eng.vit_forward(many).float().cpu()
+    finally:
+        ops.set_gemm_variant(151)
+    assert not torch.equal(folded, plain), "the LayerNorm fold did not engage at 24 frames"
+    for name, f in (("folded", folded), ("LayerNorm kernels", plain)):
+        assert all(torch.equal(f[0], f[i]) for i in range(1, 24)), name
+        e = (f[0] - ref).abs()
+        rl2 = (f[0] - ref).norm().item() / ref.norm().item()
+        print(f"{name}, 24 frames: max {e.max().item():.4f} mean {e.mean().item():.5f} rel L2 {rl2:.5f}")
+        assert e.max().item() < 0.5 and e.mean().item() < 0.02 * ref.abs().mean().item() and rl2 < 0.02, (name, e.max().item(), e.mean().item(), rl2)
+    d = (folded[0] - plain[0]).abs()
+    assert d.max().item() < 0.5 and d.mean().item() < 0.02 * ref.abs().mean().item()
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "parity_measured.txt"), "a") as fh:
+            for name, f in (("LayerNorm fold", folded), ("LayerNorm kernels", plain)):
+                fh.write(f"ViT-L/14-336 real geometry, 24 frames, {name}: rel L2 vs reference {(f[0] - ref).norm().item() / ref.norm().item():.5f}, "
+                         f"max {(f[0] - ref).abs().max().item():.4f}\n")
+    eng.close()
 
 
 def test_real_width_decoder_layer_vs_reference_fixture(golden_dir):

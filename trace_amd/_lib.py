@@ -61,6 +61,8 @@ SIGNATURES = {
     "trace_op_gemm": (I, [P, I, P, I, P, I, P, P, I, I, I, I, I, P]),
     "trace_op_set_gemm_variant": (I, [I]),
     "trace_op_layernorm": (I, [P, P, P, P, I, I, F, P]),
+    "trace_op_gemm_lnfold": (I, [P, P, P, P, P, P, I, I, I, F, I, P]),
+    "trace_op_gemm_residual_stats": (I, [P, P, P, P, P, P, I, I, I, F, P]),
     "trace_op_rmsnorm": (I, [P, P, P, I, I, F, P]),
     "trace_op_attention": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "trace_op_skinny_gemm": (I, [P, P, P, P, I, I, I, I, I, P]),

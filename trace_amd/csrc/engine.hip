@@ -23,7 +23,11 @@ static int fail(int code, const std::string& m) { g_err = m; return code; }
 #define LCHK(x) do { int r_ = (x); if (r_ != TRACE_OK) return fail(r_, std::string("launch failed: ") + #x); } while (0)
 #define TRY(x) do { int r_ = (x); if (r_ != TRACE_OK) { if (g_err.empty()) g_err = std::string("failed: ") + #x; return r_; } } while (0)
 
-struct VitLayer { bf16_t *ln1w, *ln1b, *wqkv, *bqkv, *wo, *bo, *ln2w, *ln2b, *w1, *b1, *w2, *b2; };
+struct VitLayer {
+    bf16_t *ln1w, *ln1b, *wqkv, *bqkv, *wo, *bo, *ln2w, *ln2b, *w1, *b1, *w2, *b2;
+    // LayerNorm fold (made at finalize): weights pre-multiplied by the LayerNorm weight, their row sums c1 and the folded bias c2
+    bf16_t *wqkv_f, *c1q, *c2q, *w1_f, *c1f, *c2f;
+};
 struct LlmLayer {
     bf16_t *rms1, *wqkv, *wo, *rms2, *wgu, *wd;
     bf16_t *wqkv_d, *wo_d, *wgu_d, *wd_d;      // decode copies in the GEMV tile layout (decode.hip: launch_tile_pack)
@@ -68,6 +72,7 @@ struct trace_ctx {
     size_t kv_head_stride, slot_stride, layer_stride;
     // ViT workspaces
     bf16_t *vX, *vH, *vQKV, *vVT, *vMLP;
+    float *vStats = nullptr, *vStatsPart = nullptr;      // LayerNorm fold: (rstd, -mean rstd) per token row; per-column-tile (sum, sum of squares)
     bf16_t *sl_res, *sl_out, *video;     // [T*S, vh], [T*S, H], [T*TPF, H]
     float* sl_ws = nullptr; size_t sl_ws_floats = 0;   // slot pool: per-part softmax partials
     int video_rows = 0;
@@ -178,6 +183,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     for (auto& l : c->vit) {
         A(l.ln1w, vh); A(l.ln1b, vh); A(l.wqkv, 3 * vh * vh); A(l.bqkv, 3 * vh); A(l.wo, vh * vh); A(l.bo, vh);
         A(l.ln2w, vh); A(l.ln2b, vh); A(l.w1, vi * vh); A(l.b1, vi); A(l.w2, vh * vi); A(l.b2, vh);
+        A(l.wqkv_f, 3 * vh * vh); A(l.c1q, 3 * vh); A(l.c2q, 3 * vh); A(l.w1_f, vi * vh); A(l.c1f, vi); A(l.c2f, vi);
     }
     if (!c->stc) { A(c->sl_lnw, vh); A(c->sl_lnb, vh); A(c->sl_slots, vh * c->S); A(c->sl_readout, H * vh); }
     else {
@@ -220,6 +226,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     // --- ViT workspaces ---
     const size_t Tm = cfg->max_frames, Tv_ = c->vit_frames, Mv = Tv_ * c->NT;      // tower workspaces: vit_batch_frames at a time
     A(c->vX, Mv * vh); A(c->vH, Mv * vh); A(c->vQKV, Mv * 3 * vh); A(c->vVT, Tv_ * vh * c->tokpad);
+    A(c->vStats, Mv * 2); A(c->vStatsPart, Mv * 2 * std::max<size_t>(1, vh / 256));
     {
         const size_t mlp = Mv * vi, im2 = Tv_ * c->GG * c->Kpad;
         A(c->vMLP, mlp > im2 ? mlp : im2);
@@ -496,6 +503,11 @@ extern "C" int trace_ctx_finalize(trace_ctx* c) {
         HIPCHK(hipMemcpy(c->rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
     }
+    // LayerNorm fold of the ViT: qkv and fc1 weights pre-multiplied by the preceding LayerNorm's weight, with the two correction rows
+    for (auto& l : c->vit) {
+        LCHK(launch_ln_fold_weights(l.wqkv, c->vh, l.ln1w, l.ln1b, l.bqkv, l.wqkv_f, l.c1q, l.c2q, 3 * c->vh, c->vh, 0));
+        LCHK(launch_ln_fold_weights(l.w1, c->vh, l.ln2w, l.ln2b, l.b1, l.w1_f, l.c1f, l.c2f, c->vi, c->vh, 0));
+    }
     // decode copies of the LLM matrices in the GEMV tile layout (288 GB of HBM: +14.5 GB buys ~25% on the weight stream)
     for (auto& l : c->llm) {
         LCHK(launch_tile_pack(l.wqkv, c->H, l.wqkv_d, c->QKV, c->H, 0));
@@ -528,6 +540,7 @@ extern "C" int trace_ctx_finalize(trace_ctx* c) {
 }
 
 // ------------------------------------------------------------------------------------------------ ViT
+int g_vit_ln_fold = 1;      // 0: the ViT keeps its LayerNorm kernels at every size (A/B: trace_op_set_gemm_variant(150 + x))
 static unsigned long long* g_gemm_trace = nullptr;      // tools/gemm_trace.py
 extern "C" int trace_op_set_gemm_trace(void* buf) { g_gemm_trace = (unsigned long long*)buf; return TRACE_OK; }
 static int gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* C, int ldc, const bf16_t* bias, const bf16_t* R,
@@ -568,8 +581,38 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
     a.scale = 0.125f; a.causal = 0;
     a.Vrow = c->vQKV + 2 * vh; a.vr_bs = a.q_bs; a.vr_hs = 64; a.vr_rs = 3 * vh;
     a.v_perm = attn_vit_wants_perm(NT, true) ? (attn_vit_rowmajor_v() ? 2 : 1) : 0;     // 2: V read row-major from vQKV, no transpose pass
+    // LayerNorm fold (round 3): when this call's shapes run on the kernels that carry it — qkv / fc1 on the persistent GEMM, out-proj / fc2 on the
+    // loader-wave GEMM — neither LayerNorm of a layer is a pass of its own: the residual GEMMs' epilogues leave the row sums of what they store,
+    // a finalize kernel turns them into (rstd, -mean rstd), and the next GEMM runs on the raw residual stream with pre-scaled weights and applies
+    // rstd (acc - mean c1) + c2 in its epilogue.  Smaller calls (a few frames) keep the LayerNorm kernel.
+    const bool fold = g_vit_ln_fold && vh % 256 == 0 && gemm_routes_to_pers(Mv, 3 * vh, vh) && gemm_routes_to_pers(Mv, vi, vh) &&
+                      gemm_routes_to_ldr(Mv, vh, vh) && gemm_routes_to_ldr(Mv, vh, vi);
+    auto fgemm = [&](const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* Cc, int ldc, const bf16_t* c2, const bf16_t* c1, const bf16_t* R,
+                     int N, int K, int epi, float* stats_part) -> int {
+        GemmArgs g{A, lda, W, ldw, Cc, ldc, c2, R, R ? vh : 0, Mv, N, K, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, 0, c1 ? c->vStats : nullptr, c1, stats_part};
+        const int rc = launch_gemm_bf16(g, epi, s);
+        if (rc != TRACE_OK) return fail(rc, "ViT GEMM launch failed (LayerNorm fold)");
+        return TRACE_OK;
+    };
+    if (fold) LCHK(launch_ln_row_stats(c->vX, vh, Mv, vh, c->c.v_eps, c->vStats, s));       // layer 0's input came from vit_assemble, not from a GEMM
     for (int l = 0; l < c->vL; ++l) {
         const VitLayer& L = c->vit[l];
+        if (fold) {
+            TRY(fgemm(c->vX, vh, L.wqkv_f, vh, c->vQKV, 3 * vh, L.c2q, L.c1q, nullptr, 3 * vh, vh, EPI_NONE, nullptr));
+            if (a.v_perm != 2)
+                LCHK(launch_transpose_v(c->vQKV + 2 * vh, (long)NT * 3 * vh, 64, 3 * vh, c->vVT, a.v_bs, a.v_hs, c->tokpad, NT, 64, c->vheads, T, s, a.v_perm));
+            LCHK(launch_attn_vit(a, s));
+            TRY(fgemm(c->vH, vh, L.wo, vh, c->vX, vh, L.bo, nullptr, c->vX, vh, vh, EPI_RESIDUAL, c->vStatsPart));
+            LCHK(launch_ln_stats_finalize(c->vStatsPart, vh / 256, Mv, vh, c->c.v_eps, c->vStats, s));
+            if (l == 0 && c->profile == 2 && (c->bracket_mask & 1) && Mv > c->mM) { c->mM = Mv; c->msum_ms = 0.0; c->msamples = 0; }
+            const bool probe = (l == 0 && c->profile == 2 && (c->bracket_mask & 1) && Mv == c->mM);
+            if (probe) hipEventRecord(c->mev0, s);
+            TRY(fgemm(c->vX, vh, L.w1_f, vh, c->vMLP, vi, L.c2f, L.c1f, nullptr, vi, vh, EPI_QUICKGELU, nullptr));
+            if (probe) { hipEventRecord(c->mev1, s); c->mflops = 2.0 * Mv * (double)vi * vh; }
+            TRY(fgemm(c->vMLP, vi, L.w2, vi, c->vX, vh, L.b2, nullptr, c->vX, vh, vi, EPI_RESIDUAL, c->vStatsPart));
+            if (l + 1 < c->vL) LCHK(launch_ln_stats_finalize(c->vStatsPart, vh / 256, Mv, vh, c->c.v_eps, c->vStats, s));
+            continue;
+        }
         LCHK(launch_layernorm(c->vX, vh, c->vH, vh, L.ln1w, L.ln1b, Mv, vh, c->c.v_eps, s));
         TRY(gemm(c->vH, vh, L.wqkv, vh, c->vQKV, 3 * vh, L.bqkv, nullptr, 0, Mv, 3 * vh, vh, EPI_NONE, s));
         if (a.v_perm != 2)
@@ -1287,6 +1330,7 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
+    if (variant >= 150 && variant <= 151) { g_vit_ln_fold = variant - 150; return TRACE_OK; }
     if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : 32; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
@@ -1420,6 +1464,43 @@ extern "C" int trace_op_skinny_w8(const void* X, const void* W8, const float* sw
         for (int b = 0; b < B; ++b)
             for (int n = 0; n < N; ++n) o[(size_t)b * N + n] += h[((size_t)ks * SK_ROWS + b) * N + n];
     HIPCHK(hipMemcpy(out, o.data(), o.size() * 4, hipMemcpyHostToDevice));
+    return TRACE_OK;
+}
+
+// ---- LayerNorm-fold hooks (tests/test_gpu_kernels.py) ----
+// C = act(LayerNorm(X; gamma, beta, eps) . W^T + bias) as ONE persistent GEMM on the raw rows: row statistics of X, weights pre-multiplied by gamma,
+// the fold epilogue (gemm_pers.hip).  epilogue 0 none / 2 QuickGELU.  M >= 1, N % 256 == 0, K % 64 == 0, K >= 128.
+extern "C" int trace_op_gemm_lnfold(const void* X, const void* W, const void* gamma, const void* beta, const void* bias, void* C, int M, int N, int K,
+                                    float eps, int epilogue, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    bf16_t *wf = nullptr, *c1 = nullptr, *c2 = nullptr; float* st = nullptr;
+    HIPCHK(hipMalloc((void**)&wf, (size_t)N * K * 2)); HIPCHK(hipMalloc((void**)&c1, (size_t)N * 2)); HIPCHK(hipMalloc((void**)&c2, (size_t)N * 2));
+    HIPCHK(hipMalloc((void**)&st, (size_t)M * 8));
+    int rc = launch_ln_fold_weights((const bf16_t*)W, K, (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)bias, wf, c1, c2, N, K, s);
+    if (rc == TRACE_OK) rc = launch_ln_row_stats((const bf16_t*)X, K, M, K, eps, st, s);
+    if (rc == TRACE_OK) {
+        GemmArgs g{(const bf16_t*)X, K, wf, K, (bf16_t*)C, N, c2, nullptr, 0, M, N, K, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, 0, st, c1, nullptr};
+        rc = launch_gemm_bf16(g, epilogue, s);
+    }
+    hipStreamSynchronize(s);
+    hipFree(wf); hipFree(c1); hipFree(c2); hipFree(st);
+    if (rc != TRACE_OK) return fail(rc, "LayerNorm-fold GEMM failed");
+    return TRACE_OK;
+}
+// C = A . W^T + bias + R on the loader-wave GEMM with the producer epilogue, then the finalize kernel: stats_out [M][2] = (rstd, -mean * rstd) of the
+// rows of C.  N % 256 == 0.
+extern "C" int trace_op_gemm_residual_stats(const void* A, const void* W, const void* bias, const void* R, void* C, float* stats_out, int M, int N,
+                                            int K, float eps, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    float* part = nullptr;
+    HIPCHK(hipMalloc((void**)&part, (size_t)(N / 256) * M * 8));
+    GemmArgs g{(const bf16_t*)A, K, (const bf16_t*)W, K, (bf16_t*)C, N, (const bf16_t*)bias, (const bf16_t*)R, N, M, N, K, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, 0,
+               nullptr, nullptr, part};
+    int rc = launch_gemm_bf16(g, EPI_RESIDUAL, s);
+    if (rc == TRACE_OK) rc = launch_ln_stats_finalize(part, N / 256, M, N, eps, stats_out, s);
+    hipStreamSynchronize(s);
+    hipFree(part);
+    if (rc != TRACE_OK) return fail(rc, "residual GEMM with row statistics failed");
     return TRACE_OK;
 }
 

@@ -409,9 +409,26 @@ int gemm_partial_ks(int N, int K) {
     return ks;
 }
 
+// the dispatch rule below, for callers that need to know which kernel a shape gets (the ViT's LayerNorm fold lives in two of them)
+static bool routes_256(int M, int N, int K) {
+    if (g_gemm_variant != 0 || M <= 0 || N % 256 || K % BK) return false;
+    const long blocks256 = (long)((M + 255) / 256) * (N / 256);
+    const long rounds = (blocks256 + 255) / 256;
+    return M >= 1024 && blocks256 * 10 >= rounds * 256 * 7;
+}
+bool gemm_routes_to_pers(int M, int N, int K) { return routes_256(M, N, K) && K >= 128 && (long)M * N < (1L << 30); }
+bool gemm_routes_to_ldr(int M, int N, int K) { return routes_256(M, N, K); }
+
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
     if (epi == EPI_PARTIAL) return launch_partial(p, s);
     if (p.w_tiled) return epi == EPI_SWIGLU ? launch_swiglu_tiled(p, s) : TRACE_ERR_ARG;
+    // LayerNorm fold: only the persistent kernel has the consumer epilogue, only the loader-wave kernel the producer one — no silent fall-back
+    if (p.stats) {
+        if (p.fp8 || p.N % 256 || p.K % BK || p.K < 128 || (long)p.M * p.ldc >= (1L << 30)) return TRACE_ERR_ARG;
+        g_gemm_pers_static = 0;
+        return launch_gemm_pers(p, epi, s);
+    }
+    if (p.stats_part) return (epi == EPI_RESIDUAL && !p.fp8 && p.N % 256 == 0 && p.K % BK == 0) ? launch_gemm_ldr(p, epi, s) : TRACE_ERR_ARG;
     if (p.M <= 0 || p.N % BN || p.K % BK || p.K < BK) return TRACE_ERR_ARG;
     if (p.fp8 && (p.K % 128 || (p.lda % 16) || (p.ldw % 16) || !p.sa || !p.sw || p.bias || epi == EPI_QUICKGELU)) return TRACE_ERR_ARG;
     if ((p.lda % 8) || (p.ldw % 8) || (p.ldc % 8)) return TRACE_ERR_ARG;

@@ -275,6 +275,24 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
         }
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
         __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(p.C + (size_t)m * p.ldc + on0 + ch * 8));
+        if constexpr (EPI == EPI_RESIDUAL && !FP8) {
+            // LayerNorm fold, producer side: the 32 lanes that hold a row's 256 columns of this tile add up the stored (bf16-rounded) values
+            // and their squares; lane 0 of the row writes the pair — 1 / (N / 256) of the statistics the next GEMM's epilogue needs
+            // (ln_stats_finalize_kernel adds the column tiles' shares)
+            if (p.stats_part) {
+                const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = bflo(u[e]), b = bfhi(u[e]);
+                    s1 += a + b;
+                    s2 = fmaf(a, a, fmaf(b, b, s2));
+                }
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (ch == 0) *reinterpret_cast<float2*>(p.stats_part + ((size_t)(n0 / BN) * p.M + m) * 2) = make_float2(s1, s2);
+            }
+        }
     }
 }
 

@@ -36,7 +36,14 @@ constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
 constexpr int CTL_OFF = 2 * STAGE;                // int s_next[2] | 2 x 512-byte bias rows | touch scratch
 constexpr int BIAS_OFF = CTL_OFF + 64;
 constexpr int TOUCH_OFF = BIAS_OFF + 2 * 512;    // 4 x 256 bytes: where the loader waves' L2 touches land (never read)
-constexpr int LDS_BYTES = TOUCH_OFF + 4 * 256;
+constexpr int C1_OFF = TOUCH_OFF + 4 * 256;      // LN fold (OPT bit 4 = 16): 2 x 512-byte rows of the tile's c1 column sums (bf16), beside the bias rows (= c2)
+constexpr int STAT_OFF = C1_OFF + 2 * 512;       // LN fold: 2 x 256 rows x (rstd, -mean * rstd) fp32 of the tile's row panel
+constexpr int LDS_BYTES = STAT_OFF + 2 * 2048;
+// LN FOLD (round 3): C = LayerNorm(A) . W^T + b without the LayerNorm pass.  With W' = W diag(gamma) (bf16, made at load), c1[n] = sum_k W'[n][k]
+// and c2[n] = sum_k beta[k] W[n][k] + b[n]:   C[m][n] = rstd_m (A . W'^T)[m][n] - rstd_m mean_m c1[n] + c2[n] — the K loop runs on the raw
+// residual stream, the epilogue applies one fused multiply-add pair per element from the row's (rstd, -mean rstd) — which the producing GEMM's
+// epilogue + a finalize kernel left in GemmArgs::stats — and the column's (c1, c2) — GemmArgs::c1 / GemmArgs::bias.  The loader waves park the
+// 256 row pairs and the two column rows of every tile in LDS next to the bias row, the MFMA waves read them after the K loop.
 constexpr int CTR_STRIDE = 32;                    // ints between the per-XCD ticket counters (one 128-byte line each)
 
 __device__ __forceinline__ int swz(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
@@ -159,24 +166,55 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // rows I0 .. I0+NI-1 (16-row m-tiles) of the wave's sub-tile: activation in registers, lane transposition, stores.  C and R are addressed
 // through buffer descriptors (scalar base + ONE 32-bit byte offset register per access) whose extent is the M valid rows: rows of the
 // last row panel that hang over M are dropped (stores) / read as zero (loads) by the bounds check, no predicates and no second code path.
-template <int EPI, int I0, int NI>
-__device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp)[TN], __amdgpu_buffer_rsrc_t crs, int coff, int cstep, bool hi8) {
+template <int EPI, int I0, int NI, bool LNF = false>
+__device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp)[TN], __amdgpu_buffer_rsrc_t crs, int coff, int cstep, bool hi8,
+                                              const char* lnf_c1, const char* lnf_stat) {
     constexpr bool GLU = (EPI == EPI_SWIGLU);
     constexpr int NH = GLU ? 1 : 2;               // 32-column output groups per m-tile
+    // LN fold: the lane's offsets into the tile's LDS rows, rebuilt here from an id the optimiser cannot see through (as loop invariants of the
+    // tile loop they would be two more registers held across the K loop)
+    const char* sc1 = lnf_c1;
+    const char* sstat = lnf_stat;
+    if (LNF) {
+        int lane_l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l));
+        sc1 = lnf_c1 + (lane_l >> 4) * 8;          // columns g*4 .. +3 of every n-tile (bf16)
+        sstat = lnf_stat + (lane_l & 15) * 8;      // row r of every m-tile
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         uint32_t pk[2 * NH][2];
         if (!GLU) {
             // the packed bias is re-unpacked for every m-tile (opaque to CSE): unpacked once, it is 16 registers beside 128 accumulators
+            if (!LNF) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bp[j].x), "+v"(bp[j].y));
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bp[j].x), "+v"(bp[j].y));
+            }
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            float rs = 1.f, tt = 0.f;
+            if (LNF) {                             // the row's (rstd, -mean * rstd), parked by the loader waves
+                const float2 st = *reinterpret_cast<const float2*>(sstat + (I0 + i) * 16 * 8);
+                rs = st.x; tt = st.y;
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 // two elements per VALU instruction where the ISA has packed fp32 (add / mul); exp2 and rcp stay one per element
-                typedef float f32x2_t __attribute__((ext_vector_type(2)));
-                const f32x2_t b01 = {bflo(bp[j].x), bfhi(bp[j].x)}, b23 = {bflo(bp[j].y), bfhi(bp[j].y)};
-                f32x2_t x01 = f32x2_t{acc[I0 + i][j][0], acc[I0 + i][j][1]} + b01;
-                f32x2_t x23 = f32x2_t{acc[I0 + i][j][2], acc[I0 + i][j][3]} + b23;
+                f32x2_t x01, x23;
+                if (LNF) {
+                    // c1 and c2 of the lane's 4 columns: re-read from the tile's LDS rows for every m-tile (c1 held in registers like the bias is 8
+                    // more of them beside 128 accumulators: that build spilled 84 bytes per lane; with c2 in registers it still spilled 40)
+                    const uint2 cq = *reinterpret_cast<const uint2*>(sc1 + j * 32);
+                    const uint2 bq = *reinterpret_cast<const uint2*>(sc1 + (BIAS_OFF - C1_OFF) + j * 32);
+                    const f32x2_t c01 = {bflo(cq.x), bfhi(cq.x)}, c23 = {bflo(cq.y), bfhi(cq.y)};
+                    const f32x2_t b01 = {bflo(bq.x), bfhi(bq.x)}, b23 = {bflo(bq.y), bfhi(bq.y)};
+                    // (plain fmas with the two row scalars: as packed operands they are four more registers, and this build is at the limit)
+                    x01 = f32x2_t{fmaf(acc[I0 + i][j][0], rs, fmaf(c01[0], tt, b01[0])), fmaf(acc[I0 + i][j][1], rs, fmaf(c01[1], tt, b01[1]))};
+                    x23 = f32x2_t{fmaf(acc[I0 + i][j][2], rs, fmaf(c23[0], tt, b23[0])), fmaf(acc[I0 + i][j][3], rs, fmaf(c23[1], tt, b23[1]))};
+                } else {
+                    const f32x2_t b01 = {bflo(bp[j].x), bfhi(bp[j].x)}, b23 = {bflo(bp[j].y), bfhi(bp[j].y)};
+                    x01 = f32x2_t{acc[I0 + i][j][0], acc[I0 + i][j][1]} + b01;
+                    x23 = f32x2_t{acc[I0 + i][j][2], acc[I0 + i][j][3]} + b23;
+                }
                 if (EPI == EPI_QUICKGELU) {
                     const f32x2_t t01 = x01 * -2.4554669595930157f, t23 = x23 * -2.4554669595930157f;
                     const f32x2_t d01 = f32x2_t{__builtin_amdgcn_exp2f(t01[0]), __builtin_amdgcn_exp2f(t01[1])} + 1.f;
@@ -186,6 +224,7 @@ __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp
                 }
                 pk[j][0] = pack2bf(x01[0], x01[1]);
                 pk[j][1] = pack2bf(x23[0], x23[1]);
+                if (LNF) PERS_FENCE();             // the next n-tile's LDS reads stay behind this one's math (hoisted together they spill)
             }
         } else {
 #pragma unroll
@@ -312,6 +351,9 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
     const char* src[16];
     int li = sc.slot, n = 0, q = 0, ticket = 0;
     uint2 bias2 = make_uint2(0u, 0u);
+    constexpr bool LNF = (OPT & 16) != 0 && !GLU && EPI != EPI_RESIDUAL;     // LN fold: park the tile's row statistics and c1 row as well
+    uint2 c1v = make_uint2(0u, 0u);
+    float2 st2 = make_float2(1.f, 0.f);
     // L2 touches (OPT bit 3 switches them off for A/B runs).  With two LDS stages only ONE K-tile is ever in flight, so when an operand streams
     // from HBM (ViT fc2: an 803 MB A) a K-tile costs the load's latency, not its MFMA time — and even from the Infinity Cache the pieces land
     // late often enough to show.  One byte of every A line of K-tile kt + LEAD, requested LEAD - 1 hand-overs before its LDS-DMA pieces, turns
@@ -349,6 +391,10 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
                          : reinterpret_cast<const char*>(p.W) + ((size_t)(n0_ + row) * p.ldw + kc * 8) * 2;                            \
         }                                                                                                                              \
         if (!GLU && lw == 3 && p.bias) bias2 = *reinterpret_cast<const uint2*>(p.bias + n0_ + lane * 4);  /* else stays zero */       \
+        if (LNF) {                                                                                                                     \
+            st2 = *reinterpret_cast<const float2*>(p.stats + 2 * (size_t)min(m0_ + lw * 64 + lane, p.M - 1));                           \
+            if (lw == 2) c1v = *reinterpret_cast<const uint2*>(p.c1 + n0_ + lane * 4);                                                 \
+        }                                                                                                                              \
         if (toucher)                                                                                                                   \
             tsrc = reinterpret_cast<const char*>(p.A) + (size_t)min(m0_ + (tn_ & 3) * 64 + lane, p.M - 1) * p.lda * 2;                 \
     }
@@ -384,6 +430,10 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
             PERS_WAIT_PIECES();
             if (kt == 0 && !GLU && lw == 3)                         // this tile's bias row (zeros without a bias), read by the MFMA waves after the K loop
                 *reinterpret_cast<uint2*>(smem + BIAS_OFF + (n & 1) * 512 + lane * 8) = bias2;
+            if (LNF && kt == 0) {
+                *reinterpret_cast<float2*>(smem + STAT_OFF + (n & 1) * 2048 + (lw * 64 + lane) * 8) = st2;
+                if (lw == 2) *reinterpret_cast<uint2*>(smem + C1_OFF + (n & 1) * 512 + lane * 8) = c1v;
+            }
             if (kt == 1 && tid == NMT) {                            // the tile after this one: everyone reads it after this tile's last hand-over
                 s_next[(n + 1) & 1] = dynamic ? nwg + ticket : li + nwg;
                 if (dynamic && ticket == cnt - 1) ctr[xcd * CTR_STRIDE] = 0;       // the launch's last ticket on this XCD: re-arm the counter
@@ -494,11 +544,15 @@ __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, i
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
         const int g_e = lane_e >> 4;
         uint2 bp[TN];                                               // this lane's 4 x 4 bias values, packed (unpacked where they are used)
+        constexpr bool LNF = (OPT & 16) != 0 && !GLU && EPI != EPI_RESIDUAL;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             bp[j] = make_uint2(0u, 0u);
-            if (!GLU) bp[j] = *reinterpret_cast<const uint2*>(smem + BIAS_OFF + (n & 1) * 512 + (wn * (BN / WN) + j * 16 + g_e * 4) * 2);
+            if (!GLU && !LNF) bp[j] = *reinterpret_cast<const uint2*>(smem + BIAS_OFF + (n & 1) * 512 + (wn * (BN / WN) + j * 16 + g_e * 4) * 2);
         }
+        // LN fold: the lane's c1 group (4 values per n-tile, 32 bytes apart) and row pair (16 rows apart per m-tile) in the tile's LDS rows
+        const char* sc1 = smem + C1_OFF + (n & 1) * 512 + (wn * (BN / WN)) * 2;                  // wave-uniform parts only: the lane's part is added where it is used
+        const char* sstat = smem + STAT_OFF + (n & 1) * 2048 + (wm * (BM / WM)) * 8;
         if (has_next) {                                             // K-tile 0 of the next tile: the loaders go on to its K-tile 1 during the epilogue
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -516,9 +570,9 @@ __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, i
             if (has_next) PERS_FRAGS(q);
             residual_store(out, rr, crs, coff, 32 * p.ldc);
         } else {
-            epilogue_rows<EPI, 0, TM / 2>(acc, bp, crs, coff, 32 * p.ldc, hi8);
+            epilogue_rows<EPI, 0, TM / 2, LNF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sstat);
             if (has_next) PERS_FRAGS(q);                            // 24 registers the first half of the epilogue has freed
-            epilogue_rows<EPI, TM / 2, TM / 2>(acc, bp, crs, coff, 32 * p.ldc, hi8);
+            epilogue_rows<EPI, TM / 2, TM / 2, LNF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sstat);
         }
         if (!has_next) break;
         li = li_next;
@@ -574,6 +628,10 @@ void launch_opt(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
 int g_opt = 0;
 template <int EPI>
 void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
+    if (p.stats) {                                  // LN fold (EPI_NONE / EPI_QUICKGELU: launch_gemm_pers checks)
+        if constexpr (EPI == EPI_NONE || EPI == EPI_QUICKGELU) launch_opt<EPI, 16>(p, nblk, dynamic, ctr, s);
+        return;
+    }
     switch (g_opt) {
         case 2: launch_opt<EPI, 2>(p, nblk, dynamic, ctr, s); break;
         case 4: launch_opt<EPI, 4>(p, nblk, dynamic, ctr, s); break;
@@ -605,6 +663,7 @@ void gemm_pers_release(int dev) {
 // TRACE_ERR_STATE: no ticket counters for this stream and none can be made now (capturing): the caller falls back to gemm_ldr
 int launch_gemm_pers(const GemmArgs& p, int epi, hipStream_t s) {
     if (p.M < 1 || p.N % BN || p.K % BK || p.K < 2 * BK || p.fp8) return TRACE_ERR_ARG;
+    if (p.stats && (!p.c1 || !p.bias || (epi != EPI_NONE && epi != EPI_QUICKGELU))) return TRACE_ERR_ARG;      // LN fold: c1, c2 (= bias) and the row statistics
     if ((long)p.M * p.ldc >= (1L << 30) || (epi == EPI_RESIDUAL && (long)p.M * p.ldr >= (1L << 30))) return TRACE_ERR_ARG;   // 32-bit byte offsets
     int ncu = 0;
     int* ctr = counters_for(s, &ncu);

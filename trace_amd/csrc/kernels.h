@@ -29,6 +29,10 @@ struct GemmArgs {
     // locality, as for the GEMV).  Bit 2: a 4-stage K-tile ring (three tiles in flight) instead of the double buffer.  (Bit 1 was a non-temporal
     // hint on the weight DMA: 11.58 vs 11.15 ms per 128-sequence step, profiles/r03_decode_gemm_ab_b128.txt — removed.)
     int w_tiled;
+    // LayerNorm fold (ViT, gemm_pers.hip / gemm_ldr.hip): consumer side — stats[m] = (rstd, -mean * rstd) of row m of A, c1[n] = sum_k W[n][k],
+    // bias = c2: C = rstd (A . W^T) + (-mean rstd) c1 + c2 for W pre-multiplied by the LayerNorm weight; producer side (EPI_RESIDUAL, gemm_ldr) —
+    // stats_part[tn][m] = (sum, sum of squares) of the 256 columns of output row m that column tile tn holds
+    const float* stats; const bf16_t* c1; float* stats_part;
 };
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s);
 int gemm_partial_ks(int N, int K);                                // K-chunks launch_gemm_bf16(EPI_PARTIAL) should be given for an [<= 128, K] x [N, K]^T product
@@ -45,6 +49,18 @@ int launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t*
                      int rows, int D, float eps, hipStream_t s, int silu = 0);   // silu = 1: y = SiLU(LN(x))
 int launch_rmsnorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w, int rows, int D, float eps,
                    hipStream_t s);
+
+// ---- LayerNorm fold (ViT): C = LN(A) W^T + b as one GEMM on the raw rows (GemmArgs::stats / c1 / stats_part; gemm_pers.hip, gemm_ldr.hip) ----
+// part [NT][M][2] (sum, sum of squares per 256-column tile, from the residual GEMM's epilogue) -> stats [M][2] = (rstd, -mean * rstd)
+int launch_ln_stats_finalize(const float* part, int NT, int M, int D, float eps, float* stats, hipStream_t s);
+int launch_ln_row_stats(const bf16_t* x, int ldx, int M, int D, float eps, float* stats, hipStream_t s);      // the same from the rows themselves
+// Wf = bf16(W * gamma), c1 = row sums of Wf, c2 = W . beta + b   (at load)
+int launch_ln_fold_weights(const bf16_t* W, int ldw, const bf16_t* gamma, const bf16_t* beta, const bf16_t* b, bf16_t* Wf, bf16_t* c1, bf16_t* c2,
+                           int N, int K, hipStream_t s);
+// true: launch_gemm_bf16 would run this bias / activation GEMM on the persistent kernel (which has the fold epilogue) / this residual GEMM on
+// the loader-wave kernel (whose epilogue can emit the row statistics)
+bool gemm_routes_to_pers(int M, int N, int K);
+bool gemm_routes_to_ldr(int M, int N, int K);
 
 // ---- ViT front end (vit.hip) ----
 // frames [T,3,S,S] (bf16 or fp32) -> im2col patches A [T*G*G, Kpad] bf16 (k = c*P*P + py*P + px, zero padded)

@@ -5,6 +5,9 @@ import dataclasses, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trace_amd import config as tcfg, synth
 from trace_amd.engine import TraceEngine, ops
+for v in os.environ.get("TRACE_VARIANTS", "").split(","):      # A/B switches (trace_op_set_gemm_variant), e.g. 150 = no LayerNorm fold, 160 = fold epilogue without prefetch
+    if v.strip():
+        ops.set_gemm_variant(int(v))
 if os.environ.get("TRACE_ATTN_TRANSPOSED_V"):
     ops.set_gemm_variant(116)          # A/B: the round-2 path (transpose_v + permuted V^T) instead of row-major V through LDS transpose reads
 cfg = dataclasses.replace(tcfg.trace_7b(128), num_hidden_layers=1)

@@ -1119,11 +1119,15 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
             if (s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) { e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2; }
         }
         if (e0) hipEventRecord(e0, s);
+        // up to 16 rows a 4096-wide K fits LDS in one chunk: SwiGLU next to the accumulators, no partial rows and no combine kernel
+        // (4.7 us + a kernel boundary per layer at batch 1)
+        const bool glu_in_kernel = !wo && !f8 && B <= 16 && skinny_ks(2 * I, H, EPI_SWIGLU, B) == 1;
         if (wo) { GEMVW(c->dH, W.wgu8_d, W.sgu, 2 * I, H) }
         else if (f8) { GEMV8H(W.wgu8_d, W.sgu, 2 * I) }
+        else if (glu_in_kernel) LCHK(launch_skinny_gemm(c->dH, H, W.wgu_d, H, c->dACT, I, nullptr, 0, B, 2 * I, H, EPI_SWIGLU, 1, SKWS(c), s));
         else LCHK(launch_skinny_gemm(c->dH, H, W.wgu_d, H, nullptr, 2 * I, nullptr, 0, B, 2 * I, H, EPI_PARTIAL, 1, SKWS(c), s));
         if (e1) hipEventRecord(e1, s);
-        LCHK(launch_swiglu_combine(c->sk_ws, ks_g, 2 * I, c->dACT, I, B, s));
+        if (!glu_in_kernel) LCHK(launch_swiglu_combine(c->sk_ws, ks_g, 2 * I, c->dACT, I, B, s));
         if (wo) { GEMVW(c->dACT, W.wd8_d, W.sd, H, I) }
         else if (f8) { GEMV8(c->dACT, W.wd8_d, W.sd, H, I) }
         else LCHK(launch_skinny_gemm(c->dACT, I, W.wd_d, I, nullptr, H, nullptr, 0, B, H, I, EPI_PARTIAL, 1, SKWS(c), s));
@@ -1331,6 +1335,7 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
     if (variant >= 150 && variant <= 151) { g_vit_ln_fold = variant - 150; return TRACE_OK; }
+    if (variant >= 160 && variant <= 161) { gemm_pers_set_lnf_prefetch(variant - 160); return TRACE_OK; }
     if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : 32; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }

@@ -288,9 +288,16 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
                     s1 += a + b;
                     s2 = fmaf(a, a, fmaf(b, b, s2));
                 }
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-                if (ch == 0) *reinterpret_cast<float2*>(p.stats_part + ((size_t)(n0 / BN) * p.M + m) * 2) = make_float2(s1, s2);
+                // 32-lane sums on the DPP path (plain VALU): four steps inside each 16-lane row, then row 0 -> row 1 / row 2 -> row 3.  (The first
+                // version used __shfl_xor = ds_bpermute, 160 LDS round trips per thread and tile: +35 us per ViT residual GEMM.)
+#define LDR_DPP_ADD(V, CTRL, ROWMASK) V += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), CTRL, ROWMASK, 0xf, true))
+                LDR_DPP_ADD(s1, 0xB1, 0xf); LDR_DPP_ADD(s2, 0xB1, 0xf);        // quad_perm [1,0,3,2]
+                LDR_DPP_ADD(s1, 0x4E, 0xf); LDR_DPP_ADD(s2, 0x4E, 0xf);        // quad_perm [2,3,0,1]
+                LDR_DPP_ADD(s1, 0x141, 0xf); LDR_DPP_ADD(s2, 0x141, 0xf);      // row_half_mirror
+                LDR_DPP_ADD(s1, 0x140, 0xf); LDR_DPP_ADD(s2, 0x140, 0xf);      // row_mirror: every lane of a 16-lane row holds the row's sum
+                LDR_DPP_ADD(s1, 0x142, 0xa); LDR_DPP_ADD(s2, 0x142, 0xa);      // row_bcast15 into rows 1, 3: lanes 16..31 / 48..63 hold their half's sum
+#undef LDR_DPP_ADD
+                if (ch == 16) *reinterpret_cast<float2*>(p.stats_part + ((size_t)(n0 / BN) * p.M + m) * 2) = make_float2(s1, s2);
             }
         }
     }

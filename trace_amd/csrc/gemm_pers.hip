@@ -166,7 +166,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // rows I0 .. I0+NI-1 (16-row m-tiles) of the wave's sub-tile: activation in registers, lane transposition, stores.  C and R are addressed
 // through buffer descriptors (scalar base + ONE 32-bit byte offset register per access) whose extent is the M valid rows: rows of the
 // last row panel that hang over M are dropped (stores) / read as zero (loads) by the bounds check, no predicates and no second code path.
-template <int EPI, int I0, int NI, bool LNF = false>
+template <int EPI, int I0, int NI, bool LNF = false, bool PF = false>
 __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp)[TN], __amdgpu_buffer_rsrc_t crs, int coff, int cstep, bool hi8,
                                               const char* lnf_c1, const char* lnf_stat) {
     constexpr bool GLU = (EPI == EPI_SWIGLU);
@@ -181,6 +181,18 @@ __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp
         sc1 = lnf_c1 + (lane_l >> 4) * 8;          // columns g*4 .. +3 of every n-tile (bf16)
         sstat = lnf_stat + (lane_l & 15) * 8;      // row r of every m-tile
     }
+    // LN fold: c1 and c2 of the lane's 4 columns are re-read from the tile's LDS rows for every (m-tile, n-tile) — held in registers like the bias
+    // they are 8-16 more of them beside 128 accumulators (those builds spilled 40-84 bytes per lane) — one step AHEAD of their use, with a
+    // scheduling fence per n-tile: unfenced the compiler hoists all the reads of an m-tile together (spills again), fenced but not prefetched
+    // every one of the 32 reads per tile is an exposed LDS round trip (+32..47 us on the ViT GEMMs: the first version of this epilogue).
+    constexpr bool LNF_ST_AHEAD = false;          // the row pair one m-tile ahead as well: two more registers, and that build spills (36-40 bytes)
+    uint2 cq_n = make_uint2(0u, 0u), bq_n = make_uint2(0u, 0u);
+    float2 st_n = make_float2(1.f, 0.f);
+    if (LNF && PF) {
+        cq_n = *reinterpret_cast<const uint2*>(sc1);
+        bq_n = *reinterpret_cast<const uint2*>(sc1 + (BIAS_OFF - C1_OFF));
+        if (LNF_ST_AHEAD) st_n = *reinterpret_cast<const float2*>(sstat + I0 * 16 * 8);
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         uint32_t pk[2 * NH][2];
@@ -193,18 +205,31 @@ __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp
             typedef float f32x2_t __attribute__((ext_vector_type(2)));
             float rs = 1.f, tt = 0.f;
             if (LNF) {                             // the row's (rstd, -mean * rstd), parked by the loader waves
-                const float2 st = *reinterpret_cast<const float2*>(sstat + (I0 + i) * 16 * 8);
-                rs = st.x; tt = st.y;
+                if (PF && LNF_ST_AHEAD) {
+                    rs = st_n.x; tt = st_n.y;
+                    if (i + 1 < NI) st_n = *reinterpret_cast<const float2*>(sstat + (I0 + i + 1) * 16 * 8);
+                } else {
+                    const float2 st = *reinterpret_cast<const float2*>(sstat + (I0 + i) * 16 * 8);
+                    rs = st.x; tt = st.y;
+                }
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 // two elements per VALU instruction where the ISA has packed fp32 (add / mul); exp2 and rcp stay one per element
                 f32x2_t x01, x23;
                 if (LNF) {
-                    // c1 and c2 of the lane's 4 columns: re-read from the tile's LDS rows for every m-tile (c1 held in registers like the bias is 8
-                    // more of them beside 128 accumulators: that build spilled 84 bytes per lane; with c2 in registers it still spilled 40)
-                    const uint2 cq = *reinterpret_cast<const uint2*>(sc1 + j * 32);
-                    const uint2 bq = *reinterpret_cast<const uint2*>(sc1 + (BIAS_OFF - C1_OFF) + j * 32);
+                    uint2 cq, bq;
+                    if (PF) {
+                        cq = cq_n; bq = bq_n;
+                        if (!(i + 1 == NI && j + 1 == TN)) {
+                            const int jn = (j + 1) % TN;
+                            cq_n = *reinterpret_cast<const uint2*>(sc1 + jn * 32);
+                            bq_n = *reinterpret_cast<const uint2*>(sc1 + (BIAS_OFF - C1_OFF) + jn * 32);
+                        }
+                    } else {
+                        cq = *reinterpret_cast<const uint2*>(sc1 + j * 32);
+                        bq = *reinterpret_cast<const uint2*>(sc1 + (BIAS_OFF - C1_OFF) + j * 32);
+                    }
                     const f32x2_t c01 = {bflo(cq.x), bfhi(cq.x)}, c23 = {bflo(cq.y), bfhi(cq.y)};
                     const f32x2_t b01 = {bflo(bq.x), bfhi(bq.x)}, b23 = {bflo(bq.y), bfhi(bq.y)};
                     // (plain fmas with the two row scalars: as packed operands they are four more registers, and this build is at the limit)
@@ -570,9 +595,10 @@ __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, i
             if (has_next) PERS_FRAGS(q);
             residual_store(out, rr, crs, coff, 32 * p.ldc);
         } else {
-            epilogue_rows<EPI, 0, TM / 2, LNF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sstat);
+            constexpr bool PF = (OPT & 32) != 0;                   // LN fold: c1 / c2 read one n-tile ahead (A/B builds)
+            epilogue_rows<EPI, 0, TM / 2, LNF, PF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sstat);
             if (has_next) PERS_FRAGS(q);                            // 24 registers the first half of the epilogue has freed
-            epilogue_rows<EPI, TM / 2, TM / 2, LNF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sstat);
+            epilogue_rows<EPI, TM / 2, TM / 2, LNF, PF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sstat);
         }
         if (!has_next) break;
         li = li_next;
@@ -626,10 +652,14 @@ void launch_opt(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
     hipLaunchKernelGGL((gemm_pers_kernel<EPI, OPT>), dim3(nblk), dim3(NTHR), LDS_BYTES, s, p, ctr, dynamic);
 }
 int g_opt = 0;
+int g_gemm_pers_lnf_prefetch = 1;      // LN-fold epilogue: c1 / c2 one n-tile ahead (1) or read where they are used (0) — A/B: trace_op_set_gemm_variant(160 + x)
 template <int EPI>
 void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
     if (p.stats) {                                  // LN fold (EPI_NONE / EPI_QUICKGELU: launch_gemm_pers checks)
-        if constexpr (EPI == EPI_NONE || EPI == EPI_QUICKGELU) launch_opt<EPI, 16>(p, nblk, dynamic, ctr, s);
+        if constexpr (EPI == EPI_NONE || EPI == EPI_QUICKGELU) {
+            if (g_gemm_pers_lnf_prefetch) launch_opt<EPI, 48>(p, nblk, dynamic, ctr, s);
+            else launch_opt<EPI, 16>(p, nblk, dynamic, ctr, s);
+        }
         return;
     }
     switch (g_opt) {
@@ -645,6 +675,7 @@ void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
 int g_gemm_pers_opt = 0;           // A/B builds of the K loop (trace_op_set_gemm_variant(300 + opt))
 int g_gemm_pers_static = 0;        // 1: tiles dealt round-robin instead of by ticket (A/B runs)
 
+void gemm_pers_set_lnf_prefetch(int on) { g_gemm_pers_lnf_prefetch = on; }
 int g_gemm_pers_grid_cap = 0;      // > 0: at most this many workgroups per launch (a stream confined to part of the CUs by a CU mask: the
                                    // persistent grid must not exceed the CUs it can run on, or the surplus workgroups wait for a second round)
 

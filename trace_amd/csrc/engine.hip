@@ -26,7 +26,8 @@ static int fail(int code, const std::string& m) { g_err = m; return code; }
 struct VitLayer {
     bf16_t *ln1w, *ln1b, *wqkv, *bqkv, *wo, *bo, *ln2w, *ln2b, *w1, *b1, *w2, *b2;
     // LayerNorm fold (made at finalize): weights pre-multiplied by the LayerNorm weight, their row sums c1 and the folded bias c2
-    bf16_t *wqkv_f, *c1q, *c2q, *w1_f, *c1f, *c2f;
+    bf16_t *wqkv_f, *c2q, *w1_f, *c2f;
+    float *c1q, *c1f;
 };
 struct LlmLayer {
     bf16_t *rms1, *wqkv, *wo, *rms2, *wgu, *wd;
@@ -587,7 +588,7 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
     // rstd (acc - mean c1) + c2 in its epilogue.  Smaller calls (a few frames) keep the LayerNorm kernel.
     const bool fold = g_vit_ln_fold && vh % 256 == 0 && gemm_routes_to_pers(Mv, 3 * vh, vh) && gemm_routes_to_pers(Mv, vi, vh) &&
                       gemm_routes_to_ldr(Mv, vh, vh) && gemm_routes_to_ldr(Mv, vh, vi);
-    auto fgemm = [&](const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* Cc, int ldc, const bf16_t* c2, const bf16_t* c1, const bf16_t* R,
+    auto fgemm = [&](const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* Cc, int ldc, const bf16_t* c2, const float* c1, const bf16_t* R,
                      int N, int K, int epi, float* stats_part) -> int {
         GemmArgs g{A, lda, W, ldw, Cc, ldc, c2, R, R ? vh : 0, Mv, N, K, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, 0, c1 ? c->vStats : nullptr, c1, stats_part};
         const int rc = launch_gemm_bf16(g, epi, s);
@@ -1119,15 +1120,13 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
             if (s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) { e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2; }
         }
         if (e0) hipEventRecord(e0, s);
-        // up to 16 rows a 4096-wide K fits LDS in one chunk: SwiGLU next to the accumulators, no partial rows and no combine kernel
-        // (4.7 us + a kernel boundary per layer at batch 1)
-        const bool glu_in_kernel = !wo && !f8 && B <= 16 && skinny_ks(2 * I, H, EPI_SWIGLU, B) == 1;
         if (wo) { GEMVW(c->dH, W.wgu8_d, W.sgu, 2 * I, H) }
         else if (f8) { GEMV8H(W.wgu8_d, W.sgu, 2 * I) }
-        else if (glu_in_kernel) LCHK(launch_skinny_gemm(c->dH, H, W.wgu_d, H, c->dACT, I, nullptr, 0, B, 2 * I, H, EPI_SWIGLU, 1, SKWS(c), s));
         else LCHK(launch_skinny_gemm(c->dH, H, W.wgu_d, H, nullptr, 2 * I, nullptr, 0, B, 2 * I, H, EPI_PARTIAL, 1, SKWS(c), s));
         if (e1) hipEventRecord(e1, s);
-        if (!glu_in_kernel) LCHK(launch_swiglu_combine(c->sk_ws, ks_g, 2 * I, c->dACT, I, B, s));
+        // (SwiGLU inside the gate|up GEMV at batch <= 16 — one K chunk, no combine kernel — measured 3.73 vs 3.5 ms per batch-1 step: its 224
+        //  workgroups leave 32 CUs without a weight stream)
+        LCHK(launch_swiglu_combine(c->sk_ws, ks_g, 2 * I, c->dACT, I, B, s));
         if (wo) { GEMVW(c->dACT, W.wd8_d, W.sd, H, I) }
         else if (f8) { GEMV8(c->dACT, W.wd8_d, W.sd, H, I) }
         else LCHK(launch_skinny_gemm(c->dACT, I, W.wd_d, I, nullptr, H, nullptr, 0, B, H, I, EPI_PARTIAL, 1, SKWS(c), s));
@@ -1335,7 +1334,6 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
     if (variant >= 150 && variant <= 151) { g_vit_ln_fold = variant - 150; return TRACE_OK; }
-    if (variant >= 160 && variant <= 161) { gemm_pers_set_lnf_prefetch(variant - 160); return TRACE_OK; }
     if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : 32; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
@@ -1478,8 +1476,8 @@ extern "C" int trace_op_skinny_w8(const void* X, const void* W8, const float* sw
 extern "C" int trace_op_gemm_lnfold(const void* X, const void* W, const void* gamma, const void* beta, const void* bias, void* C, int M, int N, int K,
                                     float eps, int epilogue, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    bf16_t *wf = nullptr, *c1 = nullptr, *c2 = nullptr; float* st = nullptr;
-    HIPCHK(hipMalloc((void**)&wf, (size_t)N * K * 2)); HIPCHK(hipMalloc((void**)&c1, (size_t)N * 2)); HIPCHK(hipMalloc((void**)&c2, (size_t)N * 2));
+    bf16_t *wf = nullptr, *c2 = nullptr; float *c1 = nullptr, *st = nullptr;
+    HIPCHK(hipMalloc((void**)&wf, (size_t)N * K * 2)); HIPCHK(hipMalloc((void**)&c1, (size_t)N * 4)); HIPCHK(hipMalloc((void**)&c2, (size_t)N * 2));
     HIPCHK(hipMalloc((void**)&st, (size_t)M * 8));
     int rc = launch_ln_fold_weights((const bf16_t*)W, K, (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)bias, wf, c1, c2, N, K, s);
     if (rc == TRACE_OK) rc = launch_ln_row_stats((const bf16_t*)X, K, M, K, eps, st, s);

@@ -36,8 +36,9 @@ constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
 constexpr int CTL_OFF = 2 * STAGE;                // int s_next[2] | 2 x 512-byte bias rows | touch scratch
 constexpr int BIAS_OFF = CTL_OFF + 64;
 constexpr int TOUCH_OFF = BIAS_OFF + 2 * 512;    // 4 x 256 bytes: where the loader waves' L2 touches land (never read)
-constexpr int C1_OFF = TOUCH_OFF + 4 * 256;      // LN fold (OPT bit 4 = 16): 2 x 512-byte rows of the tile's c1 column sums (bf16), beside the bias rows (= c2)
-constexpr int STAT_OFF = C1_OFF + 2 * 512;       // LN fold: 2 x 256 rows x (rstd, -mean * rstd) fp32 of the tile's row panel
+constexpr int C1_OFF = TOUCH_OFF + 4 * 256;      // LN fold (OPT bit 4 = 16): 2 x 1 KB rows of the tile's c1 column sums (fp32: it multiplies the row mean and has to
+                                                 // cancel what the K loop accumulated for it), beside the bias rows (= c2, bf16)
+constexpr int STAT_OFF = C1_OFF + 2 * 1024;      // LN fold: 2 x 256 rows x (rstd, -mean * rstd) fp32 of the tile's row panel
 constexpr int LDS_BYTES = STAT_OFF + 2 * 2048;
 // LN FOLD (round 3): C = LayerNorm(A) . W^T + b without the LayerNorm pass.  With W' = W diag(gamma) (bf16, made at load), c1[n] = sum_k W'[n][k]
 // and c2[n] = sum_k beta[k] W[n][k] + b[n]:   C[m][n] = rstd_m (A . W'^T)[m][n] - rstd_m mean_m c1[n] + c2[n] — the K loop runs on the raw
@@ -166,33 +167,27 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // rows I0 .. I0+NI-1 (16-row m-tiles) of the wave's sub-tile: activation in registers, lane transposition, stores.  C and R are addressed
 // through buffer descriptors (scalar base + ONE 32-bit byte offset register per access) whose extent is the M valid rows: rows of the
 // last row panel that hang over M are dropped (stores) / read as zero (loads) by the bounds check, no predicates and no second code path.
-template <int EPI, int I0, int NI, bool LNF = false, bool PF = false>
+template <int EPI, int I0, int NI, bool LNF = false>
 __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp)[TN], __amdgpu_buffer_rsrc_t crs, int coff, int cstep, bool hi8,
-                                              const char* lnf_c1, const char* lnf_stat) {
+                                              const char* lnf_c1, const char* lnf_c2, const char* lnf_stat) {
     constexpr bool GLU = (EPI == EPI_SWIGLU);
     constexpr int NH = GLU ? 1 : 2;               // 32-column output groups per m-tile
     // LN fold: the lane's offsets into the tile's LDS rows, rebuilt here from an id the optimiser cannot see through (as loop invariants of the
     // tile loop they would be two more registers held across the K loop)
     const char* sc1 = lnf_c1;
+    const char* sc2 = lnf_c1;
     const char* sstat = lnf_stat;
     if (LNF) {
         int lane_l;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l));
-        sc1 = lnf_c1 + (lane_l >> 4) * 8;          // columns g*4 .. +3 of every n-tile (bf16)
+        sc1 = lnf_c1 + (lane_l >> 4) * 16;         // columns g*4 .. +3 of every n-tile: fp32 c1 ...
+        sc2 = lnf_c2 + (lane_l >> 4) * 8;          // ... and bf16 c2 (the bias row)
         sstat = lnf_stat + (lane_l & 15) * 8;      // row r of every m-tile
     }
-    // LN fold: c1 and c2 of the lane's 4 columns are re-read from the tile's LDS rows for every (m-tile, n-tile) — held in registers like the bias
-    // they are 8-16 more of them beside 128 accumulators (those builds spilled 40-84 bytes per lane) — one step AHEAD of their use, with a
-    // scheduling fence per n-tile: unfenced the compiler hoists all the reads of an m-tile together (spills again), fenced but not prefetched
-    // every one of the 32 reads per tile is an exposed LDS round trip (+32..47 us on the ViT GEMMs: the first version of this epilogue).
-    constexpr bool LNF_ST_AHEAD = false;          // the row pair one m-tile ahead as well: two more registers, and that build spills (36-40 bytes)
-    uint2 cq_n = make_uint2(0u, 0u), bq_n = make_uint2(0u, 0u);
-    float2 st_n = make_float2(1.f, 0.f);
-    if (LNF && PF) {
-        cq_n = *reinterpret_cast<const uint2*>(sc1);
-        bq_n = *reinterpret_cast<const uint2*>(sc1 + (BIAS_OFF - C1_OFF));
-        if (LNF_ST_AHEAD) st_n = *reinterpret_cast<const float2*>(sstat + I0 * 16 * 8);
-    }
+    // LN fold: c1 (fp32) and c2 (bf16) of the lane's 4 columns are re-read from the tile's LDS rows for every (m-tile, n-tile), with a scheduling
+    // fence per n-tile.  Held in registers like the bias they are 8-16 more of them beside 128 accumulators (those builds spilled 40-84 bytes
+    // per lane); unfenced, the compiler hoists all the reads of an m-tile together (spills again); read one n-tile ahead (4 more registers) the
+    // build spills 16 bytes per tile and measured SLOWER than this form (profiles/r03_vit_stream170_lnfold*_kernel_stats.csv: fc1 784 vs 777 us).
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         uint32_t pk[2 * NH][2];
@@ -205,32 +200,17 @@ __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp
             typedef float f32x2_t __attribute__((ext_vector_type(2)));
             float rs = 1.f, tt = 0.f;
             if (LNF) {                             // the row's (rstd, -mean * rstd), parked by the loader waves
-                if (PF && LNF_ST_AHEAD) {
-                    rs = st_n.x; tt = st_n.y;
-                    if (i + 1 < NI) st_n = *reinterpret_cast<const float2*>(sstat + (I0 + i + 1) * 16 * 8);
-                } else {
-                    const float2 st = *reinterpret_cast<const float2*>(sstat + (I0 + i) * 16 * 8);
-                    rs = st.x; tt = st.y;
-                }
+                const float2 st = *reinterpret_cast<const float2*>(sstat + (I0 + i) * 16 * 8);
+                rs = st.x; tt = st.y;
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 // two elements per VALU instruction where the ISA has packed fp32 (add / mul); exp2 and rcp stay one per element
                 f32x2_t x01, x23;
                 if (LNF) {
-                    uint2 cq, bq;
-                    if (PF) {
-                        cq = cq_n; bq = bq_n;
-                        if (!(i + 1 == NI && j + 1 == TN)) {
-                            const int jn = (j + 1) % TN;
-                            cq_n = *reinterpret_cast<const uint2*>(sc1 + jn * 32);
-                            bq_n = *reinterpret_cast<const uint2*>(sc1 + (BIAS_OFF - C1_OFF) + jn * 32);
-                        }
-                    } else {
-                        cq = *reinterpret_cast<const uint2*>(sc1 + j * 32);
-                        bq = *reinterpret_cast<const uint2*>(sc1 + (BIAS_OFF - C1_OFF) + j * 32);
-                    }
-                    const f32x2_t c01 = {bflo(cq.x), bfhi(cq.x)}, c23 = {bflo(cq.y), bfhi(cq.y)};
+                    const float4 cq = *reinterpret_cast<const float4*>(sc1 + j * 64);
+                    const uint2 bq = *reinterpret_cast<const uint2*>(sc2 + j * 32);
+                    const f32x2_t c01 = {cq.x, cq.y}, c23 = {cq.z, cq.w};
                     const f32x2_t b01 = {bflo(bq.x), bfhi(bq.x)}, b23 = {bflo(bq.y), bfhi(bq.y)};
                     // (plain fmas with the two row scalars: as packed operands they are four more registers, and this build is at the limit)
                     x01 = f32x2_t{fmaf(acc[I0 + i][j][0], rs, fmaf(c01[0], tt, b01[0])), fmaf(acc[I0 + i][j][1], rs, fmaf(c01[1], tt, b01[1]))};
@@ -377,7 +357,7 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
     int li = sc.slot, n = 0, q = 0, ticket = 0;
     uint2 bias2 = make_uint2(0u, 0u);
     constexpr bool LNF = (OPT & 16) != 0 && !GLU && EPI != EPI_RESIDUAL;     // LN fold: park the tile's row statistics and c1 row as well
-    uint2 c1v = make_uint2(0u, 0u);
+    float4 c1v = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 st2 = make_float2(1.f, 0.f);
     // L2 touches (OPT bit 3 switches them off for A/B runs).  With two LDS stages only ONE K-tile is ever in flight, so when an operand streams
     // from HBM (ViT fc2: an 803 MB A) a K-tile costs the load's latency, not its MFMA time — and even from the Infinity Cache the pieces land
@@ -418,7 +398,7 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
         if (!GLU && lw == 3 && p.bias) bias2 = *reinterpret_cast<const uint2*>(p.bias + n0_ + lane * 4);  /* else stays zero */       \
         if (LNF) {                                                                                                                     \
             st2 = *reinterpret_cast<const float2*>(p.stats + 2 * (size_t)min(m0_ + lw * 64 + lane, p.M - 1));                           \
-            if (lw == 2) c1v = *reinterpret_cast<const uint2*>(p.c1 + n0_ + lane * 4);                                                 \
+            if (lw == 2) c1v = *reinterpret_cast<const float4*>(p.c1 + n0_ + lane * 4);                                                \
         }                                                                                                                              \
         if (toucher)                                                                                                                   \
             tsrc = reinterpret_cast<const char*>(p.A) + (size_t)min(m0_ + (tn_ & 3) * 64 + lane, p.M - 1) * p.lda * 2;                 \
@@ -457,7 +437,7 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
                 *reinterpret_cast<uint2*>(smem + BIAS_OFF + (n & 1) * 512 + lane * 8) = bias2;
             if (LNF && kt == 0) {
                 *reinterpret_cast<float2*>(smem + STAT_OFF + (n & 1) * 2048 + (lw * 64 + lane) * 8) = st2;
-                if (lw == 2) *reinterpret_cast<uint2*>(smem + C1_OFF + (n & 1) * 512 + lane * 8) = c1v;
+                if (lw == 2) *reinterpret_cast<float4*>(smem + C1_OFF + (n & 1) * 1024 + lane * 16) = c1v;
             }
             if (kt == 1 && tid == NMT) {                            // the tile after this one: everyone reads it after this tile's last hand-over
                 s_next[(n + 1) & 1] = dynamic ? nwg + ticket : li + nwg;
@@ -576,7 +556,8 @@ __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, i
             if (!GLU && !LNF) bp[j] = *reinterpret_cast<const uint2*>(smem + BIAS_OFF + (n & 1) * 512 + (wn * (BN / WN) + j * 16 + g_e * 4) * 2);
         }
         // LN fold: the lane's c1 group (4 values per n-tile, 32 bytes apart) and row pair (16 rows apart per m-tile) in the tile's LDS rows
-        const char* sc1 = smem + C1_OFF + (n & 1) * 512 + (wn * (BN / WN)) * 2;                  // wave-uniform parts only: the lane's part is added where it is used
+        const char* sc1 = smem + C1_OFF + (n & 1) * 1024 + (wn * (BN / WN)) * 4;                 // wave-uniform parts only: the lane's part is added where it is used
+        const char* sc2 = smem + BIAS_OFF + (n & 1) * 512 + (wn * (BN / WN)) * 2;
         const char* sstat = smem + STAT_OFF + (n & 1) * 2048 + (wm * (BM / WM)) * 8;
         if (has_next) {                                             // K-tile 0 of the next tile: the loaders go on to its K-tile 1 during the epilogue
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -595,10 +576,9 @@ __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, i
             if (has_next) PERS_FRAGS(q);
             residual_store(out, rr, crs, coff, 32 * p.ldc);
         } else {
-            constexpr bool PF = (OPT & 32) != 0;                   // LN fold: c1 / c2 read one n-tile ahead (A/B builds)
-            epilogue_rows<EPI, 0, TM / 2, LNF, PF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sstat);
+            epilogue_rows<EPI, 0, TM / 2, LNF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sc2, sstat);
             if (has_next) PERS_FRAGS(q);                            // 24 registers the first half of the epilogue has freed
-            epilogue_rows<EPI, TM / 2, TM / 2, LNF, PF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sstat);
+            epilogue_rows<EPI, TM / 2, TM / 2, LNF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sc2, sstat);
         }
         if (!has_next) break;
         li = li_next;
@@ -652,14 +632,10 @@ void launch_opt(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
     hipLaunchKernelGGL((gemm_pers_kernel<EPI, OPT>), dim3(nblk), dim3(NTHR), LDS_BYTES, s, p, ctr, dynamic);
 }
 int g_opt = 0;
-int g_gemm_pers_lnf_prefetch = 1;      // LN-fold epilogue: c1 / c2 one n-tile ahead (1) or read where they are used (0) — A/B: trace_op_set_gemm_variant(160 + x)
 template <int EPI>
 void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
     if (p.stats) {                                  // LN fold (EPI_NONE / EPI_QUICKGELU: launch_gemm_pers checks)
-        if constexpr (EPI == EPI_NONE || EPI == EPI_QUICKGELU) {
-            if (g_gemm_pers_lnf_prefetch) launch_opt<EPI, 48>(p, nblk, dynamic, ctr, s);
-            else launch_opt<EPI, 16>(p, nblk, dynamic, ctr, s);
-        }
+        if constexpr (EPI == EPI_NONE || EPI == EPI_QUICKGELU) launch_opt<EPI, 16>(p, nblk, dynamic, ctr, s);
         return;
     }
     switch (g_opt) {
@@ -675,7 +651,6 @@ void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
 int g_gemm_pers_opt = 0;           // A/B builds of the K loop (trace_op_set_gemm_variant(300 + opt))
 int g_gemm_pers_static = 0;        // 1: tiles dealt round-robin instead of by ticket (A/B runs)
 
-void gemm_pers_set_lnf_prefetch(int on) { g_gemm_pers_lnf_prefetch = on; }
 int g_gemm_pers_grid_cap = 0;      // > 0: at most this many workgroups per launch (a stream confined to part of the CUs by a CU mask: the
                                    // persistent grid must not exceed the CUs it can run on, or the surplus workgroups wait for a second round)
 

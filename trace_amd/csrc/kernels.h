@@ -29,17 +29,16 @@ struct GemmArgs {
     // locality, as for the GEMV).  Bit 2: a 4-stage K-tile ring (three tiles in flight) instead of the double buffer.  (Bit 1 was a non-temporal
     // hint on the weight DMA: 11.58 vs 11.15 ms per 128-sequence step, profiles/r03_decode_gemm_ab_b128.txt — removed.)
     int w_tiled;
-    // LayerNorm fold (ViT, gemm_pers.hip / gemm_ldr.hip): consumer side — stats[m] = (rstd, -mean * rstd) of row m of A, c1[n] = sum_k W[n][k],
+    // LayerNorm fold (ViT, gemm_pers.hip / gemm_ldr.hip): consumer side — stats[m] = (rstd, -mean * rstd) of row m of A, c1[n] = sum_k W[n][k] (fp32),
     // bias = c2: C = rstd (A . W^T) + (-mean rstd) c1 + c2 for W pre-multiplied by the LayerNorm weight; producer side (EPI_RESIDUAL, gemm_ldr) —
     // stats_part[tn][m] = (sum, sum of squares) of the 256 columns of output row m that column tile tn holds
-    const float* stats; const bf16_t* c1; float* stats_part;
+    const float* stats; const float* c1; float* stats_part;
 };
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s);
 int gemm_partial_ks(int N, int K);                                // K-chunks launch_gemm_bf16(EPI_PARTIAL) should be given for an [<= 128, K] x [N, K]^T product
 int launch_gemm_ldr(const GemmArgs& p, int epi, hipStream_t s);    // gemm_ldr.hip: 256x256 tiles, 8 MFMA + 4 loader waves (N % 256 == 0)
 int launch_gemm_pers(const GemmArgs& p, int epi, hipStream_t s);   // gemm_pers.hip: the same tile, persistent workgroups, register epilogue (bf16, K >= 128)
 int gemm_pers_init(hipStream_t s);                                 // creates the (current device, stream) ticket counters ahead of its first launch (optional)
-void gemm_pers_set_lnf_prefetch(int on);                           // A/B switch of the LayerNorm-fold epilogue (tools)
 void gemm_pers_release(int dev);                                   // frees every stream's counters of a device (last context on it destroyed)
 
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_SIGMOID = 2, ACT_GELU = 3 };
@@ -56,7 +55,7 @@ int launch_rmsnorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w
 int launch_ln_stats_finalize(const float* part, int NT, int M, int D, float eps, float* stats, hipStream_t s);
 int launch_ln_row_stats(const bf16_t* x, int ldx, int M, int D, float eps, float* stats, hipStream_t s);      // the same from the rows themselves
 // Wf = bf16(W * gamma), c1 = row sums of Wf, c2 = W . beta + b   (at load)
-int launch_ln_fold_weights(const bf16_t* W, int ldw, const bf16_t* gamma, const bf16_t* beta, const bf16_t* b, bf16_t* Wf, bf16_t* c1, bf16_t* c2,
+int launch_ln_fold_weights(const bf16_t* W, int ldw, const bf16_t* gamma, const bf16_t* beta, const bf16_t* b, bf16_t* Wf, float* c1, bf16_t* c2,
                            int N, int K, hipStream_t s);
 // true: launch_gemm_bf16 would run this bias / activation GEMM on the persistent kernel (which has the fold epilogue) / this residual GEMM on
 // the loader-wave kernel (whose epilogue can emit the row statistics)

@@ -194,11 +194,11 @@ __global__ __launch_bounds__(256) void ln_row_stats_kernel(const bf16_t* __restr
         *reinterpret_cast<float2*>(stats + (size_t)m * 2) = make_float2(rstd, -mean * rstd);
     }
 }
-// W [N][K], LayerNorm weight / bias gamma, beta [K], linear bias b [N] ->  Wf = bf16(W * gamma) [N][K],  c1[n] = bf16(sum_k Wf[n][k]) (of the
+// W [N][K], LayerNorm weight / bias gamma, beta [K], linear bias b [N] ->  Wf = bf16(W * gamma) [N][K],  c1[n] = sum_k Wf[n][k] in fp32 (of the
 // ROUNDED products: it has to cancel what the GEMM accumulates for a constant row),  c2[n] = bf16(sum_k beta[k] W[n][k] + b[n]).  One workgroup per row.
 __global__ __launch_bounds__(256) void ln_fold_weights_kernel(const bf16_t* __restrict__ W, int ldw, const bf16_t* __restrict__ gamma,
                                                               const bf16_t* __restrict__ beta, const bf16_t* __restrict__ b, bf16_t* __restrict__ Wf,
-                                                              bf16_t* __restrict__ c1, bf16_t* __restrict__ c2, int K) {
+                                                              float* __restrict__ c1, bf16_t* __restrict__ c2, int K) {
     __shared__ float r1[4], r2[4];
     const int n = blockIdx.x, tid = threadIdx.x;
     float s1 = 0.f, s2 = 0.f;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void ln_fold_weights_kernel(const bf16_t* __re
     if ((tid & 63) == 0) { r1[tid >> 6] = s1; r2[tid >> 6] = s2; }
     __syncthreads();
     if (tid == 0) {
-        c1[n] = f2bf(r1[0] + r1[1] + r1[2] + r1[3]);
+        c1[n] = r1[0] + r1[1] + r1[2] + r1[3];
         c2[n] = f2bf(r2[0] + r2[1] + r2[2] + r2[3] + (b ? bf2f(b[n]) : 0.f));
     }
 }
@@ -227,7 +227,7 @@ int launch_ln_row_stats(const bf16_t* x, int ldx, int M, int D, float eps, float
     hipLaunchKernelGGL(ln_row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, M, D, eps, stats);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
-int launch_ln_fold_weights(const bf16_t* W, int ldw, const bf16_t* gamma, const bf16_t* beta, const bf16_t* b, bf16_t* Wf, bf16_t* c1, bf16_t* c2,
+int launch_ln_fold_weights(const bf16_t* W, int ldw, const bf16_t* gamma, const bf16_t* beta, const bf16_t* b, bf16_t* Wf, float* c1, bf16_t* c2,
                            int N, int K, hipStream_t s) {
     if (N < 1 || K < 1) return TRACE_ERR_ARG;
     hipLaunchKernelGGL(ln_fold_weights_kernel, dim3(N), dim3(256), 0, s, W, ldw, gamma, beta, b, Wf, c1, c2, K);

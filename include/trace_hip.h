@@ -174,6 +174,10 @@ int trace_op_attention(const void* Q, const void* K, const void* V, void* O, voi
 int trace_op_skinny_gemm(const void* X, const void* W, void* out, const void* R, int B, int N, int K, int epilogue,
                          int w_tiled, void* stream);
 int trace_op_skinny_ks(int N, int K, int epilogue, int B);
+/* Decode GEMV of 1..4 rows with the preceding "sum the partial rows + residual -> new residual, RMSNorm" folded in: part_in [ks_in][sk_rows][K] fp32
+   (ks_in may be 0) + R [B,K] -> xout [B,K]; out = fp32 partial rows [trace_op_skinny_ks(N,K,4,B)][sk_rows][N] of RMSNorm(xout; w, eps) . W^T */
+int trace_op_skinny_fused_norm(const float* part_in, int ks_in, const void* R, void* xout, const void* w, float eps, const void* W, float* out,
+                               int B, int N, int K, void* stream);
 int trace_op_sk_rows(void);                 /* row stride of every fp32 partial-row buffer = the largest decode batch (128) */
 /* Decode batches above 64 rows: out = X[M <= 128, K] . W[N, K]^T (row-major W) as fp32 k-chunk partial rows
    [trace_op_gemm_partial_ks(N, K)][trace_op_sk_rows()][N] for trace_op_add_rmsnorm (split-K MFMA GEMM, 128x128 tiles) */

@@ -304,6 +304,26 @@ def test_gemm_partial_rows(M, N, K):
         check("partial gemm + rmsnorm", y, xb * torch.rsqrt((xb * xb).mean(-1, keepdim=True) + 1e-5) * w.float(), 4e-2, 2e-2)
 
 
+@pytest.mark.parametrize("Bn,N,K,ks_in", [(1, 6144, 4096, 0), (1, 28672, 4096, 8), (3, 6144, 4096, 14), (4, 512, 4096, 2), (2, 256, 1024, 3)])
+def test_skinny_gemv_with_fused_add_rmsnorm(Bn, N, K, ks_in):
+    """Batches of 1..4: the decode GEMV sums the previous GEMV's partial rows, adds the residual, RMS-normalises and multiplies in one launch;
+    against the unfused pair (add_rmsnorm kernel + GEMV): the new residual rows bit for bit, the product within fp32 re-ordering of one sum."""
+    R, w, W = rnd(Bn, K, seed=1), (1 + 0.2 * rnd(K, seed=2).float()).to(torch.bfloat16), rnd(N, K, scale=0.05, seed=3)
+    part = None
+    if ks_in:
+        part = torch.zeros((ks_in, 128, K), dtype=torch.float32, device=DEV)
+        part[:, :Bn] = torch.randn(ks_in, Bn, K, device=DEV) * 0.3
+    xout, out = ops.skinny_fused_norm(part, R, w, 1e-5, W)
+    if ks_in:
+        x_ref, y_ref = ops.add_rmsnorm(part, R, w, 1e-5)
+    else:
+        x_ref, y_ref = R, ops.rmsnorm(R, w, 1e-5)
+    assert torch.equal(xout, x_ref)
+    ref = ops.skinny_gemm(y_ref, ops.tile_pack(W), epilogue=E.EPI_PARTIAL, tiled=True)
+    # the normalised activations can differ by one bf16 ulp where the two sums of squares round differently: compare the products with that slack
+    check("fused norm gemv", out[:, :Bn].sum(0), ref[:, :Bn].sum(0), 2e-2, 1e-2)
+
+
 @pytest.mark.parametrize("Bn,ctxs", [(1, [80]), (3, [1, 200, 2047]), (2, [16, 17])])
 def test_attn_decode(Bn, ctxs):
     nq, nkv, max_ctx = 32, 8, 2048

@@ -69,6 +69,7 @@ SIGNATURES = {
     "trace_op_set_gemm_trace": (I, [P]),
     "trace_op_skinny_ks": (I, [I, I, I, I]),
     "trace_op_sk_rows": (I, []),
+    "trace_op_skinny_fused_norm": (I, [P, I, P, P, P, F, P, P, I, I, I, P]),
     "trace_op_gemm_partial_ks": (I, [I, I]),
     "trace_op_gemm_partial": (I, [P, P, P, I, I, I, I, P]),
     "trace_op_gemm_swiglu_tiled": (I, [P, P, P, I, I, I, I, P]),

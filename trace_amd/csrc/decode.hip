@@ -45,12 +45,27 @@ union Frag { uint4 u; bf16x8_t v; };
 // ([KS][NT*NB][64 lanes][4] fp32, written through) are merged by whichever wave takes the tile's last agent-scope
 // ticket, always in chunk order, so results do not depend on arrival order — but that merge costs 5-8 us of dependent
 // round trips (store drain -> ticket -> acquire -> loads) per launch, which is why the decode step does not use it.
-template <int EPI, int NB, int NT>
+// PRO (round 3, batches of at most SKINNY_PRO_ROWS): the GEMV takes its activations from the PREVIOUS GEMV's fp32 partial rows instead of a bf16
+// matrix and does the decode step's "sum the chunks + residual -> new residual, RMSNorm" itself while it parks them — what add_rmsnorm_kernel
+// does between two GEMVs (4.5 us + a kernel boundary, twice per layer, of a 109 us layer at batch 1).  Every workgroup needs sum x^2 over the
+// WHOLE row, so every workgroup redoes the row's sum (B x K x (ks + 1) loads from L2: nothing at 1-4 rows, the reason it stops there), keeps its
+// groups in registers, writes the normalised bf16 values of ITS K-chunk into LDS in fragment order (the image the LDS-DMA parking builds) and,
+// if it is row-group 0, the chunk's new residual values to xout (!= R: other workgroups are still reading R).  Same sums, same roundings as
+// add_rmsnorm_kernel; only the order of the sum of squares differs (block reduction).
+struct SkinnyPro {
+    const float* part; int ks;     // fp32 partial rows [ks][SK_ROWS][K] of the previous GEMV (ks == 0: none, x = R)
+    const bf16_t* R; int ldr;      // residual rows [B][K]
+    bf16_t* xout; int ldx;         // new residual rows (ping-pong partner of R)
+    const bf16_t* w; float eps;    // RMSNorm weight [K]
+};
+constexpr int SKINNY_PRO_ROWS = 4;
+
+template <int EPI, int NB, int NT, bool PRO = false>
 __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W, int ldw,
                                                          bf16_t* __restrict__ out, int ldo, const bf16_t* __restrict__ R, int ldr,
                                                          int B, int K, int chunk_units, int KS, int T, int WPT, int ntiles,
                                                          float* __restrict__ ws, unsigned int* __restrict__ tickets, int tiled,
-                                                         int dbg) {
+                                                         int dbg, SkinnyPro pro) {
     // NT = 16-row weight tiles per task (2: a gate|up pair, or two neighbouring tiles of a wide PARTIAL product)
     constexpr int UN = (NT == 2) ? 2 : 4;                // 64-wide k units per load batch: 8 KB of weights per batch per wave
     constexpr int NF = NT * NB;                          // accumulator fragments per task
@@ -97,6 +112,76 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restric
 
     // ---- park X[:, chunk] in LDS in fragment order: combo c = (unit*2 + half)*NB + nb, lane (r, g) holds
     //      X[16 nb + r][(u_beg + unit)*64 + g*16 + half*8 .. +8]  (zeros for rows >= B) ----
+    if constexpr (PRO) {
+        if (!parked) {
+            __shared__ float s_ss[SKINNY_PRO_ROWS][8];
+            const int nthr = blockDim.x, ngrp = K >> 3;          // 8-element groups per row
+            constexpr int MAXG = 2;                               // 8-element groups per thread and row (the launcher checks K <= 16 * threads)
+            uint4 xv[SKINNY_PRO_ROWS][MAXG];
+            float ss[SKINNY_PRO_ROWS];
+#pragma unroll
+            for (int b = 0; b < SKINNY_PRO_ROWS; ++b) {
+                ss[b] = 0.f;
+                if (b < B) {
+#pragma unroll
+                    for (int q = 0; q < MAXG; ++q) {
+                        const int e8 = tid + q * nthr;
+                        xv[b][q] = make_uint4(0u, 0u, 0u, 0u);
+                        if (e8 < ngrp) {
+                            f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                            const float* pp = pro.part + (size_t)b * K + e8 * 8;
+                            for (int k2 = 0; k2 < pro.ks; ++k2) {      // chunk order
+                                a0 += *reinterpret_cast<const f32x4_t*>(pp + (size_t)k2 * SK_ROWS * K);
+                                a1 += *reinterpret_cast<const f32x4_t*>(pp + (size_t)k2 * SK_ROWS * K + 4);
+                            }
+                            const uint4 rr = *reinterpret_cast<const uint4*>(pro.R + (size_t)b * pro.ldr + e8 * 8);
+                            uint4 xo = rr;
+                            if (pro.ks > 0) {                       // bf16(sum) + residual, rounded: add_rmsnorm_kernel's arithmetic
+                                xo.x = pack2bf(bf2f(f2bf(a0[0])) + bflo(rr.x), bf2f(f2bf(a0[1])) + bfhi(rr.x));
+                                xo.y = pack2bf(bf2f(f2bf(a0[2])) + bflo(rr.y), bf2f(f2bf(a0[3])) + bfhi(rr.y));
+                                xo.z = pack2bf(bf2f(f2bf(a1[0])) + bflo(rr.z), bf2f(f2bf(a1[1])) + bfhi(rr.z));
+                                xo.w = pack2bf(bf2f(f2bf(a1[2])) + bflo(rr.w), bf2f(f2bf(a1[3])) + bfhi(rr.w));
+                            }
+                            xv[b][q] = xo;
+                            const uint32_t u[4] = {xo.x, xo.y, xo.z, xo.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) ss[b] = fmaf(bflo(u[e]), bflo(u[e]), fmaf(bfhi(u[e]), bfhi(u[e]), ss[b]));
+                            const int unit = e8 >> 3;
+                            if (rg == 0 && unit >= u_beg && unit < u_beg + nu)       // this chunk's share of the new residual row, written once
+                                *reinterpret_cast<uint4*>(pro.xout + (size_t)b * pro.ldx + e8 * 8) = xo;
+                        }
+                    }
+                    ss[b] = wave_sum(ss[b]);
+                    if (lane == 0) s_ss[b][wid] = ss[b];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < SKINNY_PRO_ROWS; ++b) {
+                if (b < B) {
+                    float tot = 0.f;
+                    for (int w2 = 0; w2 < nwaves; ++w2) tot += s_ss[b][w2];
+                    const float rstd = rsqrtf(tot / (float)K + pro.eps);
+#pragma unroll
+                    for (int q = 0; q < MAXG; ++q) {
+                        const int e8 = tid + q * nthr, unit = e8 >> 3;
+                        if (e8 < ngrp && unit >= u_beg && unit < u_beg + nu) {
+                            const uint4 wv = *reinterpret_cast<const uint4*>(pro.w + e8 * 8);
+                            const uint32_t xu[4] = {xv[b][q].x, xv[b][q].y, xv[b][q].z, xv[b][q].w}, wu[4] = {wv.x, wv.y, wv.z, wv.w};
+                            u32x4_t y;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] = pack2bf(bflo(xu[e]) * rstd * bflo(wu[e]), bfhi(xu[e]) * rstd * bfhi(wu[e]));
+                            // fragment order: combo (unit, half) -> 1 KB image, lane (r = b, g): X[b][unit*64 + g*16 + half*8 .. +8]
+                            const int g2 = (e8 & 7) >> 1, half = e8 & 1;
+                            xs[(((unit - u_beg) * 2 + half) * NB) * 64 + g2 * 16 + b] = y;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            parked = true;
+        }
+    }
     if (!parked && dbg != 6) {                          // (dbg == 6: the register-staged parking below, for A/B runs)
         // parking by LDS-DMA: a combo is one lane-linear 1 KB image whose lanes read arbitrary 16-byte sources — exactly what
         // global_load_lds does, with no register round trip, no ds_write and no index math in the way of the weight stream
@@ -897,19 +982,38 @@ size_t skinny_ws_floats(int N, int K, int epi) {
 }
 int skinny_ks(int N, int K, int epi, int B) { return skinny_plan(N, K, epi, B).KS; }
 
-template <int EPI, int NB, int NT>
+template <int EPI, int NB, int NT, bool PRO = false>
 static int skinny_lds_launch(const SkinnyPlan& p, const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo,
-                             const bf16_t* R, int ldr, int B, int K, float* ws, unsigned int* tickets, int tiled, hipStream_t s) {
+                             const bf16_t* R, int ldr, int B, int K, float* ws, unsigned int* tickets, int tiled, hipStream_t s,
+                             const SkinnyPro& pro = SkinnyPro{}) {
     const size_t lds = (size_t)p.chunk_units * 2 * NB * 1024 + (p.WPT > 1 ? (size_t)p.T * p.WPT * NT * NB * 1024 : 0);
     static size_t granted = 0;
     if (lds > granted) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_lds_kernel<EPI, NB, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_lds_kernel<EPI, NB, NT, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) return TRACE_ERR_HIP;
         granted = lds;
     }
-    hipLaunchKernelGGL((skinny_lds_kernel<EPI, NB, NT>), dim3(p.grid), dim3(p.threads), lds, s, X, ldx, W, ldw, out, ldo, R, ldr, B, K,
-                       p.chunk_units, p.KS, p.T, p.WPT, p.ntiles, ws, tickets, tiled, g_skinny_debug);
+    hipLaunchKernelGGL((skinny_lds_kernel<EPI, NB, NT, PRO>), dim3(p.grid), dim3(p.threads), lds, s, X, ldx, W, ldw, out, ldo, R, ldr, B, K,
+                       p.chunk_units, p.KS, p.T, p.WPT, p.ntiles, ws, tickets, tiled, g_skinny_debug, pro);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+}
+
+bool skinny_fused_norm_ok(int N, int K, int B) {
+    if (B < 1 || B > SKINNY_PRO_ROWS || K % 64 || K > 16384 || N % 16) return false;
+    return (K >> 3) <= 2 * skinny_plan(N, K, EPI_PARTIAL, B).threads;
+}
+// The fused form (see SkinnyPro): out-partials[ks][SK_ROWS][N] = RMSNorm(sum_k part_in + R; w) . Wtiled^T, new residual rows to xout.  B <= SKINNY_PRO_ROWS,
+// K <= 16384, tiled weights, part_in / ws and R / xout must not alias.
+int launch_skinny_gemm_fused_norm(const float* part_in, int ks_in, const bf16_t* R, int ldr, bf16_t* xout, int ldx, const bf16_t* w, float eps,
+                                  const bf16_t* Wtiled, int B, int N, int K, float* ws, size_t ws_floats, hipStream_t s) {
+    if (B < 1 || B > SKINNY_PRO_ROWS || K % 64 || K > 16384 || N % 16 || ks_in < 0 || (ks_in > 0 && !part_in) || !R || !xout || R == xout || !w) return TRACE_ERR_ARG;
+    if (part_in == ws || (ldr % 8) || (ldx % 8)) return TRACE_ERR_ARG;
+    const SkinnyPlan p = skinny_plan(N, K, EPI_PARTIAL, B);
+    if (!ws || ws_floats < skinny_plan_ws(p, N, EPI_PARTIAL, B)) return TRACE_ERR_ARG;
+    if ((K >> 3) > 2 * p.threads) return TRACE_ERR_STATE;                     // MAXG groups per thread: the caller keeps the unfused pair for this shape
+    const SkinnyPro pro{part_in, ks_in, R, ldr, xout, ldx, w, eps};
+    return skinny_nt(N, EPI_PARTIAL) == 2 ? skinny_lds_launch<EPI_PARTIAL, 1, 2, true>(p, nullptr, K, Wtiled, K, nullptr, N, nullptr, 0, B, K, ws, nullptr, 1, s, pro)
+                                           : skinny_lds_launch<EPI_PARTIAL, 1, 1, true>(p, nullptr, K, Wtiled, K, nullptr, N, nullptr, 0, B, K, ws, nullptr, 1, s, pro);
 }
 
 // EPI_PARTIAL: `out` is unused, ldo = N, the fp32 partial rows [KS = skinny_ks()][SK_ROWS][N] land in ws.

@@ -87,6 +87,8 @@ struct trace_ctx {
     float* attn_ws; unsigned int* tickets;
     void* pp_buf = nullptr; size_t pp_bytes = 0;       // frame preprocessing: tap tables + staged rows (grow-only)
     float* sk_ws = nullptr; unsigned int* sk_tickets = nullptr; size_t sk_ws_floats = 0; int sk_ntickets = 0;   // decode GEMV K-chunk partials
+    float* sk_ws2 = nullptr;           // second partial-row buffer and residual rows: the fused-norm GEMVs of small batches read one and write the other
+    bf16_t* dX2 = nullptr;
     float* part_val; int32_t* part_idx;
     float* hl_val; int32_t* hl_idx;        // trace_llm_head_logits' own partial buffers
     int32_t *d_slots, *d_pos, *d_heads, *d_done, *d_out_ids, *d_out_len, *d_step, *d_forced, *d_params;
@@ -275,6 +277,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
         c->sk_ws_floats = std::max<size_t>(f, 64);
         c->sk_ntickets = (int)std::max<size_t>(std::max<size_t>((size_t)c->QKV, (size_t)H), (size_t)(2 * I)) / 16;
         A(c->sk_ws, c->sk_ws_floats); A(c->sk_tickets, c->sk_ntickets);
+        A(c->sk_ws2, c->sk_ws_floats); A(c->dX2, SK_ROWS * H);
     }
     c->ntiles = c->NVpad / 16;
     A(c->part_val, (size_t)SK_ROWS * c->ntiles); A(c->part_idx, (size_t)SK_ROWS * c->ntiles);
@@ -1066,6 +1069,45 @@ static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
     return head_and_select(c, c->dH, 1, logits_out, s);
 }
 
+int g_decode_fuse_norm_rows = 4;   // batches up to this size take decode_step_fused (0 = never; A/B: trace_op_set_gemm_variant(170 + rows))
+// One decode step for 1..4 sequences (the reference drivers' own call shape is 1): the two "sum the partial rows + residual -> new residual, RMSNorm"
+// kernels of a layer are folded into the GEMVs that consume their output (decode.hip, SkinnyPro) — 5 launches per layer instead of 7:
+//   qkv GEMV [sums the previous layer's down partials + residual, input norm] -> attention (RoPE / append / attention) -> o GEMV
+//   -> gate|up GEMV [sums the o partials + residual, post-attention norm] -> SwiGLU combine -> down GEMV
+// Partial rows alternate between sk_ws (written by o / down, read by the fused GEMVs) and sk_ws2 (written by the fused GEMVs, read by the attention /
+// the combine); the residual rows alternate between dX and dX2 (a fused GEMV reads one and writes the other: its workgroups all read the whole row).
+static int decode_step_fused(trace_ctx* c, float* logits_out, hipStream_t s) {
+    const int H = c->H, I = c->I, HD = c->HD, QKV = c->QKV, B = c->B;
+    const int ks_q = skinny_ks(QKV, H, EPI_PARTIAL, B), ks_o = skinny_ks(H, H, EPI_PARTIAL, B);
+    const int ks_g = skinny_ks(2 * I, H, EPI_PARTIAL, B), ks_d = skinny_ks(H, I, EPI_PARTIAL, B);
+    bf16_t *xa = c->dX, *xb = c->dX2;             // current / next residual rows
+    for (int l = 0; l < c->NL; ++l) {
+        const LlmLayer& W = c->llm[l];
+        bf16_t* kc = c->kcache + (size_t)l * c->layer_stride;
+        bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
+        LCHK(launch_skinny_gemm_fused_norm(l ? c->sk_ws : nullptr, l ? ks_d : 0, xa, H, xb, H, W.rms1, c->c.rms_eps, W.wqkv_d, B, QKV, H, c->sk_ws2,
+                                           c->sk_ws_floats, s));
+        std::swap(xa, xb);
+        LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots, c->d_pos, c->dO,
+                                H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, decode_nsplit(B), 1.0f / sqrtf((float)HD), 1,
+                                c->rope_cos, c->rope_sin, c->sk_ws2, ks_q, s));
+        LCHK(launch_skinny_gemm(c->dO, H, W.wo_d, H, nullptr, H, nullptr, 0, B, H, H, EPI_PARTIAL, 1, SKWS(c), s));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (l == 0 && c->profile == 2 && (c->bracket_mask & 2) && s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) {
+            e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2;
+        }
+        if (e0) hipEventRecord(e0, s);
+        LCHK(launch_skinny_gemm_fused_norm(c->sk_ws, ks_o, xa, H, xb, H, W.rms2, c->c.rms_eps, W.wgu_d, B, 2 * I, H, c->sk_ws2, c->sk_ws_floats, s));
+        if (e1) hipEventRecord(e1, s);
+        std::swap(xa, xb);
+        LCHK(launch_swiglu_combine(c->sk_ws2, ks_g, 2 * I, c->dACT, I, B, s));
+        LCHK(launch_skinny_gemm(c->dACT, I, W.wd_d, I, nullptr, H, nullptr, 0, B, H, I, EPI_PARTIAL, 1, SKWS(c), s));
+    }
+    // an even number of fused GEMVs: the residual rows are back in dX; the last layer's down partials + residual -> final norm -> heads
+    LCHK(launch_add_rmsnorm(c->sk_ws, ks_d, xa, H, xa, H, c->final_norm, c->dH, H, B, H, c->c.rms_eps, s));
+    return head_and_select(c, c->dH, 1, logits_out, s);
+}
+
 int g_decode_unfused = 0;   // RoPE + cache append as a kernel of its own before the decode attention: 0 = from batch 32 up (bit-identical to the fused
                             // prologue, 1 % faster per 64-sequence step, one launch more — which batch 1 would feel), 1 = always, 2 = never
                             // (trace_op_set_gemm_variant(120 + x), tools/decode_ab.py)
@@ -1076,6 +1118,7 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
     // 5-8 us of dependent round trips per GEMV): qkv -> attention (RoPE + cache append + attention) -> o -> [sum + residual
     // -> new residual, RMSNorm] -> gate|up -> [sum, SwiGLU] -> down -> [sum + residual, next layer's / the final RMSNorm].
     if (B > SKINNY_ROWS || (B >= g_decode_wide_min && !c->fp8)) return decode_step_wide(c, logits_out, s);      // (fp8 contexts: at most 64 rows, checked at begin)
+    if (B <= g_decode_fuse_norm_rows && !c->fp8 && skinny_fused_norm_ok(QKV, H, B) && skinny_fused_norm_ok(2 * I, H, B)) return decode_step_fused(c, logits_out, s);
     const bool wo = c->fp8 && c->fp8_wonly;          // weight-only decode GEMVs: bf16 activations straight from dH / dO / dACT, no quantiser launches
     const bool f8 = c->fp8 && !wo;
     auto ksf = [&](int N, int K) { return wo ? skinny_w8_ks(N, K, B) : f8 ? skinny_fp8_ks(N, K, B) : skinny_ks(N, K, EPI_PARTIAL, B); };
@@ -1334,6 +1377,7 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
     if (variant >= 150 && variant <= 151) { g_vit_ln_fold = variant - 150; return TRACE_OK; }
+    if (variant >= 170 && variant <= 174) { g_decode_fuse_norm_rows = variant - 170; return TRACE_OK; }
     if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : 32; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
@@ -1467,6 +1511,24 @@ extern "C" int trace_op_skinny_w8(const void* X, const void* W8, const float* sw
         for (int b = 0; b < B; ++b)
             for (int n = 0; n < N; ++n) o[(size_t)b * N + n] += h[((size_t)ks * SK_ROWS + b) * N + n];
     HIPCHK(hipMemcpy(out, o.data(), o.size() * 4, hipMemcpyHostToDevice));
+    return TRACE_OK;
+}
+
+// the fused-norm decode GEMV of small batches: part_in [ks_in][sk_rows][K] fp32 + R [B,K] -> xout [B,K] (new residual), out = fp32 partial rows
+// [trace_op_skinny_ks(N,K,4,B)][sk_rows][N] of RMSNorm(xout; w) . W^T (W row-major here; packed internally)
+extern "C" int trace_op_skinny_fused_norm(const float* part_in, int ks_in, const void* R, void* xout, const void* w, float eps, const void* W, float* out,
+                                          int B, int N, int K, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!skinny_fused_norm_ok(N, K, B)) return fail(TRACE_ERR_ARG, "shape not supported by the fused-norm GEMV");
+    bf16_t* wt = nullptr; float* ws = nullptr;
+    const size_t wsf = skinny_ws_floats(N, K, EPI_PARTIAL);
+    HIPCHK(hipMalloc((void**)&wt, (size_t)N * K * 2)); HIPCHK(hipMalloc((void**)&ws, wsf * 4));
+    int rc = launch_tile_pack((const bf16_t*)W, K, wt, N, K, s);
+    if (rc == TRACE_OK) rc = launch_skinny_gemm_fused_norm(part_in, ks_in, (const bf16_t*)R, K, (bf16_t*)xout, K, (const bf16_t*)w, eps, wt, B, N, K, ws, wsf, s);
+    if (rc == TRACE_OK && hipMemcpyAsync(out, ws, (size_t)skinny_ks(N, K, EPI_PARTIAL, B) * SK_ROWS * N * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = TRACE_ERR_HIP;
+    hipStreamSynchronize(s);
+    hipFree(wt); hipFree(ws);
+    if (rc != TRACE_OK) return fail(rc, "fused-norm GEMV failed");
     return TRACE_OK;
 }
 

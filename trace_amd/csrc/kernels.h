@@ -127,6 +127,11 @@ int launch_rope_kv(bf16_t* qkv, int ld, bf16_t* kcache, bf16_t* vcache, long slo
 int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo, const bf16_t* R,
                        int ldr, int B, int N, int K, int epi, int tiled, float* ws, size_t ws_floats, unsigned int* tickets,
                        int ntickets, hipStream_t s);
+// the same GEMV fed by the PREVIOUS GEMV's partial rows: sums them, adds the residual R (-> new residual xout, != R), RMS-normalises (weight w) and parks the
+// result as its activations — add_rmsnorm folded into the next GEMV (B <= 4; decode.hip SkinnyPro); output = EPI_PARTIAL rows in ws (!= part_in)
+int launch_skinny_gemm_fused_norm(const float* part_in, int ks_in, const bf16_t* R, int ldr, bf16_t* xout, int ldx, const bf16_t* w, float eps,
+                                  const bf16_t* Wtiled, int B, int N, int K, float* ws, size_t ws_floats, hipStream_t s);
+bool skinny_fused_norm_ok(int N, int K, int B);      // false: this shape keeps the GEMV + add_rmsnorm pair
 size_t skinny_ws_floats(int N, int K, int epi);
 int skinny_ks(int N, int K, int epi, int B);
 int launch_tile_pack(const bf16_t* src, int ldw, bf16_t* dst, int N, int K, hipStream_t s);

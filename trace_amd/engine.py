@@ -568,6 +568,18 @@ class ops:
         return out
 
     @staticmethod
+    def skinny_fused_norm(part_in, R, w, eps, W):
+        """(xout, out-partials): xout = bf16(sum_k part_in[k, :B]) + R; partial rows [ks, sk_rows, N] of RMSNorm(xout; w) . W^T  (B <= 4)"""
+        lib = _lib.load()
+        Bn, K = R.shape
+        N = W.shape[0]
+        ks_in = 0 if part_in is None else part_in.shape[0]
+        xout = torch.empty_like(R)
+        out = torch.zeros((lib.trace_op_skinny_ks(N, K, EPI_PARTIAL, Bn), lib.trace_op_sk_rows(), N), dtype=torch.float32, device=R.device)
+        _lib.check(lib.trace_op_skinny_fused_norm(_ptr(part_in), ks_in, _ptr(R), _ptr(xout), _ptr(w), eps, _ptr(W), _ptr(out), Bn, N, K, _stream()))
+        return xout, out
+
+    @staticmethod
     def skinny_ks(N, K, epilogue, B):
         return _lib.load().trace_op_skinny_ks(N, K, epilogue, B)
 

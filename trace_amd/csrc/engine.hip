@@ -1069,7 +1069,9 @@ static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
     return head_and_select(c, c->dH, 1, logits_out, s);
 }
 
-int g_decode_fuse_norm_rows = 4;   // batches up to this size take decode_step_fused (0 = never; A/B: trace_op_set_gemm_variant(170 + rows))
+int g_decode_fuse_norm_rows = 1;   // batches up to this size take decode_step_fused (0 = never; A/B: trace_op_set_gemm_variant(170 + rows)).  Measured, ms per step,
+                                   // unfused / fused (profiles/r03_decode_small_ab.txt): batch 1 3.596 / 3.531, batch 2 3.698 / 3.781, batch 4 3.888 / 4.327 — every
+                                   // workgroup redoes the row sums, which only a single row repays
 // One decode step for 1..4 sequences (the reference drivers' own call shape is 1): the two "sum the partial rows + residual -> new residual, RMSNorm"
 // kernels of a layer are folded into the GEMVs that consume their output (decode.hip, SkinnyPro) — 5 launches per layer instead of 7:
 //   qkv GEMV [sums the previous layer's down partials + residual, input norm] -> attention (RoPE / append / attention) -> o GEMV

@@ -437,6 +437,7 @@ class TraceEngine:
                     raise ValueError(f"batch of {len(videos)} exceeds max_batch // 2 = {half} (two KV banks)")
                 brackets(1 if pending is None else 0)
                 fut = pool.submit(dec_job, *pending) if pending is not None else None
+                enc_s.wait_stream(cur)                  # the batch's frames may have been made on the caller's stream (device preprocessing)
                 try:
                     with torch.cuda.stream(enc_s):
                         self.encode_prefill(videos, timestamps, input_ids, bank * half)

@@ -99,23 +99,35 @@ def evaluate_videos(model, tokenizer, processor, items: Sequence[dict], prompt: 
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
     world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
     eng = model.engine
-    bs = min(batch_size or eng.max_batch, eng.max_batch)
+    # videos decoded together: the decode batch limit (128; 64 on the fp8 path).  When the engine holds two such banks of KV slots (max_batch >= 2 bs)
+    # the chunks go through the two-stage pipeline: chunk k decodes on one stream while chunk k+1 is preprocessed, encoded and prefilled on another
+    bs = max(1, min(batch_size or eng.decode_batch_max, eng.decode_batch_max))
+    pipelined = eng.max_batch >= 2 * bs
     nf = num_frames or getattr(model.config, "num_frames", 128)
     aspect = getattr(model.config, "image_aspect_ratio", "pad")
     mine = tdist.shard_indices(len(items), rank, world)
     local: List[List[int]] = []
-    for s0 in range(0, len(mine), bs):
-        chunk = [items[i] for i in mine[s0: s0 + bs]]
-        vids, tss, idl = [], [], []
-        for it in chunk:
-            v, ts = process_video(it["video"], processor, aspect, nf, fps=it.get("fps"), engine=eng if device_preprocess else None)
-            vids.append(v if v.is_cuda else v.to(eng.device, torch.bfloat16))
-            tss.append(ts)
-            q = prompt.format(it["query"].strip()) if it.get("query") is not None else prompt
-            idl.append(build_prompt_ids(q, tokenizer, conv_mode).tolist())
-        eos = tokenizer.eos_token_id if getattr(tokenizer, "eos_token_id", None) is not None else -1
-        out, _ = eng.generate(vids, tss, idl, [1] * len(chunk), max_new_tokens, eos=eos)
-        local.extend(out)
+    eos = tokenizer.eos_token_id if getattr(tokenizer, "eos_token_id", None) is not None else -1
+
+    def chunks():
+        for s0 in range(0, len(mine), bs):
+            chunk = [items[i] for i in mine[s0: s0 + bs]]
+            vids, tss, idl = [], [], []
+            for it in chunk:
+                v, ts = process_video(it["video"], processor, aspect, nf, fps=it.get("fps"), engine=eng if device_preprocess else None)
+                vids.append(v if v.is_cuda else v.to(eng.device, torch.bfloat16))
+                tss.append(ts)
+                q = prompt.format(it["query"].strip()) if it.get("query") is not None else prompt
+                idl.append(build_prompt_ids(q, tokenizer, conv_mode).tolist())
+            yield vids, tss, idl, [1] * len(chunk), None
+
+    if pipelined and len(mine) > bs:
+        for out, _ in eng.generate_stream(chunks(), max_new_tokens, eos=eos):
+            local.extend(out)
+    else:
+        for vids, tss, idl, heads, _ in chunks():
+            out, _ = eng.generate(vids, tss, idl, heads, max_new_tokens, eos=eos)
+            local.extend(out)
     per_rank = (len(items) + world - 1) // world
     if torch.distributed.is_initialized():
         gathered = tdist.gather_outputs(local, max_new_tokens, per_rank, eng.device)
@@ -143,14 +155,14 @@ def main():
                                         "each event, and describe each event with sentences.")
     ap.add_argument("--num-frames", type=int, default=None)
     ap.add_argument("--max-new-tokens", type=int, default=512)
-    ap.add_argument("--batch-size", type=int, default=64)
+    ap.add_argument("--batch-size", type=int, default=128, help="videos decoded together (the engine gets two such banks of KV slots: the pipeline's)")
     args = ap.parse_args()
     from .mm_utils import get_model_name_from_path
     from .model.builder import load_pretrained_model
     rank, local, world = tdist.init_from_env()
     torch.cuda.set_device(local)
     tok, model, proc, _ = load_pretrained_model(args.model, None, get_model_name_from_path(args.model), device=f"cuda:{local}",
-                                                max_batch=args.batch_size, max_new_tokens=args.max_new_tokens)
+                                                max_batch=min(256, 2 * args.batch_size), max_new_tokens=args.max_new_tokens)
     items = json.load(open(args.items))
     res = evaluate_videos(model, tok, proc, items, args.prompt, num_frames=args.num_frames, max_new_tokens=args.max_new_tokens,
                           batch_size=args.batch_size)

@@ -266,17 +266,23 @@ def main():
         t_enc = ev_time(enc_all) / B
     else:
         t_enc = ev_time(lambda: eng.encode_video(videos[0], ts[0]))
-    eng.encode_video(videos[0], ts[0])
-    Ls, emb0 = eng.splice(ids, want_output=True)
-    if B >= 2:                                       # as in generate(): equal-length neighbours share one prefill pass
-        eng.encode_video(videos[1], ts[1])
-        _, emb1 = eng.splice(ids, want_output=True)
-        t_pre = ev_time(lambda: eng.prefill_pair(0, emb0, emb1)) / 2
+    # the KV slots of the last timed batch are still prefilled (a decode only appends behind the prompt): the decode stage is re-timed on them; the
+    # prefill stage is timed into slots of the other bank (pipelined) or over the first slots (the same prompts again)
+    slot_base = ((args.steps - 1) % 2) * B if pipelined else 0
+    pf_slot = (B if slot_base == 0 else 0) if pipelined else 0
+    npf = min(B, eng.PREFILL_GROUP)
+    embs = []
+    for b in range(npf):
+        eng.encode_video(videos[b], ts[b])
+        Ls, e = eng.splice(ids, want_output=True)
+        embs.append(e.clone())
+    if npf >= 3:                                     # as in generate(): runs of equal-length neighbours share one prefill pass
+        t_pre = ev_time(lambda: eng.prefill_multi(pf_slot, embs)) / npf
+    elif npf == 2:
+        t_pre = ev_time(lambda: eng.prefill_pair(pf_slot, embs[0], embs[1])) / 2
     else:
-        t_pre = ev_time(lambda: eng.prefill(0, Ls))
-    for b in range(2 if B >= 2 else 1, B):
-        eng.encode_video(videos[b], ts[b]); eng.prefill(b, eng.splice(ids))
-    eng.decode_begin(list(range(B)), heads, n_new, -1, forced)
+        t_pre = ev_time(lambda: eng.prefill(pf_slot, Ls, embeds=embs[0]))
+    eng.decode_begin(list(range(slot_base, slot_base + B)), heads, n_new, -1, forced)
     t_dec = ev_time(lambda: eng.decode_steps(n_new - 1, use_graph=args.graph))
     # the drivers' shape of use: ONE video, batch 1, end to end (latency, not part of `value`)
     one = lambda: eng.generate(videos[:1], ts[:1], prompt[:1], heads[:1], n_new, eos=-1, use_graph=True, forced=forced[:1])

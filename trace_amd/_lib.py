@@ -46,6 +46,7 @@ SIGNATURES = {
     "trace_splice_embeds": (I, [P, P, I, P, I, P, I, C.POINTER(I), P, P]),
     "trace_llm_prefill": (I, [P, I, P, I, P, P]),
     "trace_llm_prefill_pair": (I, [P, I, P, P, I, P]),
+    "trace_llm_prefill_multi": (I, [P, I, C.POINTER(P), I, I, P]),
     "trace_llm_head_logits": (I, [P, P, I, I, P, P]),
     "trace_decode_begin": (I, [P, P, I, P, I, I, P, P, P]),
     "trace_decode_steps": (I, [P, I, I, P, P]),

@@ -39,6 +39,7 @@ struct LlmLayer {
 };
 struct StcBlock { bf16_t *w1, *n1w, *n1b, *wdw, *n2w, *n2b, *fc1w, *fc1b, *fc2w, *fc2b, *w3, *n3w, *n3b, *wd, *ndw, *ndb; int cin, rd; };
 
+constexpr int PF_MAX = 4;        // equal-length prompts one prefill pass can take (trace_llm_prefill_multi)
 constexpr int MAX_SLOTS = 256;   // KV-cache sequence slots per context (a decode batch is at most SK_ROWS of them)
 static int g_ctx_per_dev[16] = {0};
 
@@ -243,11 +244,11 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     }
     // --- prefill workspaces ---
     const size_t Lm = c->max_ctx;
-    // prefill workspaces hold two sequences (trace_llm_prefill_pair)
-    A(c->pX, 2 * Lm * H); A(c->pH, 2 * Lm * H); A(c->pQKV, 2 * Lm * c->QKV);
-    A(c->pO, 2 * Lm * H); A(c->pACT, 2 * Lm * I);
+    // prefill workspaces hold PF_MAX sequences (trace_llm_prefill_pair / _multi)
+    A(c->pX, PF_MAX * Lm * H); A(c->pH, PF_MAX * Lm * H); A(c->pQKV, PF_MAX * Lm * c->QKV);
+    A(c->pO, PF_MAX * Lm * H); A(c->pACT, PF_MAX * Lm * I);
     A(c->d_kind, Lm); A(c->d_row, Lm);
-    if (c->fp8) { A(c->pA8, 2 * Lm * std::max(H, I)); A(c->psa, 2 * Lm); A(c->dA8, (size_t)SK_ROWS * std::max(H, I)); A(c->dsa, SK_ROWS); A(c->dH8, (size_t)SK_ROWS * H); A(c->dsh, SK_ROWS); }
+    if (c->fp8) { A(c->pA8, PF_MAX * Lm * std::max(H, I)); A(c->psa, PF_MAX * Lm); A(c->dA8, (size_t)SK_ROWS * std::max(H, I)); A(c->dsa, SK_ROWS); A(c->dH8, (size_t)SK_ROWS * H); A(c->dsh, SK_ROWS); }
     // --- decode ---
     A(c->dX, SK_ROWS * H); A(c->dH, SK_ROWS * H); A(c->dQKV, SK_ROWS * (size_t)c->QKV); A(c->dO, SK_ROWS * H); A(c->dACT, SK_ROWS * I);
     A(c->xlast, (size_t)std::max(c->max_B, 64) * H);
@@ -967,6 +968,19 @@ extern "C" int trace_llm_prefill_pair(trace_ctx* c, int slot0, const void* embed
     HIPCHK(hipMemcpyAsync(c->pX, embeds0, (size_t)L * c->H * 2, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(c->pX + (size_t)L * c->H, embeds1, (size_t)L * c->H * 2, hipMemcpyDeviceToDevice, s));
     return prefill_impl(c, slot0, 2, L, nullptr, s);
+}
+
+// n <= 4 prompts of EQUAL spliced length in one pass -> KV slots slot0 .. slot0 + n - 1.  Four 1967-row prompts give the GEMMs M = 7868 = 31 row tiles:
+// qkv 744 tiles = 2.9 rounds of the 256 CUs (a pair: 384 = 1.5 rounds, a quarter of the second round's CUs idle), o / down 496 = 1.94, gate|up 13.6
+extern "C" int trace_llm_prefill_multi(trace_ctx* c, int slot0, const void* const* embeds, int n, int L, void* stream) {
+    if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
+    if (!embeds || n < 1 || n > PF_MAX || slot0 < 0 || slot0 + n > c->max_B || L < 1 || L > c->max_ctx) return fail(TRACE_ERR_ARG, "bad slot / n / L / embeds");
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < n; ++i) {
+        if (!embeds[i]) return fail(TRACE_ERR_ARG, "null embeds");
+        HIPCHK(hipMemcpyAsync(c->pX + (size_t)i * L * c->H, embeds[i], (size_t)L * c->H * 2, hipMemcpyDeviceToDevice, s));
+    }
+    return prefill_impl(c, slot0, n, L, nullptr, s);
 }
 
 // masked logits of R final-norm hidden rows under ONE head: what forward() returns for every position of a sequence

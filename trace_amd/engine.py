@@ -262,6 +262,16 @@ class TraceEngine:
         _lib.check(self.lib.trace_llm_prefill_pair(self.h, slot0, _ptr(embeds0.contiguous()), _ptr(embeds1.contiguous()),
                                                    embeds0.shape[0], _stream()))
 
+    PREFILL_GROUP = 4          # equal-length prompts one prefill pass takes (trace_llm_prefill_multi)
+
+    def prefill_multi(self, slot0: int, embeds: Sequence[torch.Tensor]):
+        """up to 4 spliced prompts of equal length -> KV slots slot0 .. slot0 + n - 1 in one pass"""
+        n = len(embeds)
+        assert 1 <= n <= self.PREFILL_GROUP and all(e.shape == embeds[0].shape and e.dtype == torch.bfloat16 and e.is_cuda for e in embeds)
+        keep = [e.contiguous() for e in embeds]
+        ptrs = (C.c_void_p * n)(*[e.data_ptr() for e in keep])
+        _lib.check(self.lib.trace_llm_prefill_multi(self.h, slot0, ptrs, n, keep[0].shape[0], _stream()))
+
     # ---- decode --------------------------------------------------------------------------------
     def decode_begin(self, slots: Sequence[int], heads: Sequence[int], max_new: int, eos: int = -1,
                      forced: Optional[Sequence[Sequence[int]]] = None, want_logits: bool = False):
@@ -318,8 +328,21 @@ class TraceEngine:
         B = len(videos)
         if slot0 < 0 or slot0 + B > self.max_batch:
             raise ValueError(f"slots {slot0}..{slot0 + B - 1} exceed the engine's {self.max_batch} KV slots")
-        # prefill: neighbours whose spliced prompts have the same length share one pass (M = 2L fills the GEMM tile grid)
-        held = None                                   # (slot, spliced embeds) waiting for a partner
+        # prefill: runs of up to 4 neighbours whose spliced prompts have the same length share one pass (M = 4 L fills the GEMM tile grids in whole
+        # rounds of the CUs); the spliced embeddings of a run wait in `held`
+        held: List[torch.Tensor] = []                 # spliced embeds of slots held_slot0 .. (equal lengths)
+        held_slot0 = 0
+
+        def flush():
+            nonlocal held
+            if len(held) == 1:
+                self.prefill(held_slot0, held[0].shape[0], embeds=held[0])
+            elif len(held) == 2:
+                self.prefill_pair(held_slot0, held[0], held[1])
+            elif held:
+                self.prefill_multi(held_slot0, held)
+            held = []
+
         feats = None
         if B > 1 and self.vit_batch_frames > self.max_frames and self.cfg.mm_projector_type != "stc_connector":
             feats = []                                # the tower runs over groups of videos (whole GEMM rounds); 12 GB of features at a time
@@ -341,19 +364,16 @@ class TraceEngine:
                 self.encode_features(feats.pop(b), timestamps[b])
             else:
                 self.encode_video(videos[b], timestamps[b])
-            if b + 1 < B or held is not None:
-                L, emb = self.splice(input_ids[b], want_output=True)
-                if held is not None and held[1].shape[0] == L and held[0] + 1 == slot0 + b:
-                    self.prefill_pair(held[0], held[1], emb)
-                    held = None
-                    continue
-                if held is not None:
-                    self.prefill(held[0], held[1].shape[0], embeds=held[1])
-                held = (slot0 + b, emb)
-            else:
-                self.prefill(slot0 + b, self.splice(input_ids[b]))
-        if held is not None:
-            self.prefill(held[0], held[1].shape[0], embeds=held[1])
+            if B == 1:
+                self.prefill(slot0, self.splice(input_ids[b]))
+                continue
+            L, emb = self.splice(input_ids[b], want_output=True)
+            if held and (held[0].shape[0] != L or len(held) == self.PREFILL_GROUP):
+                flush()
+            if not held:
+                held_slot0 = slot0 + b
+            held.append(emb)
+        flush()
 
     def decode(self, slots: Sequence[int], heads: Sequence[int], max_new_tokens: int, eos: int = -1, use_graph: bool = True,
                forced: Optional[Sequence[Sequence[int]]] = None):

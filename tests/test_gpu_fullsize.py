@@ -75,9 +75,15 @@ def test_pair_equals_single(big):
     cfg, eng, ids, vids, ts, L = big
     n = eng.n_new
     tol = fp8_budget(cfg.num_hidden_layers)[0] if eng.llm_fp8 else LOGIT_TOL     # (the pair / single GEMMs quantise the same rows: in practice far inside)
-    single = [_first_logits(eng, cfg, [vids[k]], ts, ids, [0]) for k in range(2)]
-    a, _ = eng.generate(vids[:1], [ts], [ids], [1], n, eos=-1)
-    b, _ = eng.generate(vids[1:], [ts], [ids], [1], n, eos=-1)
+    single, margins, solo = [], [], []
+    for k in range(2):                             # each video alone, free-running, with every step's logits: step-0 logits + the top-2 margins
+        lg0 = _first_logits(eng, cfg, [vids[k]], ts, ids, [0])
+        lgs = [lg0[0]] + [eng.decode_steps(1, use_graph=False, want_logits=True).float().cpu()[0] for _ in range(n - 1)]
+        single.append(lg0)
+        solo.append(eng.decode_read()[0][0])
+        top = [torch.topk(torch.where(torch.isfinite(x), x, torch.full_like(x, -1e30)), 2).values for x in lgs]
+        margins.append([float(t[0] - t[1]) for t in top])
+    a, b = [solo[0]], [solo[1]]
     ab, _ = eng.generate(vids, [ts, ts], [ids, ids], [1, 1], n, eos=-1)          # paired prefill, batch-2 decode
     # step-0 logits of the pair path (prefill_pair) vs the single path
     emb = []
@@ -90,11 +96,13 @@ def test_pair_equals_single(big):
         fin = torch.isfinite(single[k][0])
         assert torch.equal(torch.isfinite(lp[k]), fin) and int(fin.sum()) == cfg.time_vocab_size     # -inf outside the time head
         assert (lp[k][fin] - single[k][0][fin]).abs().max().item() < tol
-    for got, ref in ((ab[0], a[0]), (ab[1], b[0])):
-        agree = sum(int(x == y) for x, y in zip(got, ref))
-        first_diff = next((i for i, (x, y) in enumerate(zip(got, ref)) if x != y), len(ref))
-        # greedy streams may part only at a near-tie; with 13-way heads that is rare: demand a long common prefix
-        assert first_diff >= (4 if eng.llm_fp8 else 8), (first_diff, agree, got, ref)
+    for got, ref, mg in ((ab[0], a[0], margins[0]), (ab[1], b[0], margins[1])):
+        # greedy streams may part only at a near-tie of the run they are compared with (batch 1 and batch 2 sum in different orders): equal ids up
+        # to the first step whose own top-2 margin is inside twice the logit budget
+        for i, (x, y) in enumerate(zip(got, ref)):
+            if mg[i] < 2 * tol:
+                break
+            assert x == y, (i, mg[i], got, ref)
 
 
 def test_forced_feed_walks_heads(big):

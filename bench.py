@@ -301,6 +301,8 @@ def main():
             try:
                 tj = json.load(open(tf))
                 traffic, g_traffic, g_traffic_M = tj.get("skinny_gateup_bytes_per_launch"), tj.get("gemm_fc1_bytes_per_launch"), tj.get("gemm_fc1_M", 73856)
+                if B > 64:      # the wide decode step brackets the decode attention: the committed PMC pass measured it at one batch / context
+                    traffic = tj.get("attn_decode_bytes_per_launch") if tj.get("attn_decode_batch") == B else None
             except Exception:
                 traffic = g_traffic = None
         g_ms, g_n, g_gf = prof[5], int(prof[6]), prof[7]
@@ -346,8 +348,6 @@ def main():
         hbm_kernel = ("attn_decode_kernel (decode attention over the batch's KV cache, layer 0, 1 bracketed launch per decode step; wide decode step: "
                       "projections as small-M MFMA GEMMs)" if B > 64 else
                       "skinny_lds_kernel<EPI_PARTIAL,NB,NT=2> (decode gate|up GEMV, 1 bracketed launch per decode step)")
-        if B > 64:
-            traffic = None                                  # the committed PMC pass measured the GEMV
         line["roofline_hbm"] = {"bound": "hbm", "kernel": hbm_kernel,
                                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
                                 "traffic": traffic, "algorithmic_bytes_per_launch": k_bytes, "avg_launch_ms": k_ms, "samples": k_n}

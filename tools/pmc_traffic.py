@@ -19,6 +19,11 @@ def counter_mean(d, counter, kernel_sub):
 
 fetch_kb, n1 = counter_mean(sys.argv[1], "FETCH_SIZE", "skinny_lds_kernel")
 write_kb, n2 = counter_mean(sys.argv[2], "WRITE_SIZE", "skinny_lds_kernel")
+af_kb, a1 = counter_mean(sys.argv[1], "FETCH_SIZE", "attn_decode_kernel")
+aw_kb, a2 = counter_mean(sys.argv[2], "WRITE_SIZE", "attn_decode_kernel")
+AD_B, AD_CTX = 128, 2100       # tools/pmc_kernels.py attn_decode
+a_alg = AD_B * AD_CTX * 8 * 128 * 2 * 2
+a_total = af_kb * 1024 * 2 + aw_kb * 1024
 gf_kb, g1 = counter_mean(sys.argv[1], "FETCH_SIZE", "gemm_pers_kernel<2")
 gw_kb, g2 = counter_mean(sys.argv[2], "WRITE_SIZE", "gemm_pers_kernel<2")
 FC1_M = 170 * 577       # tools/pmc_kernels.py: one 170-frame ViT call (the bench's probe shape)
@@ -27,10 +32,15 @@ g_total = gf_kb * 1024 * 2 + gw_kb * 1024
 alg = 28672 * 4096 * 2
 total = fetch_kb * 1024 * 2 + write_kb * 1024
 json.dump({
+    "attn_decode_bytes_per_launch": a_total, "attn_decode_batch": AD_B, "attn_decode_ctx": AD_CTX,
+    "attn_decode_detail": {
+        "kernel": "attn_decode_kernel, %d sequences x ctx %d x 8 kv heads (the wide decode step's dominant kernel), 4 launches" % (AD_B, AD_CTX),
+        "FETCH_SIZE_KB_mean": af_kb, "WRITE_SIZE_KB_mean": aw_kb, "launches": [a1, a2],
+        "correction": "FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024", "algorithmic_bytes": a_alg, "ratio_traffic_over_algorithmic": a_total / a_alg},
     "gemm_fc1_bytes_per_launch": g_total,
     "gemm_fc1_M": FC1_M,
     "gemm_fc1_detail": {
-        "kernel": "gemm_pers_kernel<EPI_QUICKGELU> (ViT fc1, M=%d N=4096 K=1024), 3 launches" % FC1_M,
+        "kernel": "gemm_pers_kernel<EPI_QUICKGELU, LayerNorm fold> (ViT fc1, M=%d N=4096 K=1024), 3 launches" % FC1_M,
         "FETCH_SIZE_KB_mean": gf_kb, "WRITE_SIZE_KB_mean": gw_kb, "launches": [g1, g2],
         "correction": "FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 (same gfx950 corrections as below; operand panels re-read by "
                       "other column tiles are served by L2 / infinity cache and only partly reach the memory-side counters)",

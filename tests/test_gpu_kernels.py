@@ -277,14 +277,15 @@ def test_gemm_residual_row_statistics(M, N, K):
     torch.testing.assert_close(st[:, 1], -mean * rstd, rtol=2e-3, atol=2e-4)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 6144, 4096), (100, 4096, 4096), (65, 4096, 14336), (128, 4096, 256), (77, 512, 4096)])
+@pytest.mark.parametrize("M,N,K", [(128, 6144, 4096), (100, 4096, 4096), (65, 4096, 14336), (128, 4096, 256), (77, 512, 4096), (256, 4096, 4096), (200, 6144, 4096)])
 def test_gemm_partial_rows(M, N, K):
     """Decode batches above 64 rows: the split-K MFMA GEMM leaves fp32 k-chunk partial rows [ks][sk_rows][N]; their sum is the product,
     and the decode consumer (sum + residual + RMSNorm) takes them exactly as it takes the GEMV's."""
     X, W = rnd(M, K, seed=3), rnd(N, K, scale=0.05, seed=4)
     part = ops.gemm_partial(X, W)
     lin = X.float() @ W.float().t()
-    assert part.shape[1] == 128 and part.shape[0] >= 1
+    SKR = part.shape[1]
+    assert SKR >= M and part.shape[0] >= 1
     check("partial gemm", part[:, :M].sum(0), lin, 3e-2, 1e-2)
     if K % 64 == 0:      # weights from the decode tile copy: each MFMA then sums another 32 of a K-tile's 64 k (fp32 order differs: tolerance, not bits);
         Wt = ops.tile_pack(W)                               # the 4-stage ring changes nothing
@@ -294,7 +295,7 @@ def test_gemm_partial_rows(M, N, K):
         if N % 256 == 0:
             sw = ops.gemm_swiglu_tiled(X, Wt)              # rows read as 16-row interleaved gate|up
             check("tiled swiglu gemm", sw, ops.gemm(X, W, epilogue=E.EPI_SWIGLU), 3e-2, 1e-2)
-    assert float(part[:, M:].abs().max()) == 0.0 if M < 128 else True          # rows beyond M are never written
+    assert float(part[:, M:].abs().max()) == 0.0 if M < SKR else True          # rows beyond M are never written
     if N <= 4096:
         R, w = rnd(M, N, seed=5), rnd(N, seed=6)
         x, y = ops.add_rmsnorm(part, R, w, 1e-5)
@@ -311,7 +312,7 @@ def test_skinny_gemv_with_fused_add_rmsnorm(Bn, N, K, ks_in):
     R, w, W = rnd(Bn, K, seed=1), (1 + 0.2 * rnd(K, seed=2).float()).to(torch.bfloat16), rnd(N, K, scale=0.05, seed=3)
     part = None
     if ks_in:
-        part = torch.zeros((ks_in, 128, K), dtype=torch.float32, device=DEV)
+        part = torch.zeros((ks_in, ops.skinny_ks.__self__ if False else E._lib.load().trace_op_sk_rows(), K), dtype=torch.float32, device=DEV)
         part[:, :Bn] = torch.randn(ks_in, Bn, K, device=DEV) * 0.3
     xout, out = ops.skinny_fused_norm(part, R, w, 1e-5, W)
     if ks_in:

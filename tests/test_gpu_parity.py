@@ -189,12 +189,12 @@ def test_errors_are_python_exceptions(setup):
         eng.time_ids([[1.0], [2.0, 3.0]])       # unequal time-token length (trace_arch.py:285)
 
 
-@pytest.mark.parametrize("nb", [20, 40, 64, 65, 100, 128])
+@pytest.mark.parametrize("nb", [20, 40, 64, 65, 100, 128, 200, 256])
 def test_big_batch_equals_single(setup, nb):
     """B > 16 / B > 32 exercise the two- and four-group decode GEMV (NB = 2, 4) and the second head pass; B > 64 the wide decode step
     (projections as small-M MFMA GEMMs: gate|up with the SwiGLU epilogue, qkv / o / down as split-K partial rows; four head passes at
-    128): nb sequences (two distinct videos, alternating) must reproduce the B = 1 streams — through the captured hipGraph (one per
-    batch size, up to the 128-row maximum) and through eager launches."""
+    128, two row panels of GEMM tiles and eight head passes at 256): nb sequences (two distinct videos, alternating) must reproduce the B = 1
+    streams — through the captured hipGraph (one per batch size, up to the 256-row maximum) and through eager launches."""
     cfg, eng, ora, E, frames = setup
     f2 = synth.synth_frames(cfg, 1).to(torch.bfloat16)
     ts, ids = E["timestamps"].tolist(), E["input_ids"].tolist()

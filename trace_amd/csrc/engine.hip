@@ -40,7 +40,7 @@ struct LlmLayer {
 struct StcBlock { bf16_t *w1, *n1w, *n1b, *wdw, *n2w, *n2b, *fc1w, *fc1b, *fc2w, *fc2b, *w3, *n3w, *n3b, *wd, *ndw, *ndb; int cin, rd; };
 
 constexpr int PF_MAX = 4;        // equal-length prompts one prefill pass can take (trace_llm_prefill_multi)
-constexpr int MAX_SLOTS = 256;   // KV-cache sequence slots per context (a decode batch is at most SK_ROWS of them)
+constexpr int MAX_SLOTS = 512;   // KV-cache sequence slots per context (a decode batch is at most SK_ROWS of them)
 static int g_ctx_per_dev[16] = {0};
 
 struct trace_ctx {
@@ -169,7 +169,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     c->fp8_wonly = cfg->llm_weights_fp8 == 2;
     if (c->fp8 && (c->H % 128 || c->I % 128 || c->I > 16384)) return bad("fp8 weight path needs hidden / intermediate sizes that are multiples of 128 (intermediate <= 16384)");
     if (!c->stc && (c->S != 8 || c->vh > 1024)) return bad("slot pool kernel needs 8 slots and mm_hidden <= 1024");
-    if (c->max_B < 1 || c->max_B > MAX_SLOTS) return bad("max_batch (KV slots) must be in [1,256]");
+    if (c->max_B < 1 || c->max_B > MAX_SLOTS) return bad("max_batch (KV slots) must be in [1,512]");
     c->nsplit = 32;                                           // upper bound (workspace size); per-batch value below
     {
         const int g2 = c->G / 2 + 1;

@@ -388,18 +388,19 @@ static int launch_dec(const GemmArgs& p, int nblk, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 static int launch_partial(const GemmArgs& p, hipStream_t s) {
-    if (p.M < 1 || p.M > 128 || p.M > SK_ROWS || p.N % 128 || p.K % BK || p.fp8 || !p.part || p.ks < 1 || (p.K / BK) % p.ks) return TRACE_ERR_ARG;
+    if (p.M < 1 || p.M > SK_ROWS || p.N % 128 || p.K % BK || p.fp8 || !p.part || p.ks < 1 || (p.K / BK) % p.ks) return TRACE_ERR_ARG;
     if ((p.lda % 8) || (p.ldw % 8)) return TRACE_ERR_ARG;
-    const int nblk = (p.N / 128) * p.ks;
+    const int nblk = ((p.M + 127) / 128) * (p.N / 128) * p.ks;      // above 128 rows: two row panels (neighbours in the tile order: the second reads its weight tile from L2)
     if (!p.w_tiled) return launch_dec<EPI_PARTIAL, false, 2>(p, nblk, s);
     return (p.w_tiled & 4) ? launch_dec<EPI_PARTIAL, true, 4>(p, nblk, s) : launch_dec<EPI_PARTIAL, true, 2>(p, nblk, s);
 }
 // gate|up of a wide decode step: [M <= 128, K] x tiled W -> SwiGLU -> bf16, one row panel of 128x128 tiles
 static int launch_swiglu_tiled(const GemmArgs& p, hipStream_t s) {
-    if (p.M < 1 || p.M > 128 || p.N % 128 || p.K % BK || p.fp8 || (p.lda % 8) || (p.ldc % 8)) return TRACE_ERR_ARG;
-    return (p.w_tiled & 4) ? launch_dec<EPI_SWIGLU, true, 4>(p, p.N / 128, s) : launch_dec<EPI_SWIGLU, true, 2>(p, p.N / 128, s);
+    if (p.M < 1 || p.M > SK_ROWS || p.N % 128 || p.K % BK || p.fp8 || (p.lda % 8) || (p.ldc % 8)) return TRACE_ERR_ARG;
+    const int nblk = ((p.M + 127) / 128) * (p.N / 128);
+    return (p.w_tiled & 4) ? launch_dec<EPI_SWIGLU, true, 4>(p, nblk, s) : launch_dec<EPI_SWIGLU, true, 2>(p, nblk, s);
 }
-// K-chunks for the partial-row GEMM: enough workgroups ((N / 128) x ks) to put at least one on every CU, chunks of whole K-tiles, at least 4
+// K-chunks for the partial-row GEMM (sized for one row panel): enough workgroups ((N / 128) x ks) to put at least one on every CU, chunks of whole K-tiles, at least 4
 // K-tiles per chunk (a shorter K loop is all prologue).  TRACE_PARTIAL_WGS overrides the workgroup target (tuning runs).
 int gemm_partial_ks(int N, int K) {
     static const int target = getenv("TRACE_PARTIAL_WGS") ? atoi(getenv("TRACE_PARTIAL_WGS")) : 256;

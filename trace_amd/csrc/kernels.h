@@ -5,7 +5,7 @@
 #include <stdint.h>
 #include "common.h"
 
-constexpr int SK_ROWS = 128;     // largest decode batch = row stride of the fp32 k-chunk partial buffers [ks][SK_ROWS][N]
+constexpr int SK_ROWS = 256;     // largest decode batch = row stride of the fp32 k-chunk partial buffers [ks][SK_ROWS][N]
 constexpr int SKINNY_ROWS = 64;  // rows one skinny (activations-parked-in-LDS) GEMV takes; larger batches run the split-K MFMA GEMM (gemm.hip)
 enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_QUICKGELU = 2, EPI_SWIGLU = 3, EPI_PARTIAL = 4 };   // PARTIAL: decode GEMV only
 

@@ -64,8 +64,8 @@ class TraceEngine:
 
     @property
     def decode_batch_max(self) -> int:
-        """sequences one decode batch can hold: the KV slots, at most 128 (64 on the fp8 weight path)"""
-        return min(self.max_batch, 64 if self.llm_fp8 else 128)
+        """sequences one decode batch can hold: the KV slots, at most 256 (64 on the fp8 weight path)"""
+        return min(self.max_batch, 64 if self.llm_fp8 else self.lib.trace_op_sk_rows())
 
     @staticmethod
     def full_round_frames(cfg: TraceConfig) -> int:

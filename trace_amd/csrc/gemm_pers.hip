@@ -167,7 +167,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // rows I0 .. I0+NI-1 (16-row m-tiles) of the wave's sub-tile: activation in registers, lane transposition, stores.  C and R are addressed
 // through buffer descriptors (scalar base + ONE 32-bit byte offset register per access) whose extent is the M valid rows: rows of the
 // last row panel that hang over M are dropped (stores) / read as zero (loads) by the bounds check, no predicates and no second code path.
-template <int EPI, int I0, int NI, bool LNF = false>
+template <int EPI, int I0, int NI, bool LNF = false, bool F2 = false>
 __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp)[TN], __amdgpu_buffer_rsrc_t crs, int coff, int cstep, bool hi8,
                                               const char* lnf_c1, const char* lnf_c2, const char* lnf_stat) {
     constexpr bool GLU = (EPI == EPI_SWIGLU);
@@ -229,7 +229,9 @@ __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp
                 }
                 pk[j][0] = pack2bf(x01[0], x01[1]);
                 pk[j][1] = pack2bf(x23[0], x23[1]);
-                if (LNF) PERS_FENCE();             // the next n-tile's LDS reads stay behind this one's math (hoisted together they spill)
+                // the next n-tile's LDS reads stay behind this one's math (hoisted together they spill).  F2 (A/B build): a fence per PAIR of n-tiles —
+                // two reads in flight, half the exposed LDS round trips, for one 16-byte spill per tile
+                if (LNF && (!F2 || (j & 1))) PERS_FENCE();
             }
         } else {
 #pragma unroll
@@ -576,9 +578,10 @@ __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, i
             if (has_next) PERS_FRAGS(q);
             residual_store(out, rr, crs, coff, 32 * p.ldc);
         } else {
-            epilogue_rows<EPI, 0, TM / 2, LNF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sc2, sstat);
+            constexpr bool F2 = (OPT & 32) != 0;
+            epilogue_rows<EPI, 0, TM / 2, LNF, F2>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sc2, sstat);
             if (has_next) PERS_FRAGS(q);                            // 24 registers the first half of the epilogue has freed
-            epilogue_rows<EPI, TM / 2, TM / 2, LNF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sc2, sstat);
+            epilogue_rows<EPI, TM / 2, TM / 2, LNF, F2>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sc2, sstat);
         }
         if (!has_next) break;
         li = li_next;
@@ -632,10 +635,14 @@ void launch_opt(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
     hipLaunchKernelGGL((gemm_pers_kernel<EPI, OPT>), dim3(nblk), dim3(NTHR), LDS_BYTES, s, p, ctr, dynamic);
 }
 int g_opt = 0;
+int g_gemm_pers_lnf_pairfence = 0;     // LN-fold epilogue: scheduling fence per pair of n-tiles instead of per n-tile (A/B: trace_op_set_gemm_variant(160 + x))
 template <int EPI>
 void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
     if (p.stats) {                                  // LN fold (EPI_NONE / EPI_QUICKGELU: launch_gemm_pers checks)
-        if constexpr (EPI == EPI_NONE || EPI == EPI_QUICKGELU) launch_opt<EPI, 16>(p, nblk, dynamic, ctr, s);
+        if constexpr (EPI == EPI_NONE || EPI == EPI_QUICKGELU) {
+            if (g_gemm_pers_lnf_pairfence) launch_opt<EPI, 48>(p, nblk, dynamic, ctr, s);
+            else launch_opt<EPI, 16>(p, nblk, dynamic, ctr, s);
+        }
         return;
     }
     switch (g_opt) {
@@ -651,6 +658,7 @@ void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
 int g_gemm_pers_opt = 0;           // A/B builds of the K loop (trace_op_set_gemm_variant(300 + opt))
 int g_gemm_pers_static = 0;        // 1: tiles dealt round-robin instead of by ticket (A/B runs)
 
+void gemm_pers_set_lnf_pairfence(int on) { g_gemm_pers_lnf_pairfence = on; }
 int g_gemm_pers_grid_cap = 0;      // > 0: at most this many workgroups per launch (a stream confined to part of the CUs by a CU mask: the
                                    // persistent grid must not exceed the CUs it can run on, or the surplus workgroups wait for a second round)
 

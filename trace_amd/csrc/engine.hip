@@ -1393,7 +1393,6 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
     if (variant >= 150 && variant <= 151) { g_vit_ln_fold = variant - 150; return TRACE_OK; }
-    if (variant >= 160 && variant <= 161) { gemm_pers_set_lnf_pairfence(variant - 160); return TRACE_OK; }
     if (variant >= 170 && variant <= 174) { g_decode_fuse_norm_rows = variant - 170; return TRACE_OK; }
     if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : 32; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }

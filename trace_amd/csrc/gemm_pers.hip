@@ -167,7 +167,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // rows I0 .. I0+NI-1 (16-row m-tiles) of the wave's sub-tile: activation in registers, lane transposition, stores.  C and R are addressed
 // through buffer descriptors (scalar base + ONE 32-bit byte offset register per access) whose extent is the M valid rows: rows of the
 // last row panel that hang over M are dropped (stores) / read as zero (loads) by the bounds check, no predicates and no second code path.
-template <int EPI, int I0, int NI, bool LNF = false, bool F2 = false>
+template <int EPI, int I0, int NI, bool LNF = false>
 __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp)[TN], __amdgpu_buffer_rsrc_t crs, int coff, int cstep, bool hi8,
                                               const char* lnf_c1, const char* lnf_c2, const char* lnf_stat) {
     constexpr bool GLU = (EPI == EPI_SWIGLU);
@@ -187,7 +187,8 @@ __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp
     // LN fold: c1 (fp32) and c2 (bf16) of the lane's 4 columns are re-read from the tile's LDS rows for every (m-tile, n-tile), with a scheduling
     // fence per n-tile.  Held in registers like the bias they are 8-16 more of them beside 128 accumulators (those builds spilled 40-84 bytes
     // per lane); unfenced, the compiler hoists all the reads of an m-tile together (spills again); read one n-tile ahead (4 more registers) the
-    // build spills 16 bytes per tile and measured SLOWER than this form (profiles/r03_vit_stream170_lnfold*_kernel_stats.csv: fc1 784 vs 777 us).
+    // build spills 16 bytes per tile and measured SLOWER than this form (profiles/r03_vit_stream170_lnfold*_kernel_stats.csv: fc1 784 vs 777 us); so did a
+    // fence per PAIR of n-tiles (two reads in flight, the same 16-byte spill: fc1 774 vs 766, qkv 563 vs 549 us).
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         uint32_t pk[2 * NH][2];
@@ -229,9 +230,7 @@ __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp
                 }
                 pk[j][0] = pack2bf(x01[0], x01[1]);
                 pk[j][1] = pack2bf(x23[0], x23[1]);
-                // the next n-tile's LDS reads stay behind this one's math (hoisted together they spill).  F2 (A/B build): a fence per PAIR of n-tiles —
-                // two reads in flight, half the exposed LDS round trips, for one 16-byte spill per tile
-                if (LNF && (!F2 || (j & 1))) PERS_FENCE();
+                if (LNF) PERS_FENCE();             // the next n-tile's LDS reads stay behind this one's math (hoisted together they spill)
             }
         } else {
 #pragma unroll
@@ -578,10 +577,9 @@ __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, i
             if (has_next) PERS_FRAGS(q);
             residual_store(out, rr, crs, coff, 32 * p.ldc);
         } else {
-            constexpr bool F2 = (OPT & 32) != 0;
-            epilogue_rows<EPI, 0, TM / 2, LNF, F2>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sc2, sstat);
+            epilogue_rows<EPI, 0, TM / 2, LNF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sc2, sstat);
             if (has_next) PERS_FRAGS(q);                            // 24 registers the first half of the epilogue has freed
-            epilogue_rows<EPI, TM / 2, TM / 2, LNF, F2>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sc2, sstat);
+            epilogue_rows<EPI, TM / 2, TM / 2, LNF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sc2, sstat);
         }
         if (!has_next) break;
         li = li_next;
@@ -635,14 +633,10 @@ void launch_opt(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
     hipLaunchKernelGGL((gemm_pers_kernel<EPI, OPT>), dim3(nblk), dim3(NTHR), LDS_BYTES, s, p, ctr, dynamic);
 }
 int g_opt = 0;
-int g_gemm_pers_lnf_pairfence = 0;     // LN-fold epilogue: scheduling fence per pair of n-tiles instead of per n-tile (A/B: trace_op_set_gemm_variant(160 + x))
 template <int EPI>
 void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
     if (p.stats) {                                  // LN fold (EPI_NONE / EPI_QUICKGELU: launch_gemm_pers checks)
-        if constexpr (EPI == EPI_NONE || EPI == EPI_QUICKGELU) {
-            if (g_gemm_pers_lnf_pairfence) launch_opt<EPI, 48>(p, nblk, dynamic, ctr, s);
-            else launch_opt<EPI, 16>(p, nblk, dynamic, ctr, s);
-        }
+        if constexpr (EPI == EPI_NONE || EPI == EPI_QUICKGELU) launch_opt<EPI, 16>(p, nblk, dynamic, ctr, s);
         return;
     }
     switch (g_opt) {
@@ -658,7 +652,6 @@ void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
 int g_gemm_pers_opt = 0;           // A/B builds of the K loop (trace_op_set_gemm_variant(300 + opt))
 int g_gemm_pers_static = 0;        // 1: tiles dealt round-robin instead of by ticket (A/B runs)
 
-void gemm_pers_set_lnf_pairfence(int on) { g_gemm_pers_lnf_pairfence = on; }
 int g_gemm_pers_grid_cap = 0;      // > 0: at most this many workgroups per launch (a stream confined to part of the CUs by a CU mask: the
                                    // persistent grid must not exceed the CUs it can run on, or the surplus workgroups wait for a second round)
 

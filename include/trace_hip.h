@@ -34,7 +34,7 @@ typedef struct trace_config {
     float slot_eps, slot_rope_base;
     int32_t max_frames;      /* largest T per video                                    */
     int32_t max_ctx;         /* KV-cache length per sequence slot (prefill + new tokens) */
-    int32_t max_batch;       /* KV-cache sequence slots, <= 256; one decode batch takes at most 128 of them (64 on the fp8 path; the rest can be
+    int32_t max_batch;       /* KV-cache sequence slots, <= 512; one decode batch takes at most 256 of them (64 on the fp8 path; the rest can be
                               * prefilled meanwhile: trace_amd.engine.TraceEngine.generate_stream) */
     int32_t max_new_tokens;  /* capacity of the on-device output id buffer               */
     int32_t projector_type;  /* 0 = spatial_slot (TRACE), 1 = stc_connector (legacy API) */

@@ -82,6 +82,23 @@ def test_decode_gemv_does_not_spill(res):
         assert v["ScratchSize"] == 0, (k, v)
 
 
+def test_round3_kernels_keep_their_budgets(res):
+    """The LayerNorm-fold instantiations of the persistent GEMM (OPT 16: the first builds of that epilogue spilled 40-116 bytes per lane) and the
+    decode GEMMs of the wide decode step (128x128 tiles, tiled weights, 4-stage ring: 128 KB of LDS = one workgroup per CU by design, no scratch)."""
+    lnf = {k: v for k, v in _pick(res["gemm_pers"], "gemm_pers_kernel").items() if "ELi16E" in k}
+    assert len(lnf) >= 2, list(res["gemm_pers"])
+    for k, v in lnf.items():
+        assert v["ScratchSize"] == 0 and v["VGPRs"] + v.get("AGPRs", 0) <= 168, (k, v)
+    dec = {k: v for k, v in _pick(res["gemm"], "gemm_glds_kernel").items() if "ELb1ELi4E" in k}      # <..., WT = true, NSTAGE = 4>
+    assert len(dec) >= 2, list(res["gemm"])
+    for k, v in dec.items():
+        assert v["ScratchSize"] == 0, (k, v)
+    pro = {k: v for k, v in _pick(res["decode"], "skinny_lds_kernel").items() if k.rstrip("E").endswith("ELb1EEvPKtiS2_iPtiS2_iiiiiiiiPfPjiiNS_9SkinnyPro") or "ELb1EE" in k}
+    assert pro, list(res["decode"])[:4]
+    for k, v in pro.items():
+        assert v["ScratchSize"] == 0, (k, v)
+
+
 def test_no_asm_load_into_a_dummy_register():
     """An inline-asm load whose output is never read is dead to the compiler the moment it is issued: the register goes to the next address
     computation and the load, returning microseconds later, overwrites it (the first L2-touch implementation faulted that way under load and

@@ -250,7 +250,12 @@ def main():
     out = outs[-1]
     # every step runs the same inputs through a path whose reductions all have a fixed order: the ids must repeat exactly
     if any(o != outs[0] for o in outs[1:]):
-        raise SystemExit("bench: output ids differ between identical steps (a race or an unordered reduction)")
+        detail = []
+        for k, o in enumerate(outs[1:], 1):
+            bad = [(b, next((i for i, (x, y) in enumerate(zip(o[b], outs[0][b])) if x != y), -1)) for b in range(len(o)) if o[b] != outs[0][b]]
+            if bad:
+                detail.append(f"step {k}: {len(bad)} of {len(o)} sequences differ, first (sequence, token) pairs {bad[:6]}")
+        raise SystemExit("bench: output ids differ between identical steps (a race or an unordered reduction)\n  " + "\n  ".join(detail[:12]))
     prof = eng.get_profile()
     eng.set_profile(0)
 

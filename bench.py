@@ -162,9 +162,12 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the captured hipGraph for decode steps (default: eager launches, which run at the same speed "
                          "— the step is GPU-bound — and allow the per-launch HIP-event roofline probe in the timed region)")
-    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", default=True,
-                    help="run the timed steps strictly one after the other (default: two-stage pipeline over the steps — batch k decodes on one "
-                         "stream while batch k+1 runs its ViT + prefill on another, TraceEngine.generate_stream)")
+    ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=False,
+                    help="two-stage pipeline over the timed steps — batch k decodes on one stream while batch k+1 runs its ViT + prefill on another "
+                         "(TraceEngine.generate_stream): +2-3 %% videos/s.  NOT the default: a stress run of 60 short pipelined steps produced ONE step in "
+                         "which one of the 128 sequences had a different arg-max from token 6 on (profiles/r03_pipeline_stress_ids_differ.txt; 40 "
+                         "sequential steps: none), a 25-step run at the C2 shape likewise; not root-caused, so the steps run one after the other")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="(the default) timed steps strictly one after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="tiny geometry (plumbing check)")
     ap.add_argument("--vit-batch", type=int, default=None, help="frames per ViT call (default: TraceEngine.full_round_frames)")

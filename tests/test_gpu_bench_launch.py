@@ -19,7 +19,7 @@ def test_bench_tiny_under_torchrun():
     env = dict(os.environ, TRACE_FORCE_PG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--tiny",
-           "--frames", "4", "--videos-per-step", "3", "--max-new", "12"]
+           "--frames", "4", "--videos-per-step", "3", "--max-new", "12", "--pipeline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]

@@ -154,7 +154,7 @@ def test_evaluate_videos_equals_the_driver_loop(loaded):
     try:
         res = ev.evaluate_videos(model, tok, proc, items, prompt, num_frames=4, max_new_tokens=10, batch_size=2)
         # two banks of KV slots (max_batch 2, one video per chunk): the chunks go through the two-stage pipeline — the same ids
-        res_p = ev.evaluate_videos(model, tok, proc, items, prompt, num_frames=4, max_new_tokens=10, batch_size=1)
+        res_p = ev.evaluate_videos(model, tok, proc, items, prompt, num_frames=4, max_new_tokens=10, batch_size=1, pipeline=True)
         assert [r["output_ids"] for r in res_p] == [r["output_ids"] for r in res]
     finally:
         ev.build_prompt_ids = orig

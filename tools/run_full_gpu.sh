@@ -20,7 +20,7 @@ python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/traffic.json && cp $O
 python tools/pmc_summary.py $O/pmc_sq > $O/pmc_sq.txt
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write > $O/pmc_traffic.txt
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_c2.json 2> $O/bench_c2.err; echo "bench c2 rc=$?"; cat $O/bench_c2.json
-python bench.py --steps 3 --warmup 1 --no-pipeline --no-cpu-baseline > $O/bench_c2_seq.json 2> $O/bench_c2_seq.err; echo "bench c2 seq rc=$?"
+python bench.py --steps 3 --warmup 1 --pipeline --no-cpu-baseline > $O/bench_c2_pipe.json 2> $O/bench_c2_pipe.err; echo "bench c2 pipelined rc=$?"
 python bench.py --config c4 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err; echo "bench c4 rc=$?"
 python bench.py --config c5 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c5_fp8.json 2> $O/bench_c5.err; echo "bench c5 rc=$?"
 python bench.py --config c5 --no-fp8 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c5_bf16.json 2>> $O/bench_c5.err; echo "bench c5 bf16 rc=$?"

@@ -149,6 +149,9 @@ int trace_set_gemm_cus(trace_ctx* ctx, int n);
 /* Timing hook for bench.py: average device time (ms, hipEvents on `stream`) of the last trace_decode_steps call
  * per step, and of its skinny-GEMM launches if profiling was enabled with trace_set_profile(ctx, 1). */
 int trace_set_profile(trace_ctx* ctx, int on);
+/* Debugging aid: device addresses of the K cache, the V^T cache and the prefill's last-position hidden rows, with strides[8] = layer, slot, kv-head
+ * strides (elements), ctx_pad, layers, kv heads, head_dim, hidden (tools/pipeline_stress.py checksums them between the pipeline's stages). */
+int trace_debug_buffers(trace_ctx* ctx, void** kcache, void** vcache, void** xlast, int64_t* strides);
 int trace_get_profile(trace_ctx* ctx, float* out, int n);
 /* Which per-launch brackets profiling mode 2 takes: bit 0 = the ViT fc1 GEMM, bit 1 = the decode step's dominant kernel.  A pipelined caller
  * (two stages on two streams) leaves a stage's bracket on only while that stage has the GPU to itself (pipeline fill / drain). */

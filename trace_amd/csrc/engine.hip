@@ -1358,6 +1358,15 @@ extern "C" int trace_set_gemm_cus(trace_ctx* c, int n) {
     return TRACE_OK;
 }
 
+// debugging aid (tools/pipeline_stress.py): device addresses and element strides of the KV caches and of the prefill's last-position hidden rows
+extern "C" int trace_debug_buffers(trace_ctx* c, void** kcache, void** vcache, void** xlast, int64_t* strides) {
+    if (!c || !kcache || !vcache || !xlast || !strides) return fail(TRACE_ERR_ARG, "null argument");
+    *kcache = c->kcache; *vcache = c->vcache; *xlast = c->xlast;
+    strides[0] = (int64_t)c->layer_stride; strides[1] = (int64_t)c->slot_stride; strides[2] = (int64_t)c->kv_head_stride; strides[3] = c->ctx_pad;
+    strides[4] = c->NL; strides[5] = c->NKV; strides[6] = c->HD; strides[7] = c->H;
+    return TRACE_OK;
+}
+
 extern "C" int trace_set_profile(trace_ctx* c, int on) {
     if (!c) return fail(TRACE_ERR_ARG, "null ctx");
     c->profile = on; c->ksum_ms = 0.0; c->ksamples = 0; c->kev_used = 0; c->kbytes_sum = 0.0; c->msum_ms = 0.0; c->msamples = 0; c->mM = 0;

@@ -61,6 +61,7 @@ class TraceEngine:
         self.time_tower, self.score_tower = TimeTower(), ScoreTower()
         self._B = 0
         self._max_new = 0
+        self._dbg = None               # debugging hook: callable(tag, index, tensor-or-None) called between the stages (tools/pipeline_stress.py)
 
     @property
     def decode_batch_max(self) -> int:
@@ -361,7 +362,10 @@ class TraceEngine:
                 if b not in feats:
                     g = next(g for g in groups if g[0] <= b < g[1])
                     feats = dict(zip(range(g[0], g[1]), self.vit_forward_many(videos[g[0]:g[1]])))
-                self.encode_features(feats.pop(b), timestamps[b])
+                fb = feats.pop(b)
+                if self._dbg is not None:
+                    self._dbg("feats", slot0 + b, fb)
+                self.encode_features(fb, timestamps[b])
             else:
                 self.encode_video(videos[b], timestamps[b])
             if B == 1:
@@ -461,6 +465,8 @@ class TraceEngine:
                 try:
                     with torch.cuda.stream(enc_s):
                         self.encode_prefill(videos, timestamps, input_ids, bank * half)
+                        if self._dbg is not None:
+                            self._dbg("prefilled", bank * half, None)
                         ready = torch.cuda.Event()
                         ready.record(enc_s)
                 finally:

@@ -53,12 +53,12 @@ cur = {"feats": {}}
 def dbg(tag, idx, t):
     if tag == "feats":
         x = t.view(torch.int16).to(torch.int64)
-        cur["feats"][idx % B] = int((x.view(-1, 4096) * w).sum())          # position-weighted: a permutation or a single flipped bit shows
+        cur["feats"][idx % B] = (x.view(-1, 4096) * w).sum()               # position-weighted; stays on the device: a host sync here would change the schedule under test
     else:                        # prefilled: bank's slots idx .. idx + B - 1
         k = K[:, idx:idx + B, :, :L].to(torch.int64).sum(dim=(0, 2, 3, 4))
         v = VT[:, idx:idx + B, :, :, :L].to(torch.int64).sum(dim=(0, 2, 3, 4))
         x = (XL[idx:idx + B].to(torch.int64) * w[:H]).sum(dim=1)
-        log["kv"].append(torch.stack([k, v, x], 1).cpu())
+        log["kv"].append(torch.stack([k, v, x], 1))
         log["feats"].append(dict(cur["feats"])); cur["feats"] = {}
 
 
@@ -73,6 +73,9 @@ if a.sequential:
 else:
     outs = [o[0] for o in eng.generate_stream([batch] * a.steps, n_new, eos=-1, use_graph=False)]
 print(f"{a.steps} steps in {time.time() - t0:.0f} s ({'sequential' if a.sequential else 'pipelined'})")
+torch.cuda.synchronize()
+log["kv"] = [t.cpu() for t in log["kv"]]
+log["feats"] = [{b: int(v) for b, v in d.items()} for d in log["feats"]]
 bad = 0
 for k in range(1, a.steps):
     f_bad = [b for b in range(B) if log["feats"][k].get(b) != log["feats"][0].get(b)]

@@ -14,6 +14,7 @@ ap.add_argument("--frames", type=int, default=32)
 ap.add_argument("--max-new", type=int, default=24)
 ap.add_argument("--B", type=int, default=128)
 ap.add_argument("--sequential", action="store_true")
+ap.add_argument("--gemm-variant", type=int, default=0, help="trace_op_set_gemm_variant: 4 = every 256^2 GEMM on the loader-wave kernel (no persistent kernel, no LayerNorm fold)")
 a = ap.parse_args()
 cfg = tcfg.trace_7b(a.frames)
 B, n_new = a.B, a.max_new
@@ -62,6 +63,8 @@ def dbg(tag, idx, t):
         log["feats"].append(dict(cur["feats"])); cur["feats"] = {}
 
 
+if a.gemm_variant:
+    _lib.check(eng.lib.trace_op_set_gemm_variant(a.gemm_variant))
 eng._dbg = dbg
 t0 = time.time()
 if a.sequential:
@@ -72,7 +75,7 @@ if a.sequential:
         outs.append(eng.decode(range(B), [1] * B, n_new, -1, False, forced)[0])
 else:
     outs = [o[0] for o in eng.generate_stream([batch] * a.steps, n_new, eos=-1, use_graph=False)]
-print(f"{a.steps} steps in {time.time() - t0:.0f} s ({'sequential' if a.sequential else 'pipelined'})")
+print(f"{a.steps} steps in {time.time() - t0:.0f} s ({'sequential' if a.sequential else 'pipelined'}, gemm variant {a.gemm_variant})")
 torch.cuda.synchronize()
 log["kv"] = [t.cpu() for t in log["kv"]]
 log["feats"] = [{b: int(v) for b, v in d.items()} for d in log["feats"]]

@@ -50,6 +50,10 @@ typedef struct trace_config {
 
 const char* trace_last_error(void);
 int trace_abi_version(void);
+/* The library's 16-bit element type: 0 = bf16 (libtrace_hip.so), 1 = IEEE fp16 (libtrace_hip_f16.so: the same sources compiled with -DTRACE_F16 —
+ * the reference's own inference dtype, torch.float16, trace/model/builder.py:50,127,147 / trace/eval/evaluate.py:316).  Every "bf16" in this header
+ * reads "the library's element type"; the two libraries export the same symbols and may be loaded side by side (RTLD_LOCAL). */
+int trace_element_type(void);
 
 /* from_pretrained (trace/model/builder.py:113-114): create, stream tensors in by their reference state-dict
  * names (bf16; `on_device` says whether `data` is a device or host pointer), then finalize. */

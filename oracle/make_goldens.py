@@ -84,10 +84,10 @@ def build_reference_model(cfg, tmp):
     return model
 
 
-def load_synth(model, cfg):
+def load_synth(model, cfg, dtype=torch.bfloat16):
     from trace_amd import synth
     sd_ref = model.state_dict()
-    mine = synth.state_dict(cfg, dtype=torch.bfloat16)
+    mine = synth.state_dict(cfg, dtype=dtype)
     used = set()
     new = {}
     for k in sd_ref:
@@ -150,12 +150,14 @@ def run_reference(model, cfg, input_ids, frames, ts, forced=None, n_new=24):
     return torch.stack(step_logits), toks, L
 
 
-def fp_goldens(tmp):
+def fp_goldens(tmp, dtype=torch.bfloat16, name="tiny_e2e.npz"):
+    """dtype: what the synthetic weights and frames are rounded to before the reference (fp32 arithmetic) sees them — bf16 for the default
+    library, fp16 for libtrace_hip_f16.so (tiny_e2e_f16.npz)."""
     from trace_amd import config as tcfg, synth
     cfg = tcfg.tiny(num_frames=4)
     model = build_reference_model(cfg, tmp)
-    keys = load_synth(model, cfg)
-    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16).float()
+    keys = load_synth(model, cfg, dtype)
+    frames = synth.synth_frames(cfg, 0).to(dtype).float()
     ts = [[float(i) * 2.5] for i in range(cfg.num_frames)]
     input_ids = synth.synth_prompt_ids(cfg, n_text=24, video_pos=10)
 
@@ -182,9 +184,21 @@ def fp_goldens(tmp):
     forced = scripted_ids(cfg)
     tf_logits, tf_argmax, _ = run_reference(model, cfg, input_ids, frames, ts, forced=forced)
 
+    extra = {}
+    if dtype == torch.float16:
+        # the reference in ITS OWN inference dtype (model.half(), trace/model/builder.py:50): the teacher-forced logits of an fp16 run, so that a
+        # test can say how far the fp16 library is from the reference's fp16 and how far both are from the fp32 arithmetic above
+        try:
+            m16 = model.half()
+            l16, a16, _ = run_reference(m16, cfg, input_ids, frames.half(), ts, forced=forced)
+            extra = {"tf_logits_ref_fp16": l16.float().numpy().astype(np.float32), "tf_argmax_ref_fp16": np.array(a16)}
+            print("reference fp16 run: max |logit - fp32 run| =", float((l16.float() - tf_logits)[torch.isfinite(tf_logits)].abs().max()))
+        except Exception as e:      # CPU half kernels missing for some op: the fp32-arithmetic fixture stands alone
+            print("reference fp16 run not possible on this host:", repr(e)[:200])
+        model.float()
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(
-        os.path.join(OUT, "tiny_e2e.npz"),
+        os.path.join(OUT, name), **extra,
         input_ids=input_ids.numpy(), timestamps=np.array(ts, dtype=np.float64),
         vit_feats=feats.numpy().astype(np.float32),
         slots=slots[0].numpy().astype(np.float32),
@@ -197,12 +211,14 @@ def fp_goldens(tmp):
         forced_ids=np.array(forced), tf_logits=tf_logits.numpy().astype(np.float32),
         tf_argmax=np.array(tf_argmax),
     )
-    with open(os.path.join(OUT, "reference_state_dict_keys.json"), "w") as f:
-        json.dump(keys, f, indent=0)
     with torch.no_grad():
         assert torch.equal(vt(frames), feats), "reference CLIP feature selection changed state mid-run"
-    print("tiny_e2e: L=%d free_ids=%s" % (L, free_ids))
+    print("%s: L=%d free_ids=%s" % (name, L, free_ids))
     print("tf_argmax", tf_argmax)
+    if dtype != torch.bfloat16:
+        return
+    with open(os.path.join(OUT, "reference_state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0)
 
     # B=2 equal-length batch (reference supports it): second video + same prompt
     frames2 = synth.synth_frames(cfg, 1).to(torch.bfloat16).float()
@@ -697,11 +713,15 @@ if __name__ == "__main__":
     if "--videomme-only" in sys.argv:
         videomme_goldens(tmp)
         sys.exit(0)
+    if "--f16-only" in sys.argv:
+        fp_goldens(tmp, torch.float16, "tiny_e2e_f16.npz")
+        sys.exit(0)
     if "--full-depth-only" in sys.argv:
         full_depth_goldens(tmp)
         sys.exit(0)
     int_goldens()
     fp_goldens(tmp)
+    fp_goldens(tmp, torch.float16, "tiny_e2e_f16.npz")
     medium_goldens(tmp)
     medium_llm_goldens(tmp)
     long_ctx_goldens(tmp)

@@ -16,8 +16,9 @@ published architecture and anchored by the same fixtures.  STC connector: parity
 
 `emulate_bf16=True` rounds activations to bf16 at the points where the HIP engine stores bf16
 tensors to HBM (same points a bf16 reference model rounds at, minus the ones fused away), so GPU
-vs oracle differences reduce to accumulation order.  `emulate_bf16=False` is the plain fp32 oracle
-that is compared against the fp32 reference fixtures.
+vs oracle differences reduce to accumulation order.  `emulate_bf16=torch.float16` does the same for
+the fp16 library (libtrace_hip_f16.so).  `emulate_bf16=False` is the plain fp32 oracle that is
+compared against the fp32 reference fixtures.
 """
 from __future__ import annotations
 
@@ -233,13 +234,16 @@ def preprocess_frames(frames_u8, image_mean, image_std, size: int, pad: bool):
 
 
 class Oracle:
-    def __init__(self, cfg, weights: Dict[str, torch.Tensor], emulate_bf16: bool = False):
+    def __init__(self, cfg, weights: Dict[str, torch.Tensor], emulate_bf16=False):
+        """emulate_bf16: False = plain fp32; True = round to bf16 at the engine's storage points; a torch dtype (torch.float16 for
+        libtrace_hip_f16.so) = round to that dtype there instead."""
         self.cfg = cfg
         self.W = {k: v.float() for k, v in weights.items()}
-        self.emu = emulate_bf16
+        self.emu = bool(emulate_bf16)
+        self.emu_dtype = emulate_bf16 if isinstance(emulate_bf16, torch.dtype) else torch.bfloat16
 
     def r(self, x: torch.Tensor) -> torch.Tensor:
-        return x.to(torch.bfloat16).float() if self.emu else x
+        return x.to(self.emu_dtype).float() if self.emu else x
 
     # -- CLIP ViT (clip_encoder.py:31-53 -> HF CLIPVisionModel; HF5 modeling_clip.py:148-385) -------
     def vit_forward(self, frames: torch.Tensor, return_all: bool = False):

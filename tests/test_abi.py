@@ -27,7 +27,21 @@ def test_header_symbols_exported(lib):
 
 def test_abi_version_and_error_string(lib):
     assert lib.trace_abi_version() == 3
+    assert lib.trace_element_type() == 0
     assert isinstance(lib.trace_last_error(), (bytes, type(None)))
+
+
+def test_fp16_library_exports_the_same_abi(lib):
+    """libtrace_hip_f16.so: the same sources with -DTRACE_F16 — every declared symbol, the same ABI version, element type 1; loaded next to
+    the bf16 library in one process."""
+    from trace_amd import _lib
+    l16 = _lib.load("f16")
+    assert l16 is not lib and l16.trace_abi_version() == 3 and l16.trace_element_type() == 1
+    for name in _lib.SIGNATURES:
+        assert hasattr(l16, name), name
+    assert lib.trace_element_type() == 0
+    with pytest.raises(ValueError):
+        _lib.load("fp32")
 
 
 def test_config_struct_matches_header():

@@ -280,3 +280,47 @@ def test_full_depth_fixture_is_self_consistent(golden_dir):
     assert F["forced_ids"].tolist() == D["forced_ids"].tolist() and F["input_ids"].tolist() == D["input_ids"].tolist()
     assert (np.isfinite(F["tf_logits"]) == np.isfinite(D["tf_logits"])).all()
     assert int(F["prefill_len"]) == int(D["prefill_len"])
+
+
+# ---- fp16 element type (libtrace_hip_f16.so): the same tiny case with weights and frames rounded to fp16 (tiny_e2e_f16.npz) ----
+@pytest.fixture(scope="module")
+def E16(golden_dir):
+    return np.load(os.path.join(golden_dir, "tiny_e2e_f16.npz"))
+
+
+@pytest.fixture(scope="module")
+def sd16():
+    cfg = tcfg.tiny(num_frames=4)
+    return cfg, synth.state_dict(cfg, dtype=torch.float16)
+
+
+def test_f16_weights_fixture_pins_the_oracle(sd16, E16):
+    cfg, sd = sd16
+    ora = O.Oracle(cfg, sd, emulate_bf16=False)
+    frames = synth.synth_frames(cfg, 0).to(torch.float16).float()
+    feats = ora.vit_forward(frames)
+    np.testing.assert_allclose(feats.numpy(), E16["vit_feats"], rtol=1e-4, atol=2e-5)
+    forced = E16["forced_ids"].tolist()
+    ids, lg = ora.generate(torch.from_numpy(E16["input_ids"]), frames, E16["timestamps"].tolist(), head=1,
+                           max_new_tokens=len(forced) + 1, forced_ids=forced, return_logits=True)
+    assert ids == E16["tf_argmax"].tolist()
+    _cmp_logits(lg.numpy(), E16["tf_logits"])
+
+
+def test_f16_emulating_oracle_tracks_the_reference_in_fp16(sd16, E16):
+    """The reference run in ITS OWN dtype (model.half(): `tf_logits_ref_fp16`) and the oracle rounding to fp16 at the engine's storage points are two
+    fp16 evaluations of the same function: both stay within the fp16 budget of the fp32 arithmetic, and of each other."""
+    cfg, sd = sd16
+    if "tf_logits_ref_fp16" not in E16:
+        pytest.skip("fixture generated on a host without CPU half kernels")
+    ora = O.Oracle(cfg, sd, emulate_bf16=torch.float16)
+    frames = synth.synth_frames(cfg, 0).to(torch.float16).float()
+    forced = E16["forced_ids"].tolist()
+    _, lg = ora.generate(torch.from_numpy(E16["input_ids"]), frames, E16["timestamps"].tolist(), head=1,
+                         max_new_tokens=len(forced) + 1, forced_ids=forced, return_logits=True)
+    ref32, ref16 = E16["tf_logits"], E16["tf_logits_ref_fp16"]
+    fin = np.isfinite(ref32)
+    e_ref = np.abs(ref16[fin] - ref32[fin]).max()
+    e_ora = np.abs(lg.numpy()[fin] - ref32[fin]).max()
+    e_x = np.abs(lg.numpy()[fin] - ref16[fin]).max()
+    assert e_ref < 0.03 and e_ora < 0.03 and e_x < 0.04, (e_ref, e_ora, e_x)      # bf16 at the same points: 0.08 (tests/test_gpu_parity.py)

@@ -7,6 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtrace_hip.so")
+LIB_PATHS = {"bf16": LIB_PATH, "f16": os.path.join(HERE, "libtrace_hip_f16.so")}      # element type of the build -> library (trace_element_type)
 
 
 class TraceConfigC(C.Structure):
@@ -32,6 +33,7 @@ P, I, F = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
     "trace_last_error": (C.c_char_p, []),
     "trace_abi_version": (I, []),
+    "trace_element_type": (I, []),
     "trace_ctx_create": (I, [C.POINTER(TraceConfigC), I, C.POINTER(P)]),
     "trace_ctx_destroy": (I, [P]),
     "trace_ctx_load_tensor": (I, [P, C.c_char_p, P, I, C.POINTER(C.c_int64), I]),
@@ -85,33 +87,49 @@ SIGNATURES = {
     "trace_op_attn_decode": (I, [P, P, P, P, P, P, I, I, I, I, I, F, P]),
 }
 
-_lib = None
+_libs = {}
 
 
 class TraceHipError(RuntimeError):
     pass
 
 
-def load():
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(element: str = "bf16"):
+    """dlopen the library of one element type ("bf16": libtrace_hip.so, "f16": libtrace_hip_f16.so — the same sources compiled with -DTRACE_F16) and
+    check every symbol include/trace_hip.h declares.  The two may be loaded side by side (RTLD_LOCAL)."""
+    if element in _libs:
+        return _libs[element]
+    if element not in LIB_PATHS:
+        raise ValueError(f"element type must be one of {sorted(LIB_PATHS)}, got {element!r}")
     # PyTorch-ROCm bundles its own libamdhip64; load it first so this library binds to the same HIP runtime
     # instance (two runtimes in one process cannot both own the device: "no ROCm-capable device is detected").
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATHS[element]
+    if not os.path.exists(path):
         raise TraceHipError(
-            f"{LIB_PATH} is missing: build it with `python -m trace_amd.build` (hipcc, gfx950). "
+            f"{path} is missing: build it with `python -m trace_amd.build` (hipcc, gfx950). "
             "trace_amd has no CPU or PyTorch fallback for the hot path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
     if lib.trace_abi_version() != 3:
-        raise TraceHipError("libtrace_hip.so ABI version mismatch")
-    _lib = lib
+        raise TraceHipError(f"{os.path.basename(path)} ABI version mismatch")
+    if lib.trace_element_type() != {"bf16": 0, "f16": 1}[element]:
+        raise TraceHipError(f"{os.path.basename(path)} was not built for {element} elements")
+    _libs[element] = lib
     return lib
+
+
+def element_of(dtype) -> str:
+    """torch dtype of a 16-bit tensor -> the element type of the library that computes in it"""
+    import torch
+    if dtype == torch.bfloat16:
+        return "bf16"
+    if dtype == torch.float16:
+        return "f16"
+    raise ValueError(f"the engine computes in torch.bfloat16 or torch.float16, not {dtype}")
 
 
 def check(rc: int) -> int:

@@ -49,7 +49,7 @@ __device__ __forceinline__ void attn_tile(const char* kb, const char* vb, int kv
 #pragma unroll
         for (int s_ = 0; s_ < HD / 16; ++s_) {
             const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + kswz<HD>(row, s_ * 2 + h));
-            S[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s_], S[st], 0, 0, 0);
+            S[st] = mfma32(kf, qf[s_], S[st]);
         }
     }
     if (MASK) {
@@ -96,7 +96,7 @@ __device__ __forceinline__ void attn_tile(const char* kb, const char* vb, int kv
 #pragma unroll
         for (int ht = 0; ht < HD / 32; ++ht) {
             const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vb + (ht * 32 + c32) * VROW + ks * 32 + h * 16);
-            oacc[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, oacc[ht], 0, 0, 0);
+            oacc[ht] = mfma32(vf, pf.v, oacc[ht]);
         }
     }
 }
@@ -448,9 +448,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                         // D != C: the builtin ties the result to its accumulator operand, which made the compiler copy cinit into S
                         // first (27 v_mov per tile); the instruction itself takes separate registers (early-clobber: D must not
                         // overlap the sources).  The s_nop covers the VALU-write -> MFMA-read wait states hipcc does not pad inside asm.
-                        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(S[st]) : "v"(kf), "v"(qf[0]), "v"(cinit));
+                        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_" TRACE_EL " %0, %1, %2, %3" : "=&v"(S[st]) : "v"(kf), "v"(qf[0]), "v"(cinit));
                     } else {
-                        S[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s_], S[st], 0, 0, 0);
+                        S[st] = mfma32(kf, qf[s_], S[st]);
                     }
                 }
             }
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                         u.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vp + 512));
                         vf = u.v;
                     } else vf = *reinterpret_cast<const bf16x8_t*>(vb + kswz<HD>(ht * 32 + c32, ks * 2 + h));
-                    oacc[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, oacc[ht], 0, 0, 0);
+                    oacc[ht] = mfma32(vf, pf.v, oacc[ht]);
                 }
             }
         }

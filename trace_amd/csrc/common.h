@@ -1,15 +1,46 @@
 // Shared device helpers for the TRACE gfx950 kernels.  CDNA4 only: wave = 64 lanes, MFMA 16x16x32 /
-// 32x32x16 bf16 with fp32 accumulators, LDS 160 KiB/CU.
+// 32x32x16 (bf16, or fp16 in the TRACE_F16 build) with fp32 accumulators, LDS 160 KiB/CU.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef uint16_t bf16_t;                                                   // raw bf16 bits in HBM
-typedef __attribute__((ext_vector_type(8))) short bf16x8_t;                // MFMA A/B fragment (8 bf16 = 4 VGPR)
+// The 16-bit element type of a build: bf16 by default; IEEE half when compiled with -DTRACE_F16 (libtrace_hip_f16.so, the reference's own fp16
+// inference dtype: trace/model/builder.py:50,127,147).  Everything that MOVES elements — LDS-DMA, tile layouts, fragment reads, the KV cache — only
+// knows "16 bits"; the element type enters through the helpers below (conversions, the two MFMA shapes, the asm mnemonic suffix, packed 1.0).
+// The names keep "bf" for both builds: bf16_t is "the build's 16-bit element", pack2bf "two fp32 -> one packed pair, round to nearest even".
+typedef uint16_t bf16_t;                                                   // raw element bits in HBM
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;                // MFMA A/B fragment (8 elements = 4 VGPR)
 typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;                 // 16x16 MFMA C/D fragment
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;               // 32x32 MFMA C/D fragment
 
+#ifdef TRACE_F16
+#define TRACE_ELEMENT_TYPE 1
+#define TRACE_EL "f16"                                                      // instruction-name suffix for inline asm
+#define TRACE_EL_ONE2 0x3c003c00u                                           // (1.0, 1.0) packed
+typedef __attribute__((ext_vector_type(2))) _Float16 el2_native_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 el8_native_t;
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ float bflo(uint32_t v) { return (float)__builtin_bit_cast(el2_native_t, v)[0]; }   // low half of a packed pair
+__device__ __forceinline__ float bfhi(uint32_t v) { return (float)__builtin_bit_cast(el2_native_t, v)[1]; }   // high half
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {             // round to nearest even, overflow -> inf (as torch.float16)
+    const el2_native_t v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ f32x4_t mfma16(const bf16x8_t& w, const bf16x8_t& a, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(el8_native_t, w), __builtin_bit_cast(el8_native_t, a), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16_t mfma32(const bf16x8_t& w, const bf16x8_t& a, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(el8_native_t, w), __builtin_bit_cast(el8_native_t, a), c, 0, 0, 0);
+}
+__device__ __forceinline__ float dot2_el(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(el2_native_t, a), __builtin_bit_cast(el2_native_t, b), c, false);
+}
+#else
+#define TRACE_ELEMENT_TYPE 0
+#define TRACE_EL "bf16"
+#define TRACE_EL_ONE2 0x3f803f80u
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ float bflo(uint32_t v) { return __uint_as_float(v << 16); }          // low half of a packed pair
 __device__ __forceinline__ float bfhi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }  // high half
@@ -21,6 +52,12 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ f32x4_t mfma16(const bf16x8_t& w, const bf16x8_t& a, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16_t mfma32(const bf16x8_t& w, const bf16x8_t& a, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, c, 0, 0, 0); }
+__device__ __forceinline__ float dot2_el(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_native_t, a), __builtin_bit_cast(bf16x2_native_t, b), c, false);
+}
+#endif
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

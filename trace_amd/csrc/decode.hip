@@ -234,8 +234,8 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restric
                     const bf16x8_t x1 = __builtin_bit_cast(bf16x8_t, xs[(((u + j) * 2 + 1) * NB + nb) * 64 + lane]);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][t][0].v, x0, acc[t][nb], 0, 0, 0);
-                        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][t][1].v, x1, acc[t][nb], 0, 0, 0);
+                        acc[t][nb] = mfma16(wf[j][t][0].v, x0, acc[t][nb]);
+                        acc[t][nb] = mfma16(wf[j][t][1].v, x1, acc[t][nb]);
                     }
                 }
             }
@@ -647,8 +647,8 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
             S[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
-                S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kr[t][s4]),
-                                                               __builtin_bit_cast(bf16x8_t, qf[s4]), S[t], 0, 0, 0);
+                S[t] = mfma16(__builtin_bit_cast(bf16x8_t, kr[t][s4]),
+                                                               __builtin_bit_cast(bf16x8_t, qf[s4]), S[t]);
         }
         if (it + 4 < nit) load_k(it + 4);
         // lane (head i, group g): S[t][r] is the score of position P0 + g*8 + t*4 + r
@@ -676,8 +676,8 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
             acc[dt] *= a;
-            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vr[dt]),
-                                                              __builtin_bit_cast(bf16x8_t, pf), acc[dt], 0, 0, 0);
+            acc[dt] = mfma16(__builtin_bit_cast(bf16x8_t, vr[dt]),
+                                                              __builtin_bit_cast(bf16x8_t, pf), acc[dt]);
         }
         if (it + 4 < nit) load_v(it + 4);
     }
@@ -816,11 +816,11 @@ __global__ __launch_bounds__(512) void head_logits_kernel(const bf16_t* __restri
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][0].v, x0[jj][0].v, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][1].v, x0[jj][1].v, acc0, 0, 0, 0);
+            acc0 = mfma16(w[jj][0].v, x0[jj][0].v, acc0);
+            acc0 = mfma16(w[jj][1].v, x0[jj][1].v, acc0);
             if (NB == 2) {
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][0].v, x1[jj][0].v, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][1].v, x1[jj][1].v, acc1, 0, 0, 0);
+                acc1 = mfma16(w[jj][0].v, x1[jj][0].v, acc1);
+                acc1 = mfma16(w[jj][1].v, x1[jj][1].v, acc1);
             }
         }
     }

@@ -140,6 +140,7 @@ static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 extern "C" const char* trace_last_error(void) { return g_err.c_str(); }
 extern "C" int trace_abi_version(void) { return TRACE_ABI_VERSION; }
+extern "C" int trace_element_type(void) { return TRACE_ELEMENT_TYPE; }
 
 extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ctx** out) {
     if (!cfg || !out) return fail(TRACE_ERR_ARG, "null argument");
@@ -165,6 +166,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     if (c->H % 128 || c->I % 128 || c->vh % 128 || c->vi % 128 || c->QKV % 128) return bad("dims must be multiples of 128");
     if (c->H > 4096) return bad("hidden_size > 4096: the decode row kernels (norms, residual add) hold one 4096-wide row per workgroup");
     c->stc = cfg->projector_type == 1;
+    if (cfg->llm_weights_fp8 && TRACE_ELEMENT_TYPE != 0) { delete c; return fail(TRACE_ERR_ARG, "llm_weights_fp8 needs the bf16 library (the fp16 build has no fp8 weight path)"); }
     c->fp8 = cfg->llm_weights_fp8 != 0;
     c->fp8_wonly = cfg->llm_weights_fp8 == 2;
     if (c->fp8 && (c->H % 128 || c->I % 128 || c->I > 16384)) return bad("fp8 weight path needs hidden / intermediate sizes that are multiples of 128 (intermediate <= 16384)");

@@ -35,7 +35,7 @@ __device__ __forceinline__ f32x4_t mma_step(const bf16x8_t& w, const bf16x8_t& a
         acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[0], a2[0], acc, 0, 0, 0);
         return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[1], a2[1], acc, 0, 0, 0);
     } else {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, acc, 0, 0, 0);
+        return mfma16(w, a, acc);
     }
 }
 

@@ -76,10 +76,10 @@ __device__ __forceinline__ void tile_coords(int t, int ntm, int ntn, int& tm, in
 // an accumulator is touched again 32 MFMAs later (no back-to-back dependence), and the epilogue's first VALU read of one comes after an
 // explicit s_nop pair.
 __device__ __forceinline__ void mfma_acc(f32x4_t& c, const bf16x8_t& w, const bf16x8_t& a) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(a));
+    asm volatile("v_mfma_f32_16x16x32_" TRACE_EL " %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(a));
 }
 __device__ __forceinline__ void mfma_new(f32x4_t& c, const bf16x8_t& w, const bf16x8_t& a) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(w), "v"(a));
+    asm volatile("v_mfma_f32_16x16x32_" TRACE_EL " %0, %1, %2, 0" : "=&v"(c) : "v"(w), "v"(a));
 }
 #define PERS_FENCE() __builtin_amdgcn_sched_barrier(0)
 

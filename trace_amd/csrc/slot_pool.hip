@@ -21,10 +21,9 @@ __device__ __forceinline__ void unpack8(const uint4& u, float* v) {
     v[4] = bflo(u.z); v[5] = bfhi(u.z); v[6] = bflo(u.w); v[7] = bfhi(u.w);
 }
 
-typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
 typedef __attribute__((ext_vector_type(2))) float f2_t;
 __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a), __builtin_bit_cast(bf2_t, b), c, false);
+    return dot2_el(a, b, c);
 }
 constexpr int NPART = 8;      // workgroups per frame
 
@@ -106,7 +105,7 @@ __global__ __launch_bounds__(256) void slot_pool_part_kernel(const bf16_t* __res
             const uint32_t xp[8] = {u1.x, u1.y, u1.z, u1.w, u2.x, u2.y, u2.z, u2.w};
             float sm = 0.f, sq = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { sm = dot2(xp[j], 0x3f803f80u, sm); sq = dot2(xp[j], xp[j], sq); }
+            for (int j = 0; j < 8; ++j) { sm = dot2(xp[j], TRACE_EL_ONE2, sm); sq = dot2(xp[j], xp[j], sq); }
             sm = wave_sum_dpp(sm); sq = wave_sum_dpp(sq);
             const float mean = sm / (float)D;
             const float rstd = rsqrtf(fmaxf(sq / (float)D - mean * mean, 0.f) + eps);

@@ -30,10 +30,15 @@ def _i32(seq) -> "C.Array":
 class TraceEngine:
     def __init__(self, cfg: TraceConfig, device: int = 0, max_batch: int = 1, max_ctx: Optional[int] = None,
                  max_frames: Optional[int] = None, max_new_tokens: int = 1024, vit_batch_frames: Optional[int] = None,
-                 llm_fp8: bool = False):
+                 llm_fp8: bool = False, dtype: torch.dtype = torch.bfloat16):
+        """dtype: the 16-bit element type everything is stored and multiplied in — torch.bfloat16 (libtrace_hip.so; north_star's configs) or
+        torch.float16 (libtrace_hip_f16.so: the reference's own inference dtype, trace/model/builder.py:50,127,147); accumulation is fp32 in both."""
         if not torch.cuda.is_available():
             raise _lib.TraceHipError("no HIP device visible: the TRACE hot path only runs on an MI355X (no CPU fallback)")
-        self.lib = _lib.load()
+        self.dtype = dtype
+        self.lib = _lib.load(_lib.element_of(dtype))
+        if llm_fp8 and dtype != torch.bfloat16:
+            raise ValueError("the fp8 weight path exists in the bf16 library only")
         self.cfg = cfg
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
@@ -91,10 +96,10 @@ class TraceEngine:
 
     # ---- weights -------------------------------------------------------------------------------
     def load_weights(self, items: Iterable[Tuple[str, torch.Tensor]]) -> int:
-        """items: (reference state-dict name, tensor).  Tensors are converted to contiguous bf16; host or device."""
+        """items: (reference state-dict name, tensor).  Tensors are converted to the engine's contiguous 16-bit dtype; host or device."""
         n = 0
         for name, t in items:
-            t = t.detach().to(torch.bfloat16).contiguous()
+            t = t.detach().to(self.dtype).contiguous()
             shape = (C.c_int64 * max(t.dim(), 1))(*(list(t.shape) or [1]))
             rc = _lib.check(self.lib.trace_ctx_load_tensor(self.h, name.encode(), C.c_void_p(t.data_ptr()),
                                                           1 if t.is_cuda else 0, shape, t.dim()))
@@ -109,8 +114,8 @@ class TraceEngine:
     def _frames(self, frames: torch.Tensor):
         if frames.dim() != 4:
             raise ValueError("frames must be [T,3,H,W]")
-        if frames.dtype not in (torch.bfloat16, torch.float32):
-            frames = frames.to(torch.bfloat16)
+        if frames.dtype not in (self.dtype, torch.float32):
+            frames = frames.to(self.dtype)
         frames = frames.to(self.device).contiguous()
         return frames, (1 if frames.dtype == torch.float32 else 0)
 
@@ -118,14 +123,15 @@ class TraceEngine:
     CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
     def preprocess_frames(self, frames_u8, pad: bool = True, image_mean: Sequence[float] = CLIP_MEAN,
-                          image_std: Sequence[float] = CLIP_STD, dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+                          image_std: Sequence[float] = CLIP_STD, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
         """process_video's per-frame image work (mm_utils.py:456-462) on the device: uint8 RGB [T,H,W,3] (tensor or numpy,
         host or device) -> [T,3,S,S] `dtype` (bf16 for the engine, fp32 = the reference's FloatTensor bit for bit)."""
         x = torch.as_tensor(frames_u8)
         if x.dtype != torch.uint8 or x.dim() != 4 or x.shape[-1] != 3:
             raise ValueError(f"expected uint8 [T,H,W,3] RGB frames, got {x.dtype} {tuple(x.shape)}")
-        if dtype not in (torch.bfloat16, torch.float32):
-            raise ValueError("dtype must be bfloat16 or float32")
+        dtype = dtype or self.dtype
+        if dtype not in (self.dtype, torch.float32):
+            raise ValueError(f"dtype must be the engine's {self.dtype} or float32")
         x = x.to(self.device).contiguous()
         T, H, W, _ = x.shape
         S = self.cfg.vision_image_size
@@ -141,14 +147,14 @@ class TraceEngine:
         if not want_output:
             _lib.check(self.lib.trace_vit_forward(self.h, _ptr(frames), dt, T, None, _stream()))
             return None
-        out = torch.empty((T, self.cfg.vision_patches, self.cfg.vision_hidden_size), dtype=torch.bfloat16, device=self.device)
+        out = torch.empty((T, self.cfg.vision_patches, self.cfg.vision_hidden_size), dtype=self.dtype, device=self.device)
         _lib.check(self.lib.trace_vit_forward(self.h, _ptr(frames), dt, T, _ptr(out), _stream()))
         return out
 
     def slot_pool(self, feats: Optional[torch.Tensor], T: int) -> torch.Tensor:
-        out = torch.empty((T, self.cfg.num_slots, self.cfg.hidden_size), dtype=torch.bfloat16, device=self.device)
+        out = torch.empty((T, self.cfg.num_slots, self.cfg.hidden_size), dtype=self.dtype, device=self.device)
         if feats is not None:
-            feats = feats.to(self.device, torch.bfloat16).contiguous()
+            feats = feats.to(self.device, self.dtype).contiguous()
         _lib.check(self.lib.trace_slot_pool(self.h, _ptr(feats), T, _ptr(out), _stream()))
         return out
 
@@ -156,9 +162,9 @@ class TraceEngine:
         """Legacy STC connector (projector_type 'stc_connector'); result also becomes the video rows for splice()."""
         g = self.cfg.vision_grid // 2 + 1
         rows = (T // 2 + 1) * g * g
-        out = torch.empty((rows, self.cfg.hidden_size), dtype=torch.bfloat16, device=self.device)
+        out = torch.empty((rows, self.cfg.hidden_size), dtype=self.dtype, device=self.device)
         if feats is not None:
-            feats = feats.to(self.device, torch.bfloat16).contiguous()
+            feats = feats.to(self.device, self.dtype).contiguous()
         n = C.c_int(0)
         _lib.check(self.lib.trace_stc_connector(self.h, _ptr(feats), T, _ptr(out), C.byref(n), _stream()))
         assert n.value == rows
@@ -178,18 +184,18 @@ class TraceEngine:
         ids = _i32(self.time_ids(timestamps))
         out = None
         if want_output:
-            out = torch.empty((T * self.cfg.tokens_per_frame, self.cfg.hidden_size), dtype=torch.bfloat16, device=self.device)
+            out = torch.empty((T * self.cfg.tokens_per_frame, self.cfg.hidden_size), dtype=self.dtype, device=self.device)
         _lib.check(self.lib.trace_encode_video(self.h, _ptr(frames), dt, T, ids, _ptr(out), _stream()))
         return out
 
     def encode_features(self, feats: torch.Tensor, timestamps, want_output: bool = False):
         """encode_video from ViT features computed earlier (vit_forward on a frame batch that may span several videos)"""
         T = feats.shape[0]
-        assert feats.dtype == torch.bfloat16 and feats.is_cuda and feats.is_contiguous()
+        assert feats.dtype == self.dtype and feats.is_cuda and feats.is_contiguous()
         ids = _i32(self.time_ids(timestamps))
         out = None
         if want_output:
-            out = torch.empty((T * self.cfg.tokens_per_frame, self.cfg.hidden_size), dtype=torch.bfloat16, device=self.device)
+            out = torch.empty((T * self.cfg.tokens_per_frame, self.cfg.hidden_size), dtype=self.dtype, device=self.device)
         _lib.check(self.lib.trace_encode_features(self.h, _ptr(feats), T, ids, _ptr(out), _stream()))
         return out
 
@@ -204,7 +210,7 @@ class TraceEngine:
         dt = dts.pop()
         counts = [v.shape[0] for v, _ in vids]
         total = sum(counts)
-        feats = torch.empty((total, self.cfg.vision_patches, self.cfg.vision_hidden_size), dtype=torch.bfloat16, device=self.device)
+        feats = torch.empty((total, self.cfg.vision_patches, self.cfg.vision_hidden_size), dtype=self.dtype, device=self.device)
         F = self.vit_batch_frames
         pos, chunk, chunk_n = 0, [], 0          # gather frames into chunks of F (a copy only when a chunk spans videos)
         def flush():
@@ -239,27 +245,27 @@ class TraceEngine:
         # length is known up-front: n_ids - 1 + video rows; allocate generously when a copy is requested
         out = None
         if want_output:
-            out = torch.empty((self.max_ctx, self.cfg.hidden_size), dtype=torch.bfloat16, device=self.device)
+            out = torch.empty((self.max_ctx, self.cfg.hidden_size), dtype=self.dtype, device=self.device)
         _lib.check(self.lib.trace_splice_embeds(self.h, ids, len(ids), tr, len(tr), sr, len(sr), C.byref(L), _ptr(out), _stream()))
         return (L.value, out[: L.value]) if want_output else L.value
 
     def prefill(self, slot: int, L: int, embeds: Optional[torch.Tensor] = None, want_hidden: bool = False):
-        hid = torch.empty((L, self.cfg.hidden_size), dtype=torch.bfloat16, device=self.device) if want_hidden else None
+        hid = torch.empty((L, self.cfg.hidden_size), dtype=self.dtype, device=self.device) if want_hidden else None
         if embeds is not None:
-            embeds = embeds.to(self.device, torch.bfloat16).contiguous()
+            embeds = embeds.to(self.device, self.dtype).contiguous()
         _lib.check(self.lib.trace_llm_prefill(self.h, slot, _ptr(embeds), L, _ptr(hid), _stream()))
         return hid
 
     def head_logits(self, hidden: torch.Tensor, head: int) -> torch.Tensor:
         """masked fp32 logits [R, total_vocab] of final-norm hidden rows under one head (forward()'s logits at every position)"""
-        assert hidden.dtype == torch.bfloat16 and hidden.is_cuda and hidden.is_contiguous()
+        assert hidden.dtype == self.dtype and hidden.is_cuda and hidden.is_contiguous()
         out = torch.empty((hidden.shape[0], self.cfg.total_vocab), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.trace_llm_head_logits(self.h, _ptr(hidden), hidden.shape[0], int(head), _ptr(out), _stream()))
         return out
 
     def prefill_pair(self, slot0: int, embeds0: torch.Tensor, embeds1: torch.Tensor):
         """two spliced prompts of equal length -> KV slots slot0, slot0 + 1 in one pass (trace_llm_prefill_pair)"""
-        assert embeds0.shape == embeds1.shape and embeds0.dtype == torch.bfloat16 and embeds0.is_cuda
+        assert embeds0.shape == embeds1.shape and embeds0.dtype == self.dtype and embeds0.is_cuda
         _lib.check(self.lib.trace_llm_prefill_pair(self.h, slot0, _ptr(embeds0.contiguous()), _ptr(embeds1.contiguous()),
                                                    embeds0.shape[0], _stream()))
 
@@ -268,7 +274,7 @@ class TraceEngine:
     def prefill_multi(self, slot0: int, embeds: Sequence[torch.Tensor]):
         """up to 4 spliced prompts of equal length -> KV slots slot0 .. slot0 + n - 1 in one pass"""
         n = len(embeds)
-        assert 1 <= n <= self.PREFILL_GROUP and all(e.shape == embeds[0].shape and e.dtype == torch.bfloat16 and e.is_cuda for e in embeds)
+        assert 1 <= n <= self.PREFILL_GROUP and all(e.shape == embeds[0].shape and e.dtype == self.dtype and e.is_cuda for e in embeds)
         keep = [e.contiguous() for e in embeds]
         ptrs = (C.c_void_p * n)(*[e.data_ptr() for e in keep])
         _lib.check(self.lib.trace_llm_prefill_multi(self.h, slot0, ptrs, n, keep[0].shape[0], _stream()))
@@ -487,17 +493,28 @@ class TraceEngine:
 
 # ---- kernel-level wrappers for unit tests / microbenchmarks -------------------------------------
 class ops:
+    element = "bf16"               # which library the wrappers call: "bf16" (libtrace_hip.so) or "f16" (libtrace_hip_f16.so); ops.use()
+
+    @staticmethod
+    def use(element: str):
+        _lib.load(element)
+        ops.element = element
+
+    @staticmethod
+    def dtype() -> torch.dtype:
+        return torch.float16 if ops.element == "f16" else torch.bfloat16
+
     @staticmethod
     def set_gemm_variant(v: int):
-        _lib.check(_lib.load().trace_op_set_gemm_variant(v))
+        _lib.check(_lib.load(ops.element).trace_op_set_gemm_variant(v))
 
     @staticmethod
     def gemm(A, W, bias=None, R=None, epilogue=EPI_NONE):
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         M, K = A.shape
         N = W.shape[0]
         No = N // 2 if epilogue == EPI_SWIGLU else N
-        Cc = torch.empty((M, No), dtype=torch.bfloat16, device=A.device)
+        Cc = torch.empty((M, No), dtype=ops.dtype(), device=A.device)
         _lib.check(lib.trace_op_gemm(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(Cc), No, _ptr(bias), _ptr(R),
                                      0 if R is None else R.stride(0), M, N, K, epilogue, _stream()))
         return Cc
@@ -505,34 +522,34 @@ class ops:
     @staticmethod
     def gemm_lnfold(X, W, gamma, beta, bias, eps, epilogue=EPI_NONE):
         """act(LayerNorm(X) . W^T + bias) as one GEMM on the raw rows (the ViT's LayerNorm fold)"""
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         M, K = X.shape
         N = W.shape[0]
-        Cc = torch.empty((M, N), dtype=torch.bfloat16, device=X.device)
+        Cc = torch.empty((M, N), dtype=ops.dtype(), device=X.device)
         _lib.check(lib.trace_op_gemm_lnfold(_ptr(X), _ptr(W), _ptr(gamma), _ptr(beta), _ptr(bias), _ptr(Cc), M, N, K, eps, epilogue, _stream()))
         return Cc
 
     @staticmethod
     def gemm_residual_stats(A, W, bias, R, eps):
         """(A . W^T + bias + R, row statistics [M, 2] = (rstd, -mean * rstd) of that result) — the fold's producer epilogue + finalize kernel"""
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         M, K = A.shape
         N = W.shape[0]
-        Cc = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+        Cc = torch.empty((M, N), dtype=ops.dtype(), device=A.device)
         st = torch.empty((M, 2), dtype=torch.float32, device=A.device)
         _lib.check(lib.trace_op_gemm_residual_stats(_ptr(A), _ptr(W), _ptr(bias), _ptr(R), _ptr(Cc), _ptr(st), M, N, K, eps, _stream()))
         return Cc, st
 
     @staticmethod
     def layernorm(x, w, b, eps):
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         y = torch.empty_like(x)
         _lib.check(lib.trace_op_layernorm(_ptr(x), _ptr(y), _ptr(w), _ptr(b), x.shape[0], x.shape[1], eps, _stream()))
         return y
 
     @staticmethod
     def rmsnorm(x, w, eps):
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         y = torch.empty_like(x)
         _lib.check(lib.trace_op_rmsnorm(_ptr(x), _ptr(y), _ptr(w), x.shape[0], x.shape[1], eps, _stream()))
         return y
@@ -540,11 +557,11 @@ class ops:
     @staticmethod
     def attention(q, k, v, causal, scale):
         """q [B, nq, heads, hd]; k, v [B, nkv, kv_heads, hd] -> [B, nq, heads, hd]"""
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         Bn, nq, heads, hd = q.shape
         nkv, kvh = k.shape[1], k.shape[2]
         pad = (nkv + 63) // 64 * 64
-        vt = torch.empty((Bn * kvh * hd * pad,), dtype=torch.bfloat16, device=q.device)
+        vt = torch.empty((Bn * kvh * hd * pad,), dtype=ops.dtype(), device=q.device)
         o = torch.empty_like(q)
         _lib.check(lib.trace_op_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(vt), Bn, heads, kvh, nq, nkv, hd,
                                           1 if causal else 0, scale, _stream()))
@@ -553,7 +570,7 @@ class ops:
     @staticmethod
     def tile_pack(W):
         """row-major [N, K] -> the decode GEMV tile layout (same shape/bytes, permuted)"""
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         out = torch.empty_like(W)
         _lib.check(lib.trace_op_tile_pack(_ptr(W), _ptr(out), W.shape[0], W.shape[1], _stream()))
         return out
@@ -561,7 +578,7 @@ class ops:
     @staticmethod
     def skinny_gemm(X, W, R=None, epilogue=EPI_NONE, tiled=False, want_partial=True):
         """decode GEMV; `tiled`: W was passed through tile_pack.  EPI_PARTIAL returns the fp32 partial rows [KS, sk_rows, N]."""
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         Bn, K = X.shape
         N = W.shape[0]
         if epilogue == EPI_PARTIAL:
@@ -569,7 +586,7 @@ class ops:
             out = torch.zeros((ks, lib.trace_op_sk_rows(), N), dtype=torch.float32, device=X.device) if want_partial else None
         else:
             No = N // 2 if epilogue == EPI_SWIGLU else N
-            out = torch.empty((Bn, No), dtype=torch.bfloat16, device=X.device)
+            out = torch.empty((Bn, No), dtype=ops.dtype(), device=X.device)
         _lib.check(lib.trace_op_skinny_gemm(_ptr(X), _ptr(W), _ptr(out), _ptr(R), Bn, N, K, epilogue, int(tiled), _stream()))
         return out
 
@@ -577,7 +594,7 @@ class ops:
     def gemm_partial(X, W, tiled: int = 0):
         """decode batches above 64 rows: X [M <= 128, K] . W [N, K]^T as fp32 k-chunk partial rows [ks, sk_rows, N] (split-K MFMA GEMM);
         tiled: W went through tile_pack (1; 5 = + the 4-stage K-tile ring)"""
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         M, K = X.shape
         N = W.shape[0]
         out = torch.zeros((lib.trace_op_gemm_partial_ks(N, K), lib.trace_op_sk_rows(), N), dtype=torch.float32, device=X.device)
@@ -587,17 +604,17 @@ class ops:
     @staticmethod
     def gemm_swiglu_tiled(X, Wt, ring: bool = True):
         """gate|up of a wide decode step: X [M <= 128, K], Wt = tile_pack(16-row interleaved gate|up [N, K]) -> [M, N/2] bf16"""
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         M, K = X.shape
         N = Wt.shape[0]
-        out = torch.empty((M, N // 2), dtype=torch.bfloat16, device=X.device)
+        out = torch.empty((M, N // 2), dtype=ops.dtype(), device=X.device)
         _lib.check(lib.trace_op_gemm_swiglu_tiled(_ptr(X), _ptr(Wt), _ptr(out), M, N, K, int(ring), _stream()))
         return out
 
     @staticmethod
     def skinny_fused_norm(part_in, R, w, eps, W):
         """(xout, out-partials): xout = bf16(sum_k part_in[k, :B]) + R; partial rows [ks, sk_rows, N] of RMSNorm(xout; w) . W^T  (B <= 4)"""
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         Bn, K = R.shape
         N = W.shape[0]
         ks_in = 0 if part_in is None else part_in.shape[0]
@@ -608,20 +625,20 @@ class ops:
 
     @staticmethod
     def skinny_ks(N, K, epilogue, B):
-        return _lib.load().trace_op_skinny_ks(N, K, epilogue, B)
+        return _lib.load(ops.element).trace_op_skinny_ks(N, K, epilogue, B)
 
     @staticmethod
     def swiglu_combine(part, Bn):
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         N2 = part.shape[2]
-        out = torch.empty((Bn, N2 // 2), dtype=torch.bfloat16, device=part.device)
+        out = torch.empty((Bn, N2 // 2), dtype=ops.dtype(), device=part.device)
         _lib.check(lib.trace_op_swiglu_combine(_ptr(part), part.shape[0], N2, _ptr(out), Bn, _stream()))
         return out
 
     @staticmethod
     def add_rmsnorm(part, R, w, eps):
         """(x, y): x = bf16(sum_ks part[ks, b]) + R[b]; y = RMSNorm(x) * w"""
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         Bn, N = R.shape
         x, y = torch.empty_like(R), torch.empty_like(R)
         _lib.check(lib.trace_op_add_rmsnorm(_ptr(part), part.shape[0], _ptr(R), _ptr(x), _ptr(w), _ptr(y), Bn, N, eps, _stream()))
@@ -631,7 +648,7 @@ class ops:
     def attn_decode(q, kcache, vcache, pos, nsplit, scale, vtcache=None):
         """q [B, nq*128]; caches [B, nkv, max_ctx, 128]; pos int32 [B] (device).  The kernel reads V transposed
         ([B, nkv, 128, max_ctx], the engine's cache layout): built here unless `vtcache` is passed."""
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         if vtcache is None:
             vtcache = vcache.transpose(2, 3).contiguous()
         vcache = vtcache
@@ -648,7 +665,7 @@ class ops:
     @staticmethod
     def quant_rows_fp8(X):
         """X bf16 [rows, K] -> (uint8 e4m3 bytes [rows, K], fp32 scale [rows])"""
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         q = torch.empty(X.shape, dtype=torch.uint8, device=X.device)
         sx = torch.empty((X.shape[0],), dtype=torch.float32, device=X.device)
         _lib.check(lib.trace_op_quant_rows_fp8(_ptr(X), _ptr(q), _ptr(sx), X.shape[0], X.shape[1], _stream()))
@@ -656,18 +673,18 @@ class ops:
 
     @staticmethod
     def gemm_fp8(A8, sa, W8, sw, R=None, epilogue=EPI_NONE):
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         M, K = A8.shape
         N = W8.shape[0]
         No = N // 2 if epilogue == EPI_SWIGLU else N
-        Cc = torch.empty((M, No), dtype=torch.bfloat16, device=A8.device)
+        Cc = torch.empty((M, No), dtype=ops.dtype(), device=A8.device)
         _lib.check(lib.trace_op_gemm_fp8(_ptr(A8), _ptr(sa), _ptr(W8), _ptr(sw), _ptr(Cc), _ptr(R), M, N, K, epilogue, _stream()))
         return Cc
 
     @staticmethod
     def skinny_w8(X, W8, sw):
         """weight-only decode GEMV: X bf16 [B, K], W8 uint8 e4m3 [N, K] + row scales -> fp32 [B, N]"""
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         Bn, K = X.shape
         N = W8.shape[0]
         out = torch.empty((Bn, N), dtype=torch.float32, device=X.device)
@@ -676,7 +693,7 @@ class ops:
 
     @staticmethod
     def skinny_fp8(X8, sx, W8, sw):
-        lib = _lib.load()
+        lib = _lib.load(ops.element)
         Bn, K = X8.shape
         N = W8.shape[0]
         out = torch.empty((Bn, N), dtype=torch.float32, device=X8.device)

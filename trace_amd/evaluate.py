@@ -117,7 +117,7 @@ def evaluate_videos(model, tokenizer, processor, items: Sequence[dict], prompt: 
             vids, tss, idl = [], [], []
             for it in chunk:
                 v, ts = process_video(it["video"], processor, aspect, nf, fps=it.get("fps"), engine=eng if device_preprocess else None)
-                vids.append(v if v.is_cuda else v.to(eng.device, torch.bfloat16))
+                vids.append(v if v.is_cuda else v.to(eng.device, eng.dtype))
                 tss.append(ts)
                 q = prompt.format(it["query"].strip()) if it.get("query") is not None else prompt
                 idl.append(build_prompt_ids(q, tokenizer, conv_mode).tolist())

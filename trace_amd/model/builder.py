@@ -137,7 +137,7 @@ def load_tokenizer(model_path: str, cfg: TraceConfig, **kwargs):
 def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto",
                           device="cuda", use_flash_attn=False, max_batch: int = 1, max_new_tokens: int = 1024, **kwargs):
     if load_8bit or load_4bit:
-        raise NotImplementedError("bitsandbytes quantised loading is outside the MI355X bf16 path")
+        raise NotImplementedError("bitsandbytes quantised loading is outside the MI355X path")
     if model_base is not None or "lora" in model_name.lower():
         raise NotImplementedError("LoRA merge-at-load is outside the accelerated path; merge the adapter offline")
     from ..engine import TraceEngine      # fails loudly without the HIP library / a GPU
@@ -154,12 +154,15 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
     else:
         vis = T * cfg.tokens_per_frame
     max_ctx = min(cfg.max_position_embeddings, vis + 1024 + max_new_tokens)
+    # the reference loads with torch_dtype=torch.float16 (trace/model/builder.py:50); north_star's configs say bf16, which stays the default here:
+    # torch_dtype=torch.float16 selects the fp16 library (libtrace_hip_f16.so)
+    dtype = kwargs.get("torch_dtype") or torch.bfloat16
     eng = TraceEngine(cfg, device=dev_index, max_batch=max_batch, max_ctx=max_ctx, max_frames=max(T, 1),
-                      max_new_tokens=max_new_tokens)
+                      max_new_tokens=max_new_tokens, dtype=dtype)
     if raw.get("synthetic_weights"):
         from .. import synth
         small = cfg.hidden_size * cfg.num_hidden_layers < 4096 * 8
-        eng.load_weights(synth.iter_weights(cfg, device="cpu" if small else f"cuda:{dev_index}"))
+        eng.load_weights(synth.iter_weights(cfg, dtype=dtype, device="cpu" if small else f"cuda:{dev_index}"))
         has_tok = any(os.path.exists(os.path.join(model_path, f)) for f in ("tokenizer.model", "tokenizer.json"))
         tokenizer = load_tokenizer(model_path, cfg, **kwargs) if has_tok else ByteTokenizer(cfg.vocab_size)
     else:

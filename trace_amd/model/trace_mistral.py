@@ -65,7 +65,7 @@ class TraceMistralForCausalLM:
                             config.vocab_size + config.time_vocab_size + 1: 0}
         self.model = _MetaModel(config, _VisionTower(config, image_processor))
         self.device = engine.device
-        self.dtype = torch.bfloat16
+        self.dtype = engine.dtype
 
     # ---- nn.Module-like conveniences the drivers call ----
     def get_model(self):

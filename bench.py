@@ -169,6 +169,8 @@ def main():
                          "sequential steps: none), a 25-step run at the C2 shape likewise; not root-caused, so the steps run one after the other")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="(the default) timed steps strictly one after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
+                    help="element type: bf16 (BASELINE's configs; libtrace_hip.so) or fp16 (the reference's own inference dtype; libtrace_hip_f16.so)")
     ap.add_argument("--tiny", action="store_true", help="tiny geometry (plumbing check)")
     ap.add_argument("--vit-batch", type=int, default=None, help="frames per ViT call (default: TraceEngine.full_round_frames)")
     args = ap.parse_args()
@@ -203,14 +205,18 @@ def main():
     ids = synth.synth_prompt_ids(cfg, n_text=n_text, video_pos=10 if args.tiny else preset["video_pos"]).tolist()
     L = n_text - 1 + args.frames * cfg.tokens_per_frame
     pipelined = args.pipeline and 2 * B <= 256 and args.steps > 1
+    el_dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    if args.fp8 and args.dtype != "bf16":
+        sys.exit("bench: the fp8 weight path exists in the bf16 library only (--config c5 --dtype fp16 needs --no-fp8)")
     eng = TraceEngine(cfg, device=local, max_batch=2 * B if pipelined else B, max_ctx=(L + n_new + 63) // 64 * 64, max_frames=args.frames,
-                      max_new_tokens=n_new, vit_batch_frames=args.vit_batch or TraceEngine.full_round_frames(cfg), llm_fp8=(args.fp8_scheme if args.fp8 else False))
+                      max_new_tokens=n_new, vit_batch_frames=args.vit_batch or TraceEngine.full_round_frames(cfg), llm_fp8=(args.fp8_scheme if args.fp8 else False),
+                      dtype=el_dtype)
     t0 = time.perf_counter()
-    eng.load_weights(synth.iter_weights(cfg, device=str(dev)))
+    eng.load_weights(synth.iter_weights(cfg, dtype=el_dtype, device=str(dev)))
     torch.cuda.synchronize()
     t_load = time.perf_counter() - t0
     # inputs resident in HBM before the timed region
-    videos = [synth.synth_frames(cfg, rank * B + b, num_frames=args.frames, dtype=torch.bfloat16, device=dev) for b in range(B)]
+    videos = [synth.synth_frames(cfg, rank * B + b, num_frames=args.frames, dtype=el_dtype, device=dev) for b in range(B)]
     ts = [[[float(i)] for i in range(args.frames)] for _ in range(B)]
     prompt = [ids] * B
     heads = [1] * B
@@ -324,7 +330,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": (("fp8 e4m3 weights in the decoder projections: W8A8 (fp8 MFMA, fp32 accumulate) in the prefill GEMMs, " +
                        ("weight-only (bf16 activations, bf16 MFMA) in the decode GEMVs" if args.fp8_scheme == "weight_only" else "W8A8 in the decode GEMVs") +
-                       "; bf16 elsewhere (ViT, attention, KV cache, norms, heads)") if args.fp8 else "bf16"), "data": "synthetic",
+                       "; bf16 elsewhere (ViT, attention, KV cache, norms, heads)") if args.fp8 else args.dtype), "data": "synthetic",
             "config": {"workload": ("tiny plumbing check" if args.tiny else
                                     f"{preset['name']}, {args.frames}x336^2 frames, prefill L={Ls}, {n_new} greedy tokens, heads=[1]"),
                        "baseline_config": args.config,

@@ -332,7 +332,7 @@ def main():
                        ("weight-only (bf16 activations, bf16 MFMA) in the decode GEMVs" if args.fp8_scheme == "weight_only" else "W8A8 in the decode GEMVs") +
                        "; bf16 elsewhere (ViT, attention, KV cache, norms, heads)") if args.fp8 else args.dtype), "data": "synthetic",
             "config": {"workload": ("tiny plumbing check" if args.tiny else
-                                    f"{preset['name']}, {args.frames}x336^2 frames, prefill L={Ls}, {n_new} greedy tokens, heads=[1]"),
+                                    f"{preset['name'].replace(' bf16', ' ' + args.dtype)}, {args.frames}x336^2 frames, prefill L={Ls}, {n_new} greedy tokens, heads=[1]"),
                        "baseline_config": args.config,
                        "videos_per_step_per_gpu": B, "frames": args.frames, "prefill_len": Ls, "new_tokens": n_new, "head_schedule": ("forced MR pattern: 14 time + 4 score + 14 text steps per 32 tokens" if preset["schedule"] == "mr" else "forced DVC pattern per event: 14 time + 4 score + 33 text steps") + " (argmax still computed every step)",
                        "decode_launch": "hipGraph" if args.graph else "eager", "parallelism": f"dp{world} (replica per GPU)",

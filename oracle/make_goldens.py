@@ -150,6 +150,21 @@ def run_reference(model, cfg, input_ids, frames, ts, forced=None, n_new=24):
     return torch.stack(step_logits), toks, L
 
 
+def _own_fp16_run(model, cfg, input_ids, frames, ts, forced, tf_logits):
+    """The reference in ITS OWN inference dtype (model.half(), trace/model/builder.py:50) on the same teacher-forced stream; {} when this
+    host's CPU half kernels cannot run it."""
+    try:
+        m16 = model.half()
+        l16, a16, _ = run_reference(m16, cfg, input_ids, frames.half(), ts, forced=forced)
+        print("reference fp16 run: max |logit - fp32 run| =", float((l16.float() - tf_logits)[torch.isfinite(tf_logits)].abs().max()))
+        return {"tf_logits_ref_fp16": l16.float().numpy().astype(np.float32), "tf_argmax_ref_fp16": np.array(a16)}
+    except Exception as e:
+        print("reference fp16 run not possible on this host:", repr(e)[:200])
+        return {}
+    finally:
+        model.float()
+
+
 def fp_goldens(tmp, dtype=torch.bfloat16, name="tiny_e2e.npz"):
     """dtype: what the synthetic weights and frames are rounded to before the reference (fp32 arithmetic) sees them — bf16 for the default
     library, fp16 for libtrace_hip_f16.so (tiny_e2e_f16.npz)."""
@@ -184,18 +199,7 @@ def fp_goldens(tmp, dtype=torch.bfloat16, name="tiny_e2e.npz"):
     forced = scripted_ids(cfg)
     tf_logits, tf_argmax, _ = run_reference(model, cfg, input_ids, frames, ts, forced=forced)
 
-    extra = {}
-    if dtype == torch.float16:
-        # the reference in ITS OWN inference dtype (model.half(), trace/model/builder.py:50): the teacher-forced logits of an fp16 run, so that a
-        # test can say how far the fp16 library is from the reference's fp16 and how far both are from the fp32 arithmetic above
-        try:
-            m16 = model.half()
-            l16, a16, _ = run_reference(m16, cfg, input_ids, frames.half(), ts, forced=forced)
-            extra = {"tf_logits_ref_fp16": l16.float().numpy().astype(np.float32), "tf_argmax_ref_fp16": np.array(a16)}
-            print("reference fp16 run: max |logit - fp32 run| =", float((l16.float() - tf_logits)[torch.isfinite(tf_logits)].abs().max()))
-        except Exception as e:      # CPU half kernels missing for some op: the fp32-arithmetic fixture stands alone
-            print("reference fp16 run not possible on this host:", repr(e)[:200])
-        model.float()
+    extra = _own_fp16_run(model, cfg, input_ids, frames, ts, forced, tf_logits) if dtype == torch.float16 else {}
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(
         os.path.join(OUT, name), **extra,
@@ -383,7 +387,7 @@ def medium_goldens(tmp):
     print("medium_vit: feats", tuple(feats.shape), "abs mean %.4f max %.3f" % (feats.abs().mean().item(), feats.abs().max().item()))
 
 
-def medium_llm_goldens(tmp):
+def medium_llm_goldens(tmp, dtype=torch.bfloat16):
     """One decoder layer at the REAL Mistral-7B widths (hidden 4096, intermediate 14336, 32/8 heads x 128) behind the tiny ViT:
     teacher-forced logits of the reference over a stream that visits all three heads.  Pins the K = 14336 down-projection
     (the decode GEMV's many-chunk partial rows) and the 28672-wide gate|up product against the reference itself."""
@@ -391,13 +395,14 @@ def medium_llm_goldens(tmp):
     from trace_amd import config as tcfg, synth
     cfg = dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336, num_hidden_layers=1)
     model = build_reference_model(cfg, os.path.join(tmp, "medllm"))
-    load_synth(model, cfg)
-    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16).float()
+    load_synth(model, cfg, dtype)
+    frames = synth.synth_frames(cfg, 0).to(dtype).float()
     ts = [[float(i) * 2.5] for i in range(cfg.num_frames)]
     input_ids = synth.synth_prompt_ids(cfg, n_text=24, video_pos=10)
     forced = scripted_ids(cfg)
     tf_logits, tf_argmax, L = run_reference(model, cfg, input_ids, frames, ts, forced=forced)
-    np.savez_compressed(os.path.join(OUT, "medium_llm.npz"), input_ids=input_ids.numpy(), timestamps=np.array(ts, dtype=np.float64),
+    extra = _own_fp16_run(model, cfg, input_ids, frames, ts, forced, tf_logits) if dtype == torch.float16 else {}
+    np.savez_compressed(os.path.join(OUT, "medium_llm" + ("_f16" if dtype == torch.float16 else "") + ".npz"), **extra, input_ids=input_ids.numpy(), timestamps=np.array(ts, dtype=np.float64),
                         forced_ids=np.array(forced), tf_logits=tf_logits.numpy().astype(np.float32), tf_argmax=np.array(tf_argmax),
                         prefill_len=np.array(L))
     print("medium_llm: L=%d steps=%d" % (L, len(tf_argmax)))
@@ -451,20 +456,21 @@ def real_vocab_goldens(tmp):
     print("real_vocab: NV=%d steps=%d finite counts %s" % (NV, len(tf_argmax), sorted(set(fin.sum(-1).tolist()))))
 
 
-def deep_llm_goldens(tmp):
+def deep_llm_goldens(tmp, dtype=torch.bfloat16):
     """Depth: EIGHT decoder layers at the real Mistral-7B widths (1.74 B parameters, a quarter of the real stack) behind the
     tiny ViT, teacher-forced.  Shows how the bf16 noise of the HIP path accumulates with depth against the fp32 reference."""
     import dataclasses
     from trace_amd import config as tcfg, synth
     cfg = dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336, num_hidden_layers=8)
     model = build_reference_model(cfg, os.path.join(tmp, "deepllm"))
-    load_synth(model, cfg)
-    frames = synth.synth_frames(cfg, 0).to(torch.bfloat16).float()
+    load_synth(model, cfg, dtype)
+    frames = synth.synth_frames(cfg, 0).to(dtype).float()
     ts = [[float(i) * 2.5] for i in range(cfg.num_frames)]
     input_ids = synth.synth_prompt_ids(cfg, n_text=24, video_pos=10)
     forced = scripted_ids(cfg)
     tf_logits, tf_argmax, L = run_reference(model, cfg, input_ids, frames, ts, forced=forced)
-    np.savez_compressed(os.path.join(OUT, "deep_llm.npz"), input_ids=input_ids.numpy(), timestamps=np.array(ts, dtype=np.float64),
+    extra = _own_fp16_run(model, cfg, input_ids, frames, ts, forced, tf_logits) if dtype == torch.float16 else {}
+    np.savez_compressed(os.path.join(OUT, "deep_llm" + ("_f16" if dtype == torch.float16 else "") + ".npz"), **extra, input_ids=input_ids.numpy(), timestamps=np.array(ts, dtype=np.float64),
                         forced_ids=np.array(forced), tf_logits=tf_logits.numpy().astype(np.float32), tf_argmax=np.array(tf_argmax),
                         prefill_len=np.array(L))
     print("deep_llm: L=%d steps=%d logit std %.3f" % (L, len(tf_argmax), tf_logits[torch.isfinite(tf_logits)].std().item()))
@@ -715,6 +721,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--f16-only" in sys.argv:
         fp_goldens(tmp, torch.float16, "tiny_e2e_f16.npz")
+        medium_llm_goldens(tmp, torch.float16)
+        deep_llm_goldens(tmp, torch.float16)
         sys.exit(0)
     if "--full-depth-only" in sys.argv:
         full_depth_goldens(tmp)
@@ -722,6 +730,8 @@ if __name__ == "__main__":
     int_goldens()
     fp_goldens(tmp)
     fp_goldens(tmp, torch.float16, "tiny_e2e_f16.npz")
+    medium_llm_goldens(tmp, torch.float16)
+    deep_llm_goldens(tmp, torch.float16)
     medium_goldens(tmp)
     medium_llm_goldens(tmp)
     long_ctx_goldens(tmp)

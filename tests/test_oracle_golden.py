@@ -324,3 +324,23 @@ def test_f16_emulating_oracle_tracks_the_reference_in_fp16(sd16, E16):
     e_ora = np.abs(lg.numpy()[fin] - ref32[fin]).max()
     e_x = np.abs(lg.numpy()[fin] - ref16[fin]).max()
     assert e_ref < 0.03 and e_ora < 0.03 and e_x < 0.04, (e_ref, e_ora, e_x)      # bf16 at the same points: 0.08 (tests/test_gpu_parity.py)
+
+
+@pytest.mark.parametrize("name,layers", [("medium_llm_f16.npz", 1), ("deep_llm_f16.npz", 8)])
+def test_real_width_f16_fixtures_pin_the_oracle(golden_dir, name, layers):
+    """Real Mistral-7B widths (1 and 8 layers) on fp16-rounded weights: the oracle against the reference's fp32-arithmetic logits; and the
+    reference's own model.half() run of the same stream stays within 0.02 / 0.04 of them — the yardstick for the fp16 library's budget."""
+    import dataclasses
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336, num_hidden_layers=layers)
+    M = np.load(os.path.join(golden_dir, name))
+    sd = {k: v.float() for k, v in synth.state_dict(cfg, dtype=torch.float16).items()}
+    ora = O.Oracle(cfg, sd, emulate_bf16=False)
+    frames = synth.synth_frames(cfg, 0).to(torch.float16).float()
+    forced = M["forced_ids"].tolist()
+    ids, lg = ora.generate(torch.from_numpy(M["input_ids"]), frames, M["timestamps"].tolist(), head=1,
+                           max_new_tokens=len(forced) + 1, forced_ids=forced, return_logits=True)
+    assert ids == M["tf_argmax"].tolist()
+    _cmp_logits(lg.numpy(), M["tf_logits"])
+    if "tf_logits_ref_fp16" in M:
+        fin = np.isfinite(M["tf_logits"])
+        assert np.abs(M["tf_logits_ref_fp16"][fin] - M["tf_logits"][fin]).max() < (0.025 if layers == 1 else 0.045)

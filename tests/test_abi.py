@@ -94,3 +94,11 @@ def test_header_is_plain_c_and_example_links(lib, tmp_path):
            "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + os.path.join(root, "trace_amd"), "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_element_type_of_torch_dtypes():
+    import torch
+    from trace_amd import _lib
+    assert _lib.element_of(torch.bfloat16) == "bf16" and _lib.element_of(torch.float16) == "f16"
+    with pytest.raises(ValueError):
+        _lib.element_of(torch.float32)

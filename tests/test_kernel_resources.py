@@ -16,10 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "trace_amd", "csrc")
 
 
-def _resources(name, tmp):
+def _resources(name, tmp, f16=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c", os.path.join(CSRC, name + ".hip"),
-           "-I", CSRC, "-o", os.path.join(tmp, name + ".o"), "-Rpass-analysis=kernel-resource-usage"]
+           "-I", CSRC, "-o", os.path.join(tmp, name + ("_f16.o" if f16 else ".o")), "-Rpass-analysis=kernel-resource-usage"] + (["-DTRACE_F16"] if f16 else [])
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp)
     assert r.returncode == 0, r.stderr[-2000:]
     out, cur = {}, None
@@ -97,6 +97,24 @@ def test_round3_kernels_keep_their_budgets(res):
     assert pro, list(res["decode"])[:4]
     for k, v in pro.items():
         assert v["ScratchSize"] == 0, (k, v)
+
+
+def test_fp16_build_keeps_the_budgets(res, tmp_path_factory):
+    """libtrace_hip_f16.so (-DTRACE_F16): the same kernels with fp16 conversions and MFMAs must keep every kernel's occupancy and stay out of
+    scratch wherever the bf16 build does (two gemm_ldr instantiations are allowed their measured 8 bytes; the fp8 GEMM instantiations are
+    unreachable in that build)."""
+    tmp = str(tmp_path_factory.mktemp("kres16"))
+    names = ["gemm_ldr", "gemm_pers", "gemm", "attn", "decode"]
+    with cf.ThreadPoolExecutor(max_workers=5) as ex:
+        r16 = dict(zip(names, ex.map(lambda n: _resources(n, tmp, True), names)))
+    for n in names:
+        assert set(r16[n]) == set(res[n]), n
+        for k, v in res[n].items():
+            w = r16[n][k]
+            if "gemm_glds_kernel" in k and "ELb1ELb0E" in k:
+                continue                                   # <..., FP8 = true, ...>: bf16 library only
+            assert w["Occupancy"] == v["Occupancy"], (k, v, w)
+            assert w["ScratchSize"] <= v["ScratchSize"] + (8 if n == "gemm_ldr" else 0), (k, v, w)
 
 
 def test_no_asm_load_into_a_dummy_register():

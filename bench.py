@@ -258,13 +258,18 @@ def main():
     dt = tdist.max_over_ranks(time.perf_counter() - t0)
     out = outs[-1]
     # every step runs the same inputs through a path whose reductions all have a fixed order: the ids must repeat exactly
+    # (checked on every rank; reported in the line as `steps_repeat_exactly` — the run is not aborted: under torchrun one rank leaving would hang the
+    # others in the closing collectives, and a throughput measured on a run with one differing sequence is still a throughput; the tests are where
+    # a difference fails)
+    repeat_detail = []
     if any(o != outs[0] for o in outs[1:]):
-        detail = []
         for k, o in enumerate(outs[1:], 1):
             bad = [(b, next((i for i, (x, y) in enumerate(zip(o[b], outs[0][b])) if x != y), -1)) for b in range(len(o)) if o[b] != outs[0][b]]
             if bad:
-                detail.append(f"step {k}: {len(bad)} of {len(o)} sequences differ, first (sequence, token) pairs {bad[:6]}")
-        raise SystemExit("bench: output ids differ between identical steps (a race or an unordered reduction)\n  " + "\n  ".join(detail[:12]))
+                repeat_detail.append(f"step {k}: {len(bad)} of {len(o)} sequences differ, first (sequence, token) pairs {bad[:6]}")
+        print(f"bench (rank {rank}): output ids differ between identical steps (a race or an unordered reduction)\n  " + "\n  ".join(repeat_detail[:12]),
+              file=sys.stderr, flush=True)
+    steps_repeat = tdist.max_over_ranks(1.0 if repeat_detail else 0.0) == 0.0          # over all ranks (a collective: every rank gets here)
     prof = eng.get_profile()
     eng.set_profile(0)
 
@@ -340,6 +345,7 @@ def main():
                                          "(fill and drain inside the timed region; the roofline brackets are taken in the fill / drain phases only)"
                                          if pipelined else "steps strictly one after the other"),
                        "weights": "random-init (device RNG), reference architecture"},
+            "steps_repeat_exactly": bool(steps_repeat), **({"steps_repeat_detail": repeat_detail[:12]} if repeat_detail else {}),
             "decode_tok_s": world * B * (n_new - 1) / (t_dec * 1e-3),
             "stages_ms": {"vit_slotpool_per_video": t_enc, "prefill_per_video": t_pre, f"decode_{n_new - 1}_steps_batch{B}": t_dec,
                           "decode_ms_per_step": t_dec / (n_new - 1), "weights_load_s": t_load},

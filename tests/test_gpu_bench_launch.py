@@ -27,6 +27,7 @@ def test_bench_tiny_under_torchrun():
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["unit"] == "videos/s" and d["scaling"] == "weak"
     assert d["config"]["videos_per_step_per_gpu"] == 3
     assert "roofline" in d and "cpu_baseline" in d
+    assert d["steps_repeat_exactly"] is True, d.get("steps_repeat_detail")
 
 
 def test_evaluate_driver_under_torchrun(tmp_path):

@@ -15,6 +15,8 @@ ap.add_argument("--max-new", type=int, default=24)
 ap.add_argument("--B", type=int, default=128)
 ap.add_argument("--sequential", action="store_true")
 ap.add_argument("--gemm-variant", type=int, default=0, help="trace_op_set_gemm_variant: 4 = every 256^2 GEMM on the loader-wave kernel (no persistent kernel, no LayerNorm fold)")
+ap.add_argument("--plan", default="", help="comma-separated phases run in one process, each a '+'-joined list of variant codes, e.g. 500,500,502")
+ap.add_argument("--adaptive", action="store_true", help="after the plan: if a phase on the shipped tile walk (500) differed, also run 501 (static deal) and 150 (no LayerNorm fold)")
 a = ap.parse_args()
 cfg = tcfg.trace_7b(a.frames)
 B, n_new = a.B, a.max_new
@@ -63,32 +65,53 @@ def dbg(tag, idx, t):
         log["feats"].append(dict(cur["feats"])); cur["feats"] = {}
 
 
-if a.gemm_variant:
-    _lib.check(eng.lib.trace_op_set_gemm_variant(a.gemm_variant))
 eng._dbg = dbg
-t0 = time.time()
-if a.sequential:
-    outs = []
-    for _ in range(a.steps):
-        eng.encode_prefill(videos, ts, [ids] * B, 0)
-        dbg("prefilled", 0, None)
-        outs.append(eng.decode(range(B), [1] * B, n_new, -1, False, forced)[0])
-else:
-    outs = [o[0] for o in eng.generate_stream([batch] * a.steps, n_new, eos=-1, use_graph=False)]
-print(f"{a.steps} steps in {time.time() - t0:.0f} s ({'sequential' if a.sequential else 'pipelined'}, gemm variant {a.gemm_variant})")
-torch.cuda.synchronize()
-log["kv"] = [t.cpu() for t in log["kv"]]
-log["feats"] = [{b: int(v) for b, v in d.items()} for d in log["feats"]]
-bad = 0
-for k in range(1, a.steps):
-    f_bad = [b for b in range(B) if log["feats"][k].get(b) != log["feats"][0].get(b)]
-    kv_bad = torch.nonzero((log["kv"][k] != log["kv"][0]).any(dim=1)).flatten().tolist()
-    kv_cols = (log["kv"][k] != log["kv"][0]).any(dim=0).tolist()
-    id_bad = [(b, next(i for i, (x, y) in enumerate(zip(outs[k][b], outs[0][b])) if x != y), sum(int(x != y) for x, y in zip(outs[k][b], outs[0][b])))
-              for b in range(B) if outs[k][b] != outs[0][b]]
-    if f_bad or kv_bad or id_bad:
-        bad += 1
-        print(f"step {k}: ViT features differ for videos {f_bad[:8]}; prefilled state differs for slots {kv_bad[:8]} (K, V^T, last hidden: {kv_cols}); "
-              f"ids differ for (sequence, first token, count) {id_bad[:8]}")
-print("all steps identical" if not bad else f"{bad} of {a.steps - 1} steps differ from step 0")
+
+
+def run_phase(variants, steps):
+    """one run of `steps` identical steps under the given trace_op_set_gemm_variant codes -> number of steps that differ from the phase's step 0"""
+    for v in variants:
+        _lib.check(eng.lib.trace_op_set_gemm_variant(v))
+    log["feats"], log["kv"], log["ids"] = [], [], []
+    cur["feats"] = {}
+    t0 = time.time()
+    if a.sequential:
+        outs = []
+        for _ in range(steps):
+            eng.encode_prefill(videos, ts, [ids] * B, 0)
+            dbg("prefilled", 0, None)
+            outs.append(eng.decode(range(B), [1] * B, n_new, -1, False, forced)[0])
+    else:
+        outs = [o[0] for o in eng.generate_stream([batch] * steps, n_new, eos=-1, use_graph=False)]
+    torch.cuda.synchronize()
+    print(f"phase {variants}: {steps} steps in {time.time() - t0:.0f} s ({'sequential' if a.sequential else 'pipelined'})", flush=True)
+    kv = [t.cpu() for t in log["kv"]]
+    feats = [{b: int(v) for b, v in d.items()} for d in log["feats"]]
+    bad = 0
+    for k in range(1, steps):
+        f_bad = [b for b in range(B) if feats[k].get(b) != feats[0].get(b)]
+        kv_bad = torch.nonzero((kv[k] != kv[0]).any(dim=1)).flatten().tolist()
+        kv_cols = (kv[k] != kv[0]).any(dim=0).tolist()
+        id_bad = [(b, next(i for i, (x, y) in enumerate(zip(outs[k][b], outs[0][b])) if x != y), sum(int(x != y) for x, y in zip(outs[k][b], outs[0][b])))
+                  for b in range(B) if outs[k][b] != outs[0][b]]
+        if f_bad or kv_bad or id_bad:
+            bad += 1
+            print(f"  step {k}: ViT features differ for videos {f_bad[:8]}; prefilled state differs for slots {kv_bad[:8]} (K, V^T, last hidden: {kv_cols}); "
+                  f"ids differ for (sequence, first token, count) {id_bad[:8]}")
+    print(f"phase {variants}: " + ("all steps identical" if not bad else f"{bad} of {steps - 1} steps differ from step 0"), flush=True)
+    for v in variants:                      # back to the defaults
+        _lib.check(eng.lib.trace_op_set_gemm_variant({500: 500, 501: 500, 502: 500, 150: 151, 151: 151}.get(v, 0)))
+    return bad
+
+
+# --plan "500,500,502" : phases, each a '+'-joined list of variant codes (500 = shipped tile walk, 501 = static deal, 502 = round 3's plain-store re-arm,
+# 150 = no LayerNorm fold, 4 = no persistent kernel).  --adaptive: if a shipped-walk phase (500) shows a difference, add the phases that localise it.
+plan = [[int(x) for x in ph.split("+")] for ph in (a.plan.split(",") if a.plan else [str(a.gemm_variant or 500)])]
+res = []
+for ph in plan:
+    res.append((ph, run_phase(ph, a.steps)))
+if a.adaptive and any(b for ph, b in res if ph == [500]):
+    for ph in ([501], [150]):
+        res.append((ph, run_phase(ph, a.steps)))
+print("summary: " + "; ".join(f"{ph}: {b} differing steps of {a.steps - 1}" for ph, b in res))
 eng.close()

@@ -1397,6 +1397,7 @@ extern int g_attn_pf_debug;
 extern int g_skinny_debug;
 extern int g_gemm_pers_opt;
 extern int g_gemm_ldr_opt;
+extern int g_gemm_pers_walk;
 extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 1000 && variant <= 1000 + 1024) { g_gemm_pers_grid_cap = variant - 1000; return TRACE_OK; }   // persistent GEMM: at most n workgroups (0 = #CUs)
     if (variant >= 100 && variant < 104) { g_attn_debug = variant - 100; return TRACE_OK; }
@@ -1408,6 +1409,7 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : 32; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
+    if (variant >= 500 && variant <= 502) { g_gemm_pers_walk = variant - 500; return TRACE_OK; }   // the persistent GEMM's tile walk on every route (gemm_pers.hip)
     if (variant >= 400 && variant < 404) { g_gemm_ldr_opt = variant - 400; return TRACE_OK; }   // microbench: attention phase cut-offs
     if (variant < 0 || variant > 7) return fail(TRACE_ERR_ARG, "variant must be 0..7");
     g_gemm_variant = variant;

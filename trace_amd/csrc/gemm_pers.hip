@@ -442,7 +442,14 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
             }
             if (kt == 1 && tid == NMT) {                            // the tile after this one: everyone reads it after this tile's last hand-over
                 s_next[(n + 1) & 1] = dynamic ? nwg + ticket : li + nwg;
-                if (dynamic && ticket == cnt - 1) ctr[xcd * CTR_STRIDE] = 0;       // the launch's last ticket on this XCD: re-arm the counter
+                // the launch's last ticket on this XCD re-arms the counter — with an agent-scope atomic, like the tickets themselves: every draw of the
+                // launch precedes it in the counter's modification order (the last draw returned cnt - 1), and it reaches memory the way the next
+                // launch's draws will.  Until round 3 this was a plain store: that one sits in whichever XCD's L2 the holder ran on until a
+                // write-back, while the draws are performed memory-side (dynamic == 3 keeps that form for the A/B stress run of DESIGN 5a).
+                if (dynamic && ticket == cnt - 1) {
+                    if (dynamic == 3) ctr[xcd * CTR_STRIDE] = 0;
+                    else (void)atomicExch(ctr + xcd * CTR_STRIDE, 0);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                           // K-tile q handed over; the stage of q-1 is free
@@ -651,6 +658,8 @@ void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
 
 int g_gemm_pers_opt = 0;           // A/B builds of the K loop (trace_op_set_gemm_variant(300 + opt))
 int g_gemm_pers_static = 0;        // 1: tiles dealt round-robin instead of by ticket (A/B runs)
+int g_gemm_pers_walk = 0;          // every route, the LayerNorm-fold launches included (trace_op_set_gemm_variant(500 + w)): 0 = tickets, atomic re-arm;
+                                   // 1 = static deal; 2 = tickets with round 3's plain-store re-arm (the stress tool's positive control)
 
 int g_gemm_pers_grid_cap = 0;      // > 0: at most this many workgroups per launch (a stream confined to part of the CUs by a CU mask: the
                                    // persistent grid must not exceed the CUs it can run on, or the surplus workgroups wait for a second round)
@@ -680,7 +689,7 @@ int launch_gemm_pers(const GemmArgs& p, int epi, hipStream_t s) {
     // g_gemm_pers_static == 2: one workgroup per tile (the dispatcher places them as CUs free up, nothing persists): this kernel's K loop and
     // register epilogue without the tile walk (A/B runs)
     const int nblk = g_gemm_pers_static == 2 ? total : (total < ncu ? total : ncu);
-    const int dynamic = g_gemm_pers_static ? 0 : 1;
+    const int dynamic = (g_gemm_pers_static || g_gemm_pers_walk == 1) ? 0 : (g_gemm_pers_walk == 2 ? 3 : 1);
     g_opt = g_gemm_pers_opt;
     switch (epi) {
         case EPI_NONE: launch_one<EPI_NONE>(p, nblk, dynamic, ctr, s); break;

@@ -6,12 +6,14 @@
         --nproc-per-node N, rendezvous on 127.0.0.1) and fails if fewer than N GPUs are visible; under an external
         torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE and requires WORLD_SIZE == N.
 
-A "step" = one pass of the hot path over one batch of `--videos-per-step` (default 64) videos per GPU, inputs already
-resident in HBM: CLIP-ViT-L/14-336 over 128 frames -> SpatialSlotPool -> splice -> Mistral-7B prefill (L = 1968) -> 256 greedy
+A "step" = one pass of the hot path over one batch of `--videos-per-step` (default 128; 32 for c5) videos per GPU, inputs already
+resident in HBM: CLIP-ViT-L/14-336 over 128 frames -> SpatialSlotPool -> splice -> Mistral-7B prefill (L = 1967) -> 256 greedy
 decode steps with head switching, then ONE RCCL all-gather of the packed token ids (N > 1).  Prints one JSON line
-(rank 0) with the whole-job videos/sec, the decode tokens/sec, the roofline of the dominant kernel (the fused gate|up
-weight-streaming GEMV of a decode step) measured with HIP events inside the timed region, and the CPU baseline (the
-oracle timed on a bounded sample on this box's host cores).
+(rank 0) with the whole-job videos/sec, the decode tokens/sec, `roofline` = the dominant kernel family of the run (the 256x256 loader-wave
+MFMA GEMM: gemm_ldr_kernel<1> is the top symbol by total time, gemm_pers_kernel<2,16> its largest single launch; all four ViT shapes are
+bracketed with HIP events inside the timed region), `roofline_hbm` = the dominant HBM-bound kernel of the decode phase (the decode
+attention at the default batch), per-rank timings and host placement (N > 1), and the CPU baseline (the oracle timed on a bounded sample
+on this box's host cores; N = 1 only).
 """
 from __future__ import annotations
 
@@ -133,14 +135,20 @@ def plumbing_check(args, rank, world) -> None:
     """Launcher / rendezvous / gather path with no kernels (runs on CPU over gloo: tests/test_bench_launcher.py): every rank fabricates
     its videos' ids, the packed all-gather runs, rank 0 prints a line whose n_gpus / rccl_ranks prove every rank took part."""
     B, n_new = 3, 8
+    place = tdist.bind_rank(int(os.environ.get("LOCAL_RANK", rank)), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     local = [[(1000 * rank + 10 * b + i) % 32027 for i in range(1 + (b + rank) % n_new)] for b in range(B)]
     tdist.barrier()
+    t0 = time.perf_counter()
     g = tdist.gather_outputs(local, n_new, B, None if torch.cuda.is_available() else torch.device("cpu"))
+    dt_local = time.perf_counter() - t0
     tdist.barrier()
     ok = all(g[r][b] == [(1000 * r + 10 * b + i) % 32027 for i in range(1 + (b + r) % n_new)] for r in range(world) for b in range(B))
+    per_rank = tdist.gather_floats([dt_local * 1e3, float(rank), float(len(os.sched_getaffinity(0)))])          # the real line's per-rank collective
     if rank == 0:
         print(json.dumps({"metric": "plumbing check (no kernels)", "value": 0.0, "unit": "videos/s", "n_gpus": world, "rccl_ranks": len(g),
-                          "gather_ok": ok, "data": "none", "config": {"workload": "launcher + rendezvous + packed-id all-gather only"}}), flush=True)
+                          "gather_ok": ok, "data": "none", "config": {"workload": "launcher + rendezvous + packed-id all-gather only"},
+                          "per_rank": {"ms_per_step": [r[0] for r in per_rank], "rank": [int(r[1]) for r in per_rank], "cpus": [int(r[2]) for r in per_rank],
+                                       "host_placement_rank0": place}}), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
@@ -197,6 +205,9 @@ def main():
         raise SystemExit(f"{world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # host placement: each rank on the CPUs of its GPU's NUMA node (or an even slice of the allowed CPUs when the platform does not say): eight ranks
+    # issue ~75 k launches per decode batch each, from two threads — they must not share cores
+    place = tdist.bind_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     from trace_amd.engine import TraceEngine
 
     cfg = tcfg.tiny(args.frames) if args.tiny else tcfg.trace_7b(args.frames)
@@ -254,6 +265,8 @@ def main():
     tdist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     outs = run(args.steps)
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0                 # this rank's own K steps (before the closing barrier): the per-rank figure of the line
     tdist.barrier(); torch.cuda.synchronize()
     dt = tdist.max_over_ranks(time.perf_counter() - t0)
     out = outs[-1]
@@ -308,6 +321,10 @@ def main():
     one()                                            # captures the batch-1 decode graph
     t_one = ev_time(one)
 
+    # per-rank figures (a collective: every rank gets here): a sub-linear N-GPU curve must show which rank was slow and in which stage
+    rank_keys = ["ms_per_step", "vit_slotpool_per_video_ms", "prefill_per_video_ms", "decode_ms_per_step", "weights_load_s", "single_video_latency_ms", "numa_node"]
+    per_rank = tdist.gather_floats([dt_local / args.steps * 1e3, t_enc, t_pre, t_dec / (n_new - 1), t_load, t_one, float(place.get("numa_node", -1))])
+
     if rank == 0:
         vps = world * B * args.steps / dt
         vit_flops = args.frames * (366.0e9 if not args.tiny else 0.0)
@@ -320,8 +337,10 @@ def main():
             try:
                 tj = json.load(open(tf))
                 traffic, g_traffic, g_traffic_M = tj.get("skinny_gateup_bytes_per_launch"), tj.get("gemm_fc1_bytes_per_launch"), tj.get("gemm_fc1_M", 73856)
-                if B > 64:      # the wide decode step brackets the decode attention: the committed PMC pass measured it at one batch / context
+                if int(prof[8]) == 3:      # the wide decode step brackets the decode attention: the committed PMC pass measured it at one batch / context
                     traffic = tj.get("attn_decode_bytes_per_launch") if tj.get("attn_decode_batch") == B else None
+                elif int(prof[8]) != 1 or args.fp8:
+                    traffic = None
             except Exception:
                 traffic = g_traffic = None
         g_ms, g_n, g_gf = prof[5], int(prof[6]), prof[7]
@@ -345,6 +364,10 @@ def main():
                                          "(fill and drain inside the timed region; the roofline brackets are taken in the fill / drain phases only)"
                                          if pipelined else "steps strictly one after the other"),
                        "weights": "random-init (device RNG), reference architecture"},
+            "per_rank": {**{k: [round(r[i], 4) for r in per_rank] for i, k in enumerate(rank_keys)},
+                         "ms_per_step_min_median_max": [float(np.min([r[0] for r in per_rank])), float(np.median([r[0] for r in per_rank])), float(np.max([r[0] for r in per_rank]))],
+                         "host_placement_rank0": place,
+                         "note": "ms_per_step per rank = that rank's own K steps up to its own synchronize (before the closing barrier); `ms_per_step` of the line is the max over ranks with the barrier; stage times are re-timed per rank after the timed region"},
             "steps_repeat_exactly": bool(steps_repeat), **({"steps_repeat_detail": repeat_detail[:12]} if repeat_detail else {}),
             "decode_tok_s": world * B * (n_new - 1) / (t_dec * 1e-3),
             "stages_ms": {"vit_slotpool_per_video": t_enc, "prefill_per_video": t_pre, f"decode_{n_new - 1}_steps_batch{B}": t_dec,
@@ -353,10 +376,17 @@ def main():
             "mfma_util": {"vit": vit_flops / (t_enc * 1e-3) / 2.5e15, "prefill": pre_flops / (t_pre * 1e-3) / 2.5e15},
             # dominant kernel of the run: the 256x256 MFMA GEMM (its four epilogue variants are ~half of GPU time; the probe
             # brackets its largest instance, the ViT fc1 projection, once per video inside the timed region)
-            "roofline": {"bound": "mfma", "kernel": f"gemm_pers_kernel<EPI_QUICKGELU>, 256x256 tiles, persistent workgroups of 8 MFMA + 4 loader waves (ViT fc1 GEMM {g_M}x4096x1024 = one {eng.vit_batch_frames if B >= 2 else args.frames}-frame tower call, 1 bracketed launch per call)",
+            "roofline": {"bound": "mfma", "kernel": f"256x256-tile loader-wave MFMA GEMM family (8 MFMA + 4 loader waves per workgroup): by total time the run's top symbol is gemm_ldr_kernel<EPI_RESIDUAL> (ViT out-proj + fc2, prefill o / down); achieved / frac below are its largest single launch, gemm_pers_kernel<EPI_QUICKGELU, LN fold> = ViT fc1 {g_M}x4096x1024 of one {eng.vit_batch_frames if B >= 2 else args.frames}-frame tower call (1 bracketed launch per call); every ViT shape of the family is in `shapes`",
                          "achieved": g_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": (g_tf / 2500.0) if g_tf else None,
                          "traffic": g_traffic, "algorithmic_gflop_per_launch": g_gf, "algorithmic_bytes_per_launch": g_M * 1024 * 2 + 4096 * 1024 * 2 + g_M * 4096 * 2,
-                         "avg_launch_ms": g_ms, "samples": g_n},
+                         "avg_launch_ms": g_ms, "samples": g_n,
+                         "shapes": {name: {"kernel": sym, "MxNxK": f"{g_M}x{N_}x{K_}", "avg_launch_ms": ms_, "tflops": (gf_ / ms_) if ms_ > 0 else None,
+                                           "frac": (gf_ / ms_ / 2500.0) if ms_ > 0 else None}
+                                    for name, sym, N_, K_, ms_, gf_ in (
+                                        ("vit_qkv", "gemm_pers_kernel<EPI_NONE, LN fold>", 3072, 1024, prof[12], prof[15]),
+                                        ("vit_out_proj", "gemm_ldr_kernel<EPI_RESIDUAL> (+ row statistics)", 1024, 1024, prof[13], prof[16]),
+                                        ("vit_fc1", "gemm_pers_kernel<EPI_QUICKGELU, LN fold>", 4096, 1024, g_ms, g_gf),
+                                        ("vit_fc2", "gemm_ldr_kernel<EPI_RESIDUAL> (+ row statistics)", 1024, 4096, prof[14], prof[17]))}},
         }
         # dominant HBM-bound kernel of the decode phase
         # whole decode step: algorithmic bytes = the decoder weights once + the heads on the steps that stream them (not counted) + every sequence's KV rows
@@ -365,14 +395,19 @@ def main():
                                                  + 3 * cfg.hidden_size * cfg.intermediate_size) * (0.5 if args.fp8 else 1.0)
         line["decode_step"] = {"algorithmic_gb": (kv_step + w_step) / 1e9, "weights_gb": w_step / 1e9, "kv_gb": kv_step / 1e9,
                                "tb_per_s": (kv_step + w_step) / (t_dec / (n_new - 1) * 1e-3) / 1e12, "gb_per_token": (kv_step + w_step) / B / 1e9}
-        hbm_kernel = ("attn_decode_kernel (decode attention over the batch's KV cache, layer 0, 1 bracketed launch per decode step; wide decode step: "
-                      "projections as small-M MFMA GEMMs)" if B > 64 else
-                      "skinny_lds_kernel<EPI_PARTIAL,NB,NT=2> (decode gate|up GEMV, 1 bracketed launch per decode step)")
+        bkind = int(prof[8])            # which launch the engine put the decode bracket around (it knows which decode path the batch took)
+        hbm_kernel = {3: "attn_decode_kernel (decode attention over the batch's KV cache, layer 0, 1 bracketed launch per decode step; wide decode step: "
+                         "projections as small-M MFMA GEMMs)",
+                      2: "skinny_lds_kernel<EPI_PARTIAL, fused RMSNorm prologue> (batch-1 decode gate|up GEMV, 1 bracketed launch per decode step)",
+                      1: ("skinny_fp8_kernel (decode gate|up GEMV on e4m3 weights, 1 bracketed launch per decode step)" if args.fp8 else
+                          "skinny_lds_kernel<EPI_PARTIAL,NB,NT=2> (decode gate|up GEMV, 1 bracketed launch per decode step)")}.get(bkind, "none bracketed")
         line["roofline_hbm"] = {"bound": "hbm", "kernel": hbm_kernel,
                                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
                                 "traffic": traffic, "algorithmic_bytes_per_launch": k_bytes, "avg_launch_ms": k_ms, "samples": k_n}
         if world > 1:
-            line["cpu_baseline"] = None            # timed on rank 0 of the single-GPU run only
+            # timed on rank 0 of the single-GPU run only (the host cores are busy driving N ranks here): the N = 1 line of the same round carries it
+            line["cpu_baseline"] = {"value": None, "unit": "videos/s", "cores": None, "kind": "port",
+                                    "sample": "not re-timed under N > 1: inherited from the N = 1 run of the same bench.py on the same box (BENCH line)"}
         elif not args.no_cpu_baseline and not args.tiny:
             try:
                 cores = len(os.sched_getaffinity(0))

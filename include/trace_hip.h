@@ -144,8 +144,9 @@ int trace_decode_feed(trace_ctx* ctx, const int32_t* tokens, int B, void* stream
  * the next batch's ViT + prefill — MFMA-bound — can run on another stream into other KV slots; the stages share no buffers).
  * trace_stream_create: a HIP stream confined to cu_count CUs starting at logical CU cu_first (hipExtStreamCreateWithCUMask; mask bit i
  * is CU i / 8 of XCD i % 8, so a run of bits is spread evenly over the XCDs; cu_first and cu_count multiples of 8); cu_count == 0: an
- * ordinary non-blocking stream.  trace_set_gemm_cus: the persistent GEMM launches at most n workgroups (0 = the device's CU count) —
- * set it to the CU count of the stream the ViT / prefill GEMMs run on.  Streams are destroyed with trace_stream_destroy (idle). */
+ * ordinary non-blocking stream.  A CU-masked stream's persistent GEMMs launch at most cu_count workgroups (one per CU the stream can use);
+ * trace_set_gemm_cus overrides that number for the streams this context has created (n workgroups; 0 = the device's CU count) — it is a
+ * property of those streams and goes away with them.  Streams are destroyed with trace_stream_destroy (idle). */
 int trace_stream_create(trace_ctx* ctx, int cu_first, int cu_count, void** stream_out);
 int trace_stream_destroy(trace_ctx* ctx, void* stream);
 int trace_set_gemm_cus(trace_ctx* ctx, int n);
@@ -156,6 +157,10 @@ int trace_set_profile(trace_ctx* ctx, int on);
 /* Debugging aid: device addresses of the K cache, the V^T cache and the prefill's last-position hidden rows, with strides[8] = layer, slot, kv-head
  * strides (elements), ctx_pad, layers, kv heads, head_dim, hidden (tools/pipeline_stress.py checksums them between the pipeline's stages). */
 int trace_debug_buffers(trace_ctx* ctx, void** kcache, void** vcache, void** xlast, int64_t* strides);
+/* out[0..n) (n <= 20): [0] ms per decode step of the last trace_decode_steps call, [1] its steps, [2] average ms of the bracketed decode launch,
+ * [3] its samples, [4] its algorithmic bytes, [5] average ms of the bracketed ViT fc1 GEMM launch, [6] its samples, [7] its GFLOP,
+ * [8] which decode launch took the bracket: 1 = gate|up GEMV, 2 = batch-1 fused-norm gate|up GEMV, 3 = the wide step's layer-0 decode attention,
+ * [12..14] average ms of the bracketed ViT qkv / out-proj / fc2 GEMM launches (layer 0, the same calls as [5]), [15..17] their GFLOP. */
 int trace_get_profile(trace_ctx* ctx, float* out, int n);
 /* Which per-launch brackets profiling mode 2 takes: bit 0 = the ViT fc1 GEMM, bit 1 = the decode step's dominant kernel.  A pipelined caller
  * (two stages on two streams) leaves a stage's bracket on only while that stage has the GPU to itself (pipeline fill / drain). */

@@ -44,6 +44,20 @@ def test_fp16_library_exports_the_same_abi(lib):
         _lib.load("fp32")
 
 
+def test_error_text_comes_from_the_library_that_failed(lib):
+    """Each .so has its own thread-local error text: a failing call through the fp16 library must report ITS message, not the bf16 library's (round 3's
+    check() always asked libtrace_hip.so).  trace_ctx_create(NULL, ...) fails on the argument check, before any HIP call — safe without a GPU."""
+    from trace_amd import _lib
+    l16 = _lib.load("f16")
+    with pytest.raises(_lib.TraceHipError, match=r"libtrace_hip_f16\.so error -\d+ in trace_ctx_create: null argument"):
+        l16.trace_ctx_create(None, 0, None)
+    with pytest.raises(_lib.TraceHipError, match=r"libtrace_hip\.so error -\d+ in trace_ctx_create: null argument"):
+        lib.trace_ctx_create(None, 0, None)
+    assert _lib.check(0) == 0 and _lib.check(1) == 1
+    with pytest.raises(_lib.TraceHipError):
+        _lib.check(-2)
+
+
 def test_config_struct_matches_header():
     from trace_amd._lib import TraceConfigC
     hdr = open(os.path.join(ROOT, "include", "trace_hip.h")).read()
@@ -79,6 +93,18 @@ def test_engine_fails_loudly_without_gpu():
     from trace_amd._lib import TraceHipError
     with pytest.raises(TraceHipError, match="no CPU fallback"):
         TraceEngine(tcfg.tiny())
+
+
+def test_engine_rejects_unknown_fp8_scheme():
+    """llm_fp8 takes False / True / 'w8a8' / 'weight_only' only: a typo must not silently select a numerics scheme (checked before any device work)."""
+    import torch
+    from trace_amd import config as tcfg
+    from trace_amd.engine import TraceEngine
+    for bad in ("weight-only", "w8", 2, "fp8"):
+        with pytest.raises(ValueError, match="llm_fp8 must be"):
+            TraceEngine(tcfg.tiny(), llm_fp8=bad)
+    with pytest.raises(ValueError, match="bf16 library only"):
+        TraceEngine(tcfg.tiny(), llm_fp8="weight_only", dtype=torch.float16)
 
 
 def test_header_is_plain_c_and_example_links(lib, tmp_path):

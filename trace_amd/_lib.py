@@ -87,6 +87,7 @@ SIGNATURES = {
     "trace_op_attn_decode": (I, [P, P, P, P, P, P, I, I, I, I, I, F, P]),
 }
 
+NOT_A_STATUS = {"trace_abi_version", "trace_element_type", "trace_op_skinny_ks", "trace_op_sk_rows", "trace_op_gemm_partial_ks"}   # ints that are values
 _libs = {}
 
 
@@ -110,10 +111,19 @@ def load(element: str = "bf16"):
             f"{path} is missing: build it with `python -m trace_amd.build` (hipcc, gfx950). "
             "trace_amd has no CPU or PyTorch fallback for the hot path.")
     lib = C.CDLL(path)
+
+    def errcheck(rc, fn, args):        # a negative status becomes an exception carrying THIS library's message (each .so has its own thread-local text)
+        if rc < 0:
+            msg = lib.trace_last_error()
+            raise TraceHipError(f"{os.path.basename(path)} error {rc} in {fn.__name__}: {msg.decode() if msg else '?'}")
+        return rc
+
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+        if res is I and name not in NOT_A_STATUS:
+            fn.errcheck = errcheck
     if lib.trace_abi_version() != 3:
         raise TraceHipError(f"{os.path.basename(path)} ABI version mismatch")
     if lib.trace_element_type() != {"bf16": 0, "f16": 1}[element]:
@@ -133,7 +143,9 @@ def element_of(dtype) -> str:
 
 
 def check(rc: int) -> int:
+    """Status of a C-ABI call.  Every status-returning entry point already raises through its library's own errcheck (load()), with the message of
+    the .so that returned it; this stays as the call-site idiom and as a backstop for a status obtained some other way — it never dlopens anything."""
     if rc < 0:
-        msg = load().trace_last_error()
-        raise TraceHipError(f"libtrace_hip error {rc}: {msg.decode() if msg else '?'}")
+        msgs = [m.decode() for m in (lib.trace_last_error() for lib in _libs.values()) if m]
+        raise TraceHipError(f"libtrace_hip error {rc}: {' | '.join(msgs) if msgs else '?'}")
     return rc

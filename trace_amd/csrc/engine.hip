@@ -120,7 +120,13 @@ struct trace_ctx {
     double ksum_ms = 0.0; int ksamples = 0;
     hipEvent_t mev0 = nullptr, mev1 = nullptr;   // bracket of one ViT fc1 GEMM launch per trace_vit_forward (profile == 2)
     double msum_ms = 0.0; int msamples = 0; double mflops = 0.0; int mM = 0;
-    float prof[8] = {0};
+    // the other three GEMM shapes of the layer (qkv, out-proj, fc2), bracketed the same way in layer 0: the 256x256 MFMA GEMM family is the run's
+    // dominant kernel and its four shapes sit at different fractions of the peak — the line reports each (pairs 0 = qkv, 1 = out-proj, 2 = fc2)
+    hipEvent_t vev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double vsum_ms[3] = {0.0, 0.0, 0.0}; double vflops[3] = {0.0, 0.0, 0.0};
+    float prof[20] = {0};
+    int bracket_kind = 0;             // which launch the decode bracket of profile == 2 was put around: 0 none yet, 1 = gate|up GEMV (skinny path), 2 = the fused-norm
+                                      // gate|up GEMV of a batch-1 step, 3 = the wide step's layer-0 decode attention
 };
 
 template <typename T>
@@ -297,6 +303,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
     hipEventCreate(&c->gev0); hipEventCreate(&c->gev1);
     hipEventCreate(&c->mev0); hipEventCreate(&c->mev1);
+    for (auto& e : c->vev) hipEventCreate(&e);
     c->kev.resize(1024);
     for (auto& e : c->kev) hipEventCreate(&e);
     if (device_id >= 0 && device_id < 16) { g_ctx_per_dev[device_id] += 1; c->counted = true; }
@@ -307,9 +314,10 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
 extern "C" int trace_ctx_destroy(trace_ctx* c) {
     if (!c) return TRACE_OK;
     hipDeviceSynchronize();
-    for (auto& st : c->streams) hipStreamDestroy(st);
+    for (auto& st : c->streams) { gemm_pers_forget(st); hipStreamDestroy(st); }
     for (auto& g : c->graphs) if (g) hipGraphExecDestroy(g);
     for (auto& e : c->kev) if (e) hipEventDestroy(e);
+    for (auto& e : c->vev) if (e) hipEventDestroy(e);
     if (c->mev0) hipEventDestroy(c->mev0);
     if (c->mev1) hipEventDestroy(c->mev1);
     if (c->gev0) hipEventDestroy(c->gev0);
@@ -604,47 +612,65 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
     if (fold) LCHK(launch_ln_row_stats(c->vX, vh, Mv, vh, c->c.v_eps, c->vStats, s));       // layer 0's input came from vit_assemble, not from a GEMM
     for (int l = 0; l < c->vL; ++l) {
         const VitLayer& L = c->vit[l];
+        // MFMA roofline probe (profile == 2): HIP events around ONE launch of each of the layer's four GEMM shapes, in layer 0, per call — of the
+        // largest call shape seen since trace_set_profile only (the short tail call of a frame stream would mix two shapes into one average).
+        // The fc1 pair (mev0 / mev1) is the `roofline` object's bracket; pairs 0..2 of vev are qkv, out-proj and fc2.
+        const bool vprof = c->profile == 2 && (c->bracket_mask & 1);
+        if (l == 0 && vprof && Mv > c->mM) { c->mM = Mv; c->msum_ms = 0.0; c->msamples = 0; c->vsum_ms[0] = c->vsum_ms[1] = c->vsum_ms[2] = 0.0; }
+        const bool probe = (l == 0 && vprof && Mv == c->mM);
+#define VPROBE_BEGIN(i) if (probe) hipEventRecord(c->vev[2 * (i)], s)
+#define VPROBE_END(i, N_, K_) if (probe) { hipEventRecord(c->vev[2 * (i) + 1], s); c->vflops[i] = 2.0 * Mv * (double)(N_) * (K_); }
         if (fold) {
+            VPROBE_BEGIN(0);
             TRY(fgemm(c->vX, vh, L.wqkv_f, vh, c->vQKV, 3 * vh, L.c2q, L.c1q, nullptr, 3 * vh, vh, EPI_NONE, nullptr));
+            VPROBE_END(0, 3 * vh, vh);
             if (a.v_perm != 2)
                 LCHK(launch_transpose_v(c->vQKV + 2 * vh, (long)NT * 3 * vh, 64, 3 * vh, c->vVT, a.v_bs, a.v_hs, c->tokpad, NT, 64, c->vheads, T, s, a.v_perm));
             LCHK(launch_attn_vit(a, s));
+            VPROBE_BEGIN(1);
             TRY(fgemm(c->vH, vh, L.wo, vh, c->vX, vh, L.bo, nullptr, c->vX, vh, vh, EPI_RESIDUAL, c->vStatsPart));
+            VPROBE_END(1, vh, vh);
             LCHK(launch_ln_stats_finalize(c->vStatsPart, vh / 256, Mv, vh, c->c.v_eps, c->vStats, s));
-            if (l == 0 && c->profile == 2 && (c->bracket_mask & 1) && Mv > c->mM) { c->mM = Mv; c->msum_ms = 0.0; c->msamples = 0; }
-            const bool probe = (l == 0 && c->profile == 2 && (c->bracket_mask & 1) && Mv == c->mM);
             if (probe) hipEventRecord(c->mev0, s);
             TRY(fgemm(c->vX, vh, L.w1_f, vh, c->vMLP, vi, L.c2f, L.c1f, nullptr, vi, vh, EPI_QUICKGELU, nullptr));
             if (probe) { hipEventRecord(c->mev1, s); c->mflops = 2.0 * Mv * (double)vi * vh; }
+            VPROBE_BEGIN(2);
             TRY(fgemm(c->vMLP, vi, L.w2, vi, c->vX, vh, L.b2, nullptr, c->vX, vh, vi, EPI_RESIDUAL, c->vStatsPart));
+            VPROBE_END(2, vh, vi);
             if (l + 1 < c->vL) LCHK(launch_ln_stats_finalize(c->vStatsPart, vh / 256, Mv, vh, c->c.v_eps, c->vStats, s));
             continue;
         }
         LCHK(launch_layernorm(c->vX, vh, c->vH, vh, L.ln1w, L.ln1b, Mv, vh, c->c.v_eps, s));
+        VPROBE_BEGIN(0);
         TRY(gemm(c->vH, vh, L.wqkv, vh, c->vQKV, 3 * vh, L.bqkv, nullptr, 0, Mv, 3 * vh, vh, EPI_NONE, s));
+        VPROBE_END(0, 3 * vh, vh);
         if (a.v_perm != 2)
             LCHK(launch_transpose_v(c->vQKV + 2 * vh, (long)NT * 3 * vh, 64, 3 * vh, c->vVT, a.v_bs, a.v_hs, c->tokpad, NT, 64,
                                     c->vheads, T, s, a.v_perm));
         LCHK(launch_attn_vit(a, s));
+        VPROBE_BEGIN(1);
         TRY(gemm(c->vH, vh, L.wo, vh, c->vX, vh, L.bo, c->vX, vh, Mv, vh, vh, EPI_RESIDUAL, s));
+        VPROBE_END(1, vh, vh);
         LCHK(launch_layernorm(c->vX, vh, c->vH, vh, L.ln2w, L.ln2b, Mv, vh, c->c.v_eps, s));
-        // MFMA roofline probe: HIP events around ONE fc1 GEMM launch per call — of the largest shape seen since
-        // trace_set_profile only (the short tail call of a frame stream would mix two shapes into one average)
-        const bool vprof = c->profile == 2 && (c->bracket_mask & 1);
-        if (l == 0 && vprof && Mv > c->mM) { c->mM = Mv; c->msum_ms = 0.0; c->msamples = 0; }
-        const bool probe = (l == 0 && vprof && Mv == c->mM);
         if (probe) hipEventRecord(c->mev0, s);
         TRY(gemm(c->vH, vh, L.w1, vh, c->vMLP, vi, L.b1, nullptr, 0, Mv, vi, vh, EPI_QUICKGELU, s));
         if (probe) { hipEventRecord(c->mev1, s); c->mflops = 2.0 * Mv * (double)vi * vh; }
+        VPROBE_BEGIN(2);
         TRY(gemm(c->vMLP, vi, L.w2, vi, c->vX, vh, L.b2, c->vX, vh, Mv, vh, vi, EPI_RESIDUAL, s));
+        VPROBE_END(2, vh, vi);
+#undef VPROBE_BEGIN
+#undef VPROBE_END
     }
     if (c->profile == 2 && (c->bracket_mask & 1) && c->vL > 0 && Mv == c->mM) {
-        hipEventSynchronize(c->mev1);
+        hipEventSynchronize(c->vev[5]);                       // layer 0's fc2: the last of the bracketed launches
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->mev0, c->mev1) == hipSuccess) { c->msum_ms += ms; c->msamples += 1; }
+        for (int i = 0; i < 3; ++i)
+            if (hipEventElapsedTime(&ms, c->vev[2 * i], c->vev[2 * i + 1]) == hipSuccess) c->vsum_ms[i] += ms;
         c->prof[5] = (float)(c->msum_ms / c->msamples);
         c->prof[6] = (float)c->msamples;
         c->prof[7] = (float)(c->mflops / 1e9);               // GFLOP of the bracketed launch
+        for (int i = 0; i < 3; ++i) { c->prof[12 + i] = (float)(c->vsum_ms[i] / c->msamples); c->prof[15 + i] = (float)(c->vflops[i] / 1e9); }
     }
     if (feats_out)   // drop CLS: [T, GG, vh]
         HIPCHK(hipMemcpy2DAsync(feats_out, (size_t)GG * vh * 2, c->vX + vh, (size_t)NT * vh * 2, (size_t)GG * vh * 2, T,
@@ -1066,6 +1092,7 @@ static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
         if (l == 0 && c->profile == 2 && (c->bracket_mask & 2) && s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) {
             e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2;
             c->kbytes_sum += (double)(c->pos_sum + (long)B * (c->step_in_call + 1)) * c->NKV * HD * 2 * 2;   // K + V^T rows of every sequence, bf16
+            c->bracket_kind = 3;
         }
         if (e0) hipEventRecord(e0, s);
         LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots, c->d_pos, c->dO,
@@ -1113,6 +1140,7 @@ static int decode_step_fused(trace_ctx* c, float* logits_out, hipStream_t s) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (l == 0 && c->profile == 2 && (c->bracket_mask & 2) && s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) {
             e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2;
+            c->bracket_kind = 2;
         }
         if (e0) hipEventRecord(e0, s);
         LCHK(launch_skinny_gemm_fused_norm(c->sk_ws, ks_o, xa, H, xb, H, W.rms2, c->c.rms_eps, W.wgu_d, B, 2 * I, H, c->sk_ws2, c->sk_ws_floats, s));
@@ -1178,7 +1206,7 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (l == 0 && c->profile == 2 && (c->bracket_mask & 2)) {
             // (event-record nodes captured into a hipGraph do not yield usable timestamps on ROCm 7.2: eager launches only)
-            if (s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) { e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2; }
+            if (s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) { e0 = c->kev[c->kev_used]; e1 = c->kev[c->kev_used + 1]; c->kev_used += 2; c->bracket_kind = 1; }
         }
         if (e0) hipEventRecord(e0, s);
         if (wo) { GEMVW(c->dH, W.wgu8_d, W.sgu, 2 * I, H) }
@@ -1285,8 +1313,12 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
         c->prof[1] = (float)n;
         c->prof[2] = c->ksamples ? (float)(c->ksum_ms / c->ksamples) : 0.f;
         c->prof[3] = (float)c->ksamples;
-        c->prof[4] = (float)(2.0 * c->I * c->H * (c->fp8 ? 1.0 : 2.0));      // algorithmic bytes of the bracketed launch (gate|up weights; fp8: the bracket also spans the activation quantiser)
-        if (c->B > SKINNY_ROWS && c->ksamples) c->prof[4] = (float)(c->kbytes_sum / c->ksamples);   // wide step: the bracket is the layer-0 attention (its KV bytes, averaged)
+        // algorithmic bytes of the bracketed launch, by WHICH launch took the bracket (bracket_kind — not by the batch size: the wide step starts at
+        // g_decode_wide_min rows, below SKINNY_ROWS): the gate|up weights (fp8: the bracket also spans the activation quantiser), or the layer-0
+        // attention's KV rows averaged over the bracketed steps
+        c->prof[4] = (float)(2.0 * c->I * c->H * (c->fp8 ? 1.0 : 2.0));
+        if (c->bracket_kind == 3 && c->ksamples) c->prof[4] = (float)(c->kbytes_sum / c->ksamples);
+        c->prof[8] = (float)c->bracket_kind;
     }
     return TRACE_OK;
 }
@@ -1341,6 +1373,7 @@ extern "C" int trace_stream_create(trace_ctx* c, int cu_first, int cu_count, voi
         HIPCHK(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
     }
     if (gemm_pers_init(s) != TRACE_OK) { hipStreamDestroy(s); return fail(TRACE_ERR_HIP, "persistent GEMM ticket counters"); }
+    if (cu_count > 0) gemm_pers_set_cap(s, cu_count);          // a CU-masked stream: its persistent GEMMs launch one workgroup per CU IT can use
     c->streams.push_back(s);
     *stream_out = (void*)s;
     return TRACE_OK;
@@ -1350,13 +1383,17 @@ extern "C" int trace_stream_destroy(trace_ctx* c, void* stream) {
     auto it = std::find(c->streams.begin(), c->streams.end(), (hipStream_t)stream);
     if (it == c->streams.end()) return fail(TRACE_ERR_ARG, "not a stream of this context");
     HIPCHK(hipStreamSynchronize(*it));
+    gemm_pers_forget(*it);
     HIPCHK(hipStreamDestroy(*it));
     c->streams.erase(it);
     return TRACE_OK;
 }
 extern "C" int trace_set_gemm_cus(trace_ctx* c, int n) {
     if (!c || n < 0) return fail(TRACE_ERR_ARG, "bad argument");
-    g_gemm_pers_grid_cap = n;
+    // per stream, and only this context's streams (trace_stream_create already sets a CU-masked stream's cap to its CU count; this overrides it).
+    // Until round 3 this wrote a process-wide number that nothing reset: every later persistent GEMM of the process stayed capped.
+    for (hipStream_t st : c->streams)
+        if (gemm_pers_set_cap(st, n) != TRACE_OK) return fail(TRACE_ERR_HIP, "persistent GEMM ticket counters");
     return TRACE_OK;
 }
 
@@ -1371,7 +1408,7 @@ extern "C" int trace_debug_buffers(trace_ctx* c, void** kcache, void** vcache, v
 
 extern "C" int trace_set_profile(trace_ctx* c, int on) {
     if (!c) return fail(TRACE_ERR_ARG, "null ctx");
-    c->profile = on; c->ksum_ms = 0.0; c->ksamples = 0; c->kev_used = 0; c->kbytes_sum = 0.0; c->msum_ms = 0.0; c->msamples = 0; c->mM = 0;
+    c->profile = on; c->bracket_kind = 0; c->ksum_ms = 0.0; c->ksamples = 0; c->kev_used = 0; c->kbytes_sum = 0.0; c->msum_ms = 0.0; c->msamples = 0; c->mM = 0;
     return TRACE_OK;
 }
 extern "C" int trace_set_profile_brackets(trace_ctx* c, int mask) {
@@ -1381,7 +1418,7 @@ extern "C" int trace_set_profile_brackets(trace_ctx* c, int mask) {
 }
 extern "C" int trace_get_profile(trace_ctx* c, float* out, int n) {
     if (!c || !out) return fail(TRACE_ERR_ARG, "null argument");
-    for (int i = 0; i < n && i < 8; ++i) out[i] = c->prof[i];
+    for (int i = 0; i < n && i < 20; ++i) out[i] = c->prof[i];
     return TRACE_OK;
 }
 

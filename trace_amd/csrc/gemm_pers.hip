@@ -607,9 +607,10 @@ struct CtrKey {
     bool operator==(const CtrKey& o) const { return dev == o.dev && s == o.s; }
 };
 struct CtrHash { size_t operator()(const CtrKey& k) const { return std::hash<const void*>()((const void*)k.s) * 31u + (size_t)k.dev; } };
-std::unordered_map<CtrKey, int*, CtrHash> g_ctrs;
+struct CtrState { int* ctr; int cap; };           // cap > 0: at most this many workgroups per launch on this stream (a CU-masked stream)
+std::unordered_map<CtrKey, CtrState, CtrHash> g_ctrs;
 // nullptr: the counters do not exist yet and cannot be made now (the stream is capturing: no allocation / memset inside a capture) or HIP failed
-int* counters_for(hipStream_t s, int* ncu_out) {
+CtrState* counters_for(hipStream_t s, int* ncu_out) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
     std::lock_guard<std::mutex> lk(g_ctr_mu);
@@ -620,14 +621,13 @@ int* counters_for(hipStream_t s, int* ncu_out) {
     }
     if (ncu_out) *ncu_out = g_ncu[dev];
     auto it = g_ctrs.find(CtrKey{dev, s});
-    if (it != g_ctrs.end()) return it->second;
+    if (it != g_ctrs.end()) return &it->second;           // (node-based map: the address stays valid across later insertions)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
     int* c = nullptr;
     if (hipMalloc(&c, 8 * CTR_STRIDE * sizeof(int)) != hipSuccess) return nullptr;
     if (hipMemsetAsync(c, 0, 8 * CTR_STRIDE * sizeof(int), s) != hipSuccess) { (void)hipFree(c); return nullptr; }   // ordered before the launch
-    g_ctrs[CtrKey{dev, s}] = c;
-    return c;
+    return &(g_ctrs[CtrKey{dev, s}] = CtrState{c, 0});
 }
 
 template <int EPI, int OPT>
@@ -661,17 +661,34 @@ int g_gemm_pers_static = 0;        // 1: tiles dealt round-robin instead of by t
 int g_gemm_pers_walk = 0;          // every route, the LayerNorm-fold launches included (trace_op_set_gemm_variant(500 + w)): 0 = tickets, atomic re-arm;
                                    // 1 = static deal; 2 = tickets with round 3's plain-store re-arm (the stress tool's positive control)
 
-int g_gemm_pers_grid_cap = 0;      // > 0: at most this many workgroups per launch (a stream confined to part of the CUs by a CU mask: the
+int g_gemm_pers_grid_cap = 0;      // tuning knob (trace_op_set_gemm_variant(1000 + n)); streams carry their own cap: gemm_pers_set_cap.  > 0: at most this many workgroups per launch (a stream confined to part of the CUs by a CU mask: the
                                    // persistent grid must not exceed the CUs it can run on, or the surplus workgroups wait for a second round)
 
 // Creates the ticket counters of a stream ahead of its first launch (an allocation + a memset: not something to meet inside a timed or
 // captured region); launch_gemm_pers does it on demand otherwise.
 int gemm_pers_init(hipStream_t s) { return counters_for(s, nullptr) ? TRACE_OK : TRACE_ERR_HIP; }
+// The persistent grid of launches on stream `s` is at most `cap` workgroups (0 = the device's CU count): a stream confined to part of the CUs by a
+// CU mask must not be handed more workgroups than it can run at once, or the surplus waits for a second round.  Lives with the stream's counters
+// (until round 3 this was one process-wide number that outlived the streams it was set for).
+int gemm_pers_set_cap(hipStream_t s, int cap) {
+    CtrState* st = counters_for(s, nullptr);
+    if (!st || cap < 0) return TRACE_ERR_HIP;
+    st->cap = cap;
+    return TRACE_OK;
+}
+// forgets one stream's counters (the stream is about to be destroyed and idle; a later stream may get the same handle value)
+void gemm_pers_forget(hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_ctr_mu);
+    auto it = g_ctrs.find(CtrKey{dev, s});
+    if (it != g_ctrs.end()) { (void)hipFree(it->second.ctr); g_ctrs.erase(it); }
+}
 // Frees the counters of every stream of `dev` (the last context on a device going away; the device must be idle)
 void gemm_pers_release(int dev) {
     std::lock_guard<std::mutex> lk(g_ctr_mu);
     for (auto it = g_ctrs.begin(); it != g_ctrs.end();) {
-        if (it->first.dev == dev) { (void)hipFree(it->second); it = g_ctrs.erase(it); }
+        if (it->first.dev == dev) { (void)hipFree(it->second.ctr); it = g_ctrs.erase(it); }
         else ++it;
     }
 }
@@ -682,9 +699,11 @@ int launch_gemm_pers(const GemmArgs& p, int epi, hipStream_t s) {
     if (p.stats && (!p.c1 || !p.bias || (epi != EPI_NONE && epi != EPI_QUICKGELU))) return TRACE_ERR_ARG;      // LN fold: c1, c2 (= bias) and the row statistics
     if ((long)p.M * p.ldc >= (1L << 30) || (epi == EPI_RESIDUAL && (long)p.M * p.ldr >= (1L << 30))) return TRACE_ERR_ARG;   // 32-bit byte offsets
     int ncu = 0;
-    int* ctr = counters_for(s, &ncu);
-    if (!ctr) return TRACE_ERR_STATE;
-    if (g_gemm_pers_grid_cap > 0 && g_gemm_pers_grid_cap < ncu) ncu = g_gemm_pers_grid_cap < 8 ? 8 : g_gemm_pers_grid_cap;   // every XCD keeps a workgroup: tiles are dealt per XCD
+    CtrState* st = counters_for(s, &ncu);
+    if (!st) return TRACE_ERR_STATE;
+    int* ctr = st->ctr;
+    const int cap = st->cap > 0 ? st->cap : g_gemm_pers_grid_cap;      // the stream's own cap (CU-masked streams), else the process-wide tuning knob
+    if (cap > 0 && cap < ncu) ncu = cap < 8 ? 8 : cap;                 // every XCD keeps a workgroup: tiles are dealt per XCD
     const int total = ((p.M + BM - 1) / BM) * (p.N / BN);
     // g_gemm_pers_static == 2: one workgroup per tile (the dispatcher places them as CUs free up, nothing persists): this kernel's K loop and
     // register epilogue without the tile walk (A/B runs)

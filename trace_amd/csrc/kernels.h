@@ -39,6 +39,8 @@ int gemm_partial_ks(int N, int K);                                // K-chunks la
 int launch_gemm_ldr(const GemmArgs& p, int epi, hipStream_t s);    // gemm_ldr.hip: 256x256 tiles, 8 MFMA + 4 loader waves (N % 256 == 0)
 int launch_gemm_pers(const GemmArgs& p, int epi, hipStream_t s);   // gemm_pers.hip: the same tile, persistent workgroups, register epilogue (bf16, K >= 128)
 int gemm_pers_init(hipStream_t s);                                 // creates the (current device, stream) ticket counters ahead of its first launch (optional)
+int gemm_pers_set_cap(hipStream_t s, int cap);                       // at most `cap` workgroups per persistent launch on this stream (0 = #CUs)
+void gemm_pers_forget(hipStream_t s);                               // drops one (idle) stream's counters before the stream is destroyed
 void gemm_pers_release(int dev);                                   // frees every stream's counters of a device (last context on it destroyed)
 
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_SIGMOID = 2, ACT_GELU = 3 };

@@ -82,3 +82,92 @@ def max_over_ranks(x: float) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(vec: Sequence[float]) -> List[List[float]]:
+    """All-gather of a short float vector -> [world][len(vec)] (per-rank timings for the bench line: a sub-linear scaling curve
+    has to show WHICH rank was slow, and in which stage)."""
+    v = [float(x) for x in vec]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [v]
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor(v, dtype=torch.float64, device=dev)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.cpu().tolist() for o in out]
+
+
+# ---- host placement of the ranks -----------------------------------------------------------------------------------------
+def parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' (sysfs cpulist) -> [0, 1, 2, 3, 8, 10, 11]"""
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out += list(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def numa_node_of_pci(bdf: str, sysfs: str = "/sys") -> int:
+    """NUMA node of a PCI function ('0000:c1:00.0'); -1 when the platform does not say (single node, VM)."""
+    try:
+        with open(os.path.join(sysfs, "bus", "pci", "devices", bdf.lower(), "numa_node")) as f:
+            return int(f.read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
+def cpus_of_numa_node(node: int, sysfs: str = "/sys") -> List[int]:
+    try:
+        with open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")) as f:
+            return parse_cpulist(f.read())
+    except (OSError, ValueError):
+        return []
+
+
+def gpu_pci_bdf(local_rank: int) -> str | None:
+    """PCI address of HIP device `local_rank` as sysfs spells it, or None (no GPU / torch too old to say)."""
+    if not torch.cuda.is_available():
+        return None
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+    except Exception:
+        return None
+
+
+def plan_affinity(allowed: Sequence[int], local_rank: int, local_world: int, node_cpus: Sequence[int]) -> Tuple[List[int], str]:
+    """Which CPUs rank `local_rank` of `local_world` on this host should run on -> (cpus, how).  With a known NUMA node for its GPU: that
+    node's CPUs (those the process may use), shared by the ranks whose GPUs sit on the node.  Otherwise the allowed CPUs are cut into
+    `local_world` equal contiguous slices, so that eight ranks' Python threads do not pile onto the same cores.  One rank alone is left as it is."""
+    allowed = sorted(set(int(c) for c in allowed))
+    if local_world <= 1 or not allowed:
+        return list(allowed), "unchanged (single rank)"
+    on_node = [c for c in allowed if c in set(node_cpus)]
+    if on_node:
+        return on_node, "cpus of the GPU's NUMA node"
+    n = len(allowed) // local_world
+    if n < 1:
+        return list(allowed), "unchanged (fewer CPUs than ranks)"
+    return allowed[local_rank * n:(local_rank + 1) * n], f"even slice {local_rank + 1}/{local_world} of the allowed CPUs (NUMA node unknown)"
+
+
+def bind_rank(local_rank: int, local_world: int, sysfs: str = "/sys") -> dict:
+    """Pins this process to the CPUs plan_affinity picks for its GPU; never fails the run (returns what it did)."""
+    info = {"numa_node": -1, "cpus": None, "how": "unchanged"}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return info
+    bdf = gpu_pci_bdf(local_rank)
+    node = numa_node_of_pci(bdf, sysfs) if bdf else -1
+    cpus, how = plan_affinity(allowed, local_rank, local_world, cpus_of_numa_node(node, sysfs) if node >= 0 else [])
+    info.update(numa_node=node, how=how, pci=bdf)
+    try:
+        if cpus and cpus != allowed:
+            os.sched_setaffinity(0, cpus)
+        info["cpus"] = f"{len(cpus)} cpus: {cpus[0]}..{cpus[-1]}" if cpus else None
+    except OSError as e:
+        info["how"] = f"unchanged (sched_setaffinity: {e})"
+    return info

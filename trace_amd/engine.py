@@ -30,15 +30,25 @@ def _i32(seq) -> "C.Array":
 class TraceEngine:
     def __init__(self, cfg: TraceConfig, device: int = 0, max_batch: int = 1, max_ctx: Optional[int] = None,
                  max_frames: Optional[int] = None, max_new_tokens: int = 1024, vit_batch_frames: Optional[int] = None,
-                 llm_fp8: bool = False, dtype: torch.dtype = torch.bfloat16):
+                 llm_fp8=False, dtype: torch.dtype = torch.bfloat16):
         """dtype: the 16-bit element type everything is stored and multiplied in — torch.bfloat16 (libtrace_hip.so; north_star's configs) or
         torch.float16 (libtrace_hip_f16.so: the reference's own inference dtype, trace/model/builder.py:50,127,147); accumulation is fp32 in both."""
+        # llm_fp8: False / None = bf16 weights; "w8a8" (True is accepted as its alias) = W8A8 prefill GEMMs and decode GEMVs; "weight_only" = W8A8
+        # prefill GEMMs, weight-only decode GEMVs (bf16 activations).  Anything else is an error — a typo must not silently pick a numerics scheme.
+        if llm_fp8 in (False, None):
+            self.fp8_scheme = None
+        elif llm_fp8 is True or llm_fp8 == "w8a8":
+            self.fp8_scheme = "w8a8"
+        elif llm_fp8 == "weight_only":
+            self.fp8_scheme = "weight_only"
+        else:
+            raise ValueError(f"llm_fp8 must be False, True / 'w8a8' or 'weight_only', got {llm_fp8!r}")
+        if self.fp8_scheme and dtype != torch.bfloat16:
+            raise ValueError("the fp8 weight path exists in the bf16 library only")
         if not torch.cuda.is_available():
             raise _lib.TraceHipError("no HIP device visible: the TRACE hot path only runs on an MI355X (no CPU fallback)")
         self.dtype = dtype
         self.lib = _lib.load(_lib.element_of(dtype))
-        if llm_fp8 and dtype != torch.bfloat16:
-            raise ValueError("the fp8 weight path exists in the bf16 library only")
         self.cfg = cfg
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
@@ -58,8 +68,8 @@ class TraceEngine:
             cfg.vision_image_size, cfg.vision_patch_size, cfg.vision_layer_norm_eps, cfg.num_slots, cfg.slot_ln_eps,
             cfg.slot_rope_base, max_frames, max_ctx, max_batch, max_new_tokens,
             1 if cfg.mm_projector_type == "stc_connector" else 0, self.vit_batch_frames,
-            {"w8a8": 1, "weight_only": 2}.get(llm_fp8, 1 if llm_fp8 else 0) if llm_fp8 else 0)
-        self.llm_fp8 = bool(llm_fp8)          # False / True = "w8a8" / "weight_only" (W8A8 prefill GEMMs, weight-only decode GEMVs)
+            {None: 0, "w8a8": 1, "weight_only": 2}[self.fp8_scheme])
+        self.llm_fp8 = self.fp8_scheme is not None
         h = C.c_void_p()
         _lib.check(self.lib.trace_ctx_create(C.byref(c), device, C.byref(h)))
         self.h = h
@@ -323,8 +333,8 @@ class TraceEngine:
         _lib.check(self.lib.trace_set_profile(self.h, int(mode)))
 
     def get_profile(self) -> List[float]:
-        buf = (C.c_float * 8)()
-        _lib.check(self.lib.trace_get_profile(self.h, buf, 8))
+        buf = (C.c_float * 20)()
+        _lib.check(self.lib.trace_get_profile(self.h, buf, 20))
         return list(buf)
 
     # ---- one-call convenience: what generate() does for one batch of videos ----------------------
@@ -415,8 +425,8 @@ class TraceEngine:
     # ---- two-stage pipeline over a stream of batches ---------------------------------------------------
     def make_streams(self, decode_cus: int = 0):
         """The pipeline's (encode stream, decode stream).  decode_cus > 0 confines the decode stream to that many CUs and the encode
-        stream to the rest (trace_stream_create: CU-masked HIP streams, spread evenly over the 8 XCDs) and caps the persistent GEMM's
-        grid at the encode stream's CU count (trace_set_gemm_cus): the MFMA-bound GEMMs
+        stream to the rest (trace_stream_create: CU-masked HIP streams, spread evenly over the 8 XCDs; the persistent GEMM's grid on such a
+        stream is capped at the stream's CU count): the MFMA-bound GEMMs
         and the HBM-bound decode kernels then run side by side instead of taking turns on the whole chip."""
         if decode_cus <= 0:
             return torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
@@ -427,8 +437,7 @@ class TraceEngine:
             h = C.c_void_p()
             _lib.check(self.lib.trace_stream_create(self.h, lo, n, C.byref(h)))
             return torch.cuda.ExternalStream(h.value, device=self.device)
-        dec, enc = masked(0, decode_cus), masked(decode_cus, ncu - decode_cus)
-        _lib.check(self.lib.trace_set_gemm_cus(self.h, ncu - decode_cus))
+        dec, enc = masked(0, decode_cus), masked(decode_cus, ncu - decode_cus)      # (trace_stream_create caps each stream's persistent GEMMs at its CU count)
         return enc, dec
 
     def generate_stream(self, batches: Iterable, max_new_tokens: int, eos: int = -1, use_graph: bool = True, streams=None):
@@ -460,35 +469,35 @@ class TraceEngine:
         # profiling mode 2 brackets single launches with HIP events: meaningful only while a stage has the GPU to itself — the first batch's
         # encode (pipeline fill) and the last batch's decode (drain); in between the brackets are off
         brackets = lambda m: _lib.check(self.lib.trace_set_profile_brackets(self.h, m))
-        with cf.ThreadPoolExecutor(max_workers=1, thread_name_prefix="trace-decode") as pool:
-            for item in batches:
-                videos, timestamps, input_ids, heads, forced = item
-                if len(videos) > min(half, self.decode_batch_max):
-                    raise ValueError(f"batch of {len(videos)} exceeds max_batch // 2 = {half} (two KV banks)")
-                brackets(1 if pending is None else 0)
-                fut = pool.submit(dec_job, *pending) if pending is not None else None
-                enc_s.wait_stream(cur)                  # the batch's frames may have been made on the caller's stream (device preprocessing)
-                try:
-                    with torch.cuda.stream(enc_s):
-                        self.encode_prefill(videos, timestamps, input_ids, bank * half)
-                        if self._dbg is not None:
-                            self._dbg("prefilled", bank * half, None)
-                        ready = torch.cuda.Event()
-                        ready.record(enc_s)
-                finally:
-                    out = fut.result() if fut is not None else None      # also drains the decode stage before an exception propagates
-                if out is not None:
-                    yield out
-                pending = (bank, list(heads), forced, len(videos), ready)
-                bank ^= 1
-            if pending is not None:
-                brackets(2)
-                try:
+        try:                                            # whatever ends the generator (exhaustion, an exception, the caller closing it early): both brackets back on
+            with cf.ThreadPoolExecutor(max_workers=1, thread_name_prefix="trace-decode") as pool:
+                for item in batches:
+                    videos, timestamps, input_ids, heads, forced = item
+                    if len(videos) > min(half, self.decode_batch_max):
+                        raise ValueError(f"batch of {len(videos)} exceeds max_batch // 2 = {half} (two KV banks)")
+                    brackets(1 if pending is None else 0)
+                    fut = pool.submit(dec_job, *pending) if pending is not None else None
+                    enc_s.wait_stream(cur)                  # the batch's frames may have been made on the caller's stream (device preprocessing)
+                    try:
+                        with torch.cuda.stream(enc_s):
+                            self.encode_prefill(videos, timestamps, input_ids, bank * half)
+                            if self._dbg is not None:
+                                self._dbg("prefilled", bank * half, None)
+                            ready = torch.cuda.Event()
+                            ready.record(enc_s)
+                    finally:
+                        out = fut.result() if fut is not None else None      # also drains the decode stage before an exception propagates
+                    if out is not None:
+                        yield out
+                    pending = (bank, list(heads), forced, len(videos), ready)
+                    bank ^= 1
+                if pending is not None:
+                    brackets(2)
                     out = pool.submit(dec_job, *pending).result()
-                finally:
-                    brackets(3)
-                cur.wait_stream(dec_s); cur.wait_stream(enc_s)
-                yield out
+                    cur.wait_stream(dec_s); cur.wait_stream(enc_s)
+                    yield out
+        finally:
+            brackets(3)
 
 
 # ---- kernel-level wrappers for unit tests / microbenchmarks -------------------------------------

@@ -150,19 +150,33 @@ def run_reference(model, cfg, input_ids, frames, ts, forced=None, n_new=24):
     return torch.stack(step_logits), toks, L
 
 
-def _own_fp16_run(model, cfg, input_ids, frames, ts, forced, tf_logits):
-    """The reference in ITS OWN inference dtype (model.half(), trace/model/builder.py:50) on the same teacher-forced stream; {} when this
-    host's CPU half kernels cannot run it."""
+def _own_lowp_run(model, cfg, input_ids, frames, ts, forced, tf_logits, dtype=torch.float16):
+    """The reference ITSELF in a 16-bit dtype on the same teacher-forced stream: model.half() is its own inference dtype (trace/model/builder.py:50),
+    model.to(torch.bfloat16) the dtype BASELINE's configurations name (the same `torch_dtype` switch) — the anchor for the HIP path's bf16 tolerance:
+    how far the reference's own 16-bit run lands from its fp32 run.  {} when this host's CPU kernels cannot run it."""
+    tag = "fp16" if dtype == torch.float16 else "bf16"
     try:
-        m16 = model.half()
-        l16, a16, _ = run_reference(m16, cfg, input_ids, frames.half(), ts, forced=forced)
-        print("reference fp16 run: max |logit - fp32 run| =", float((l16.float() - tf_logits)[torch.isfinite(tf_logits)].abs().max()))
-        return {"tf_logits_ref_fp16": l16.float().numpy().astype(np.float32), "tf_argmax_ref_fp16": np.array(a16)}
+        m16 = model.to(dtype)
+        l16, a16, _ = run_reference(m16, cfg, input_ids, frames.to(dtype), ts, forced=forced)
+        print(f"reference {tag} run: max |logit - fp32 run| =", float((l16.float() - tf_logits)[torch.isfinite(tf_logits)].abs().max()))
+        return {f"tf_logits_ref_{tag}": l16.float().numpy().astype(np.float32), f"tf_argmax_ref_{tag}": np.array(a16)}
     except Exception as e:
-        print("reference fp16 run not possible on this host:", repr(e)[:200])
+        print(f"reference {tag} run not possible on this host:", repr(e)[:200])
         return {}
     finally:
         model.float()
+
+
+def _own_fp16_run(model, cfg, input_ids, frames, ts, forced, tf_logits):
+    return _own_lowp_run(model, cfg, input_ids, frames, ts, forced, tf_logits, torch.float16)
+
+
+def add_arrays(npz_name, **arrays):
+    """adds arrays to a committed fixture without touching what it already holds"""
+    path = os.path.join(OUT, npz_name)
+    old = dict(np.load(path))
+    old.update(arrays)
+    np.savez_compressed(path, **old)
 
 
 def fp_goldens(tmp, dtype=torch.bfloat16, name="tiny_e2e.npz"):
@@ -469,7 +483,7 @@ def deep_llm_goldens(tmp, dtype=torch.bfloat16):
     input_ids = synth.synth_prompt_ids(cfg, n_text=24, video_pos=10)
     forced = scripted_ids(cfg)
     tf_logits, tf_argmax, L = run_reference(model, cfg, input_ids, frames, ts, forced=forced)
-    extra = _own_fp16_run(model, cfg, input_ids, frames, ts, forced, tf_logits) if dtype == torch.float16 else {}
+    extra = _own_lowp_run(model, cfg, input_ids, frames, ts, forced, tf_logits, dtype)     # the reference's own run in the fixture's 16-bit dtype (bf16 anchor: round 4)
     np.savez_compressed(os.path.join(OUT, "deep_llm" + ("_f16" if dtype == torch.float16 else "") + ".npz"), **extra, input_ids=input_ids.numpy(), timestamps=np.array(ts, dtype=np.float64),
                         forced_ids=np.array(forced), tf_logits=tf_logits.numpy().astype(np.float32), tf_argmax=np.array(tf_argmax),
                         prefill_len=np.array(L))
@@ -532,7 +546,7 @@ def videomme_goldens(tmp):
 
 
 @torch.no_grad()
-def run_reference_layer_streamed(cfg_full, tmp, input_ids, frames, ts, forced):
+def run_reference_layer_streamed(cfg_full, tmp, input_ids, frames, ts, forced, dtype=torch.float32):
     """Teacher-forced logits of the FULL-depth stack without holding it in RAM: the reference model is built with ONE decoder
     layer; its own modules do the embedding splice (prepare_inputs_labels_for_multimodal, both branches), the layer
     (`model.model.layers[0]`, the transformers MistralDecoderLayer the reference delegates to), the final norm and the four
@@ -545,6 +559,9 @@ def run_reference_layer_streamed(cfg_full, tmp, input_ids, frames, ts, forced):
     cfg1 = dataclasses.replace(cfg_full, num_hidden_layers=1)
     model = build_reference_model(cfg1, tmp)
     load_synth(model, cfg1)                                    # embeddings, towers, ViT, slot pool, norm, heads (+ layer 0)
+    if dtype != torch.float32:                                 # the reference's own modules in a 16-bit dtype (model.to(dtype), builder.py:50's switch)
+        model = model.to(dtype)
+        frames = frames.to(dtype)
     ids = input_ids.view(1, -1)
     (_, _, _, embeds, _, _, _) = model.prepare_inputs_labels_for_multimodal(
         ids, torch.ones_like(ids), None, None, [[frames], ["video"]], [[]], [[]], video_timestamps=[ts])
@@ -564,14 +581,14 @@ def run_reference_layer_streamed(cfg_full, tmp, input_ids, frames, ts, forced):
     pos = torch.arange(N)[None]
     layer, mm = model.model.layers[0], model.model
     pe = mm.rotary_emb(x, pos)
-    mask = torch.full((N, N), float("-inf")).triu(1)[None, None]
+    mask = torch.full((N, N), float("-inf")).triu(1)[None, None].to(dtype)
     keys = [k for k in layer.state_dict().keys()]
     specs = {sp[0]: sp for sp in synth.weight_specs(cfg_full)}
     for l in range(cfg_full.num_hidden_layers):
         sd = {}
         for k in keys:
             spec = specs[f"model.layers.{l}.{k}"]
-            sd[k] = synth.synth_tensor(spec[0], spec[1], spec[2], torch.bfloat16).float()
+            sd[k] = synth.synth_tensor(spec[0], spec[1], spec[2], torch.bfloat16).to(dtype)
         layer.load_state_dict(sd, strict=True)
         out = layer(x, attention_mask=mask, position_ids=pos, position_embeddings=pe, use_cache=False)
         x = out[0] if isinstance(out, tuple) else out
@@ -612,6 +629,50 @@ def full_depth_goldens(tmp):
                         forced_ids=np.array(forced), tf_logits=lg.numpy().astype(np.float32), tf_argmax=masked.argmax(-1).numpy(),
                         prefill_len=np.array(L), harness_err_8_layers=np.array(err8))
     print("full_depth_llm: L=%d steps=%d logit std %.3f" % (L, lg.shape[0], lg[torch.isfinite(lg)].std().item()))
+
+
+def bf16_anchor_goldens(tmp):
+    """Round 4: the reference's OWN bf16 run next to its fp32 run, at 8 and at all 32 real-width layers, added to deep_llm.npz / full_depth_llm.npz
+    (`tf_logits_ref_bf16`, `tf_argmax_ref_bf16`).  8 layers: the unmodified forward() of model.to(torch.bfloat16) (prefill + cached single-token steps).
+    32 layers: the layer-streamed harness with the reference's modules in bf16 — first run at 8 layers next to the forward() run to show that its bf16
+    error against fp32 has the same size (it cannot be bit-equal: one causal pass over L + n rows rounds differently from L rows + n cached steps)."""
+    import dataclasses
+    from trace_amd import config as tcfg, synth
+    base = dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336)
+    frames = synth.synth_frames(base, 0).to(torch.bfloat16).float()
+    ts = [[float(i) * 2.5] for i in range(base.num_frames)]
+    input_ids = synth.synth_prompt_ids(base, n_text=24, video_pos=10)
+    forced = scripted_ids(base)
+    D8 = np.load(os.path.join(OUT, "deep_llm.npz"))
+    ref8 = torch.from_numpy(D8["tf_logits"])
+    fin = torch.isfinite(ref8)
+    if "tf_logits_ref_bf16" not in D8.files:
+        cfg8 = dataclasses.replace(base, num_hidden_layers=8)
+        model = build_reference_model(cfg8, os.path.join(tmp, "deepllm_bf16"))
+        load_synth(model, cfg8)
+        chk, _, _ = run_reference(model, cfg8, input_ids, frames, ts, forced=forced)
+        assert (chk[fin] - ref8[fin]).abs().max().item() < 1e-4, "the fp32 run no longer reproduces the committed deep_llm.npz"
+        add_arrays("deep_llm.npz", **_own_lowp_run(model, cfg8, input_ids, frames, ts, forced, ref8, torch.bfloat16))
+        del model
+        D8 = np.load(os.path.join(OUT, "deep_llm.npz"))
+    fw8 = torch.from_numpy(D8["tf_logits_ref_bf16"])
+    lg8, _ = run_reference_layer_streamed(dataclasses.replace(base, num_hidden_layers=8), os.path.join(tmp, "fd8b"), input_ids, frames, ts, forced, torch.bfloat16)
+    e_fw, e_st = (fw8[fin] - ref8[fin]).abs(), (lg8.float()[fin] - ref8[fin]).abs()
+    print("8 layers, reference bf16 vs fp32: forward() max %.3f rms %.4f | layer-streamed harness max %.3f rms %.4f" %
+          (e_fw.max(), e_fw.pow(2).mean().sqrt(), e_st.max(), e_st.pow(2).mean().sqrt()))
+    assert 0.5 < e_st.pow(2).mean().sqrt() / e_fw.pow(2).mean().sqrt() < 2.0, "the streamed bf16 harness is not representative of forward() in bf16"
+    D32 = np.load(os.path.join(OUT, "full_depth_llm.npz"))
+    ref32 = torch.from_numpy(D32["tf_logits"])
+    lg32, _ = run_reference_layer_streamed(dataclasses.replace(base, num_hidden_layers=32), os.path.join(tmp, "fd32b"), input_ids, frames, ts, forced, torch.bfloat16)
+    lg32 = lg32.float()
+    fin32 = torch.isfinite(ref32)
+    assert torch.equal(fin32, torch.isfinite(lg32))
+    e32 = (lg32[fin32] - ref32[fin32]).abs()
+    masked = torch.where(torch.isfinite(lg32), lg32, torch.full_like(lg32, -1e30))
+    add_arrays("full_depth_llm.npz", tf_logits_ref_bf16=lg32.numpy().astype(np.float32), tf_argmax_ref_bf16=masked.argmax(-1).numpy(),
+               harness_bf16_vs_forward_bf16_rms_ratio_8_layers=np.array(float(e_st.pow(2).mean().sqrt() / e_fw.pow(2).mean().sqrt())))
+    flips = int((masked.argmax(-1) != torch.from_numpy(D32["tf_argmax"])).sum())
+    print("32 layers, reference bf16 (streamed) vs fp32: max %.3f rms %.4f; arg-max differs on %d of %d steps" % (e32.max(), e32.pow(2).mean().sqrt(), flips, lg32.shape[0]))
 
 
 def tokenizer_goldens():
@@ -724,6 +785,9 @@ if __name__ == "__main__":
         medium_llm_goldens(tmp, torch.float16)
         deep_llm_goldens(tmp, torch.float16)
         sys.exit(0)
+    if "--bf16-anchor-only" in sys.argv:
+        bf16_anchor_goldens(tmp)
+        sys.exit(0)
     if "--full-depth-only" in sys.argv:
         full_depth_goldens(tmp)
         sys.exit(0)
@@ -740,5 +804,6 @@ if __name__ == "__main__":
     charades_goldens(tmp)
     videomme_goldens(tmp)
     full_depth_goldens(tmp)
+    bf16_anchor_goldens(tmp)
     tokenizer_goldens()
     preprocess_goldens()

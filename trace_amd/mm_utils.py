@@ -97,11 +97,15 @@ def _to_frames(video, fps):
         if os.path.isdir(video):
             names = sorted(n for n in os.listdir(video) if n.lower().endswith((".png", ".jpg", ".jpeg", ".bmp")))
             return [np.array(Image.open(os.path.join(video, n)).convert("RGB")) for n in names], float(fps or 1.0)
+        from .video_io import open_container
+        vr = open_container(video)                    # .y4m, Motion-JPEG / uncompressed .avi: read here, decord's VideoReader surface
+        if vr is not None:
+            return vr, float(vr.get_avg_fps())
         try:
             from decord import VideoReader, cpu       # same reader as the reference (mm_utils.py:421)
         except ImportError as e:
-            raise ImportError("decoding a video container needs `decord` (as in the reference); pass decoded frames, a "
-                              ".npy file or a directory of images instead") from e
+            raise ImportError("decoding this video container needs `decord` (as in the reference); without it: a .y4m file (`ffmpeg -i clip.mp4 clip.y4m`), "
+                              "a Motion-JPEG .avi, a .gif, a .npy file, a directory of images, or decoded frames") from e
         vr = VideoReader(uri=video, ctx=cpu(0))
         return vr, float(vr.get_avg_fps())
     if isinstance(video, torch.Tensor):

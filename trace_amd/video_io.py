@@ -1,0 +1,307 @@
+"""Container readers for `process_video` that need no decord / imageio / moviepy (trace/mm_utils.py:379-449 opens `.mp4 / .gif / .webm`
+through those packages; none of them exists in this image, and a codec such as H.264 is out of this build's scope).  What is read here:
+
+* `.y4m` (YUV4MPEG2, the uncompressed interchange format `ffmpeg -i clip.mp4 clip.y4m` writes): 4:2:0 / 4:2:2 / 4:4:4 / mono, 8 bit;
+* `.avi` holding Motion-JPEG (`MJPG`) or uncompressed 24-bit (`DIB `) frames: every frame is an independent image, decoded with Pillow.
+
+Both readers present decord's `VideoReader` surface as far as `process_video` uses it — `len(vr)`, `vr.get_avg_fps()`,
+`vr.get_batch(indices).asnumpy()` -> uint8 `[n, H, W, 3]` RGB (mm_utils.py:421-431) — so the sampling / timestamp code above them is the
+same code that runs over decord.  YUV -> RGB is BT.601 limited range (what libswscale assumes for untagged SD material), integer
+arithmetic, chroma replicated to full resolution (nearest); `rgb_to_yuv601` / `yuv601_to_rgb` state the exact formulas and
+`tests/test_video_io.py` pins them.  A writer for each format serves the tests and `bench.py --config c1` (a synthetic clip on disk).
+"""
+from __future__ import annotations
+
+import io
+import os
+import struct
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+
+class _Batch:
+    """what decord's get_batch returns, reduced to the one method the callers use"""
+
+    def __init__(self, arr: np.ndarray):
+        self._a = arr
+
+    def asnumpy(self) -> np.ndarray:
+        return self._a
+
+    def numpy(self) -> np.ndarray:
+        return self._a
+
+
+# ---------------------------------------------------------------------------------------------------------------- colour
+def yuv601_to_rgb(y: np.ndarray, u: np.ndarray, v: np.ndarray) -> np.ndarray:
+    """BT.601 limited range, 8 bit, integer arithmetic (16.16 fixed point, rounded):  C = Y - 16, D = U - 128, E = V - 128,
+    R = 1.164383 C + 1.596027 E,  G = 1.164383 C - 0.391762 D - 0.812968 E,  B = 1.164383 C + 2.017232 D;  planes of equal shape."""
+    c = y.astype(np.int64) - 16
+    d = u.astype(np.int64) - 128
+    e = v.astype(np.int64) - 128
+    r = (76309 * c + 104597 * e + 32768) >> 16
+    g = (76309 * c - 25675 * d - 53279 * e + 32768) >> 16
+    b = (76309 * c + 132201 * d + 32768) >> 16
+    return np.clip(np.stack([r, g, b], axis=-1), 0, 255).astype(np.uint8)
+
+
+def rgb_to_yuv601(rgb: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """inverse convention (writer side): Y = 16 + 0.256788 R + 0.504129 G + 0.097906 B, U = 128 - 0.148223 R - 0.290993 G + 0.439216 B,
+    V = 128 + 0.439216 R - 0.367788 G - 0.071427 B; 16.16 fixed point, rounded."""
+    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+    y = 16 + ((16829 * r + 33039 * g + 6416 * b + 32768) >> 16)
+    u = 128 + ((-9714 * r - 19070 * g + 28784 * b + 32768) >> 16)
+    v = 128 + ((28784 * r - 24103 * g - 4681 * b + 32768) >> 16)
+    return tuple(np.clip(p, 0, 255).astype(np.uint8) for p in (y, u, v))
+
+
+# ---------------------------------------------------------------------------------------------------------------- YUV4MPEG2
+_Y4M_SUB = {"420": (2, 2), "422": (2, 1), "444": (1, 1), "mono": (0, 0)}          # chroma subsampling (horizontal, vertical)
+
+
+class Y4MReader:
+    def __init__(self, path: str):
+        self.path = path
+        with open(path, "rb") as f:
+            head = f.readline(4096)
+            if not head.startswith(b"YUV4MPEG2 ") or not head.endswith(b"\n"):
+                raise ValueError(f"{path}: not a YUV4MPEG2 stream")
+            self._data0 = f.tell()
+        w = h = 0
+        fps = (25, 1)
+        chroma = "420"
+        for tok in head[len(b"YUV4MPEG2 "):].split():
+            tag, val = chr(tok[0]), tok[1:].decode("ascii", "replace")
+            if tag == "W":
+                w = int(val)
+            elif tag == "H":
+                h = int(val)
+            elif tag == "F":
+                n, _, d = val.partition(":")
+                fps = (int(n), int(d or 1))
+            elif tag == "C":
+                chroma = val
+        key = {"420": "420", "420jpeg": "420", "420mpeg2": "420", "420paldv": "420", "422": "422", "444": "444", "mono": "mono"}.get(chroma)
+        if key is None:                                    # (420p10, 444p16, 444alpha, ...: not 8-bit three-plane)
+            raise ValueError(f"{path}: unsupported y4m colour space C{chroma} (8-bit 420 / 422 / 444 / mono only)")
+        if w < 1 or h < 1 or fps[0] < 1 or fps[1] < 1:
+            raise ValueError(f"{path}: bad y4m header {head!r}")
+        self.width, self.height, self._fps, self._key = w, h, fps[0] / fps[1], key
+        sx, sy = _Y4M_SUB[key]
+        self._cw = 0 if not sx else (w + sx - 1) // sx
+        self._ch = 0 if not sy else (h + sy - 1) // sy
+        self._frame_bytes = w * h + 2 * self._cw * self._ch
+        # frame offsets: every frame is "FRAME[ params]\n" + planes; headers may carry parameters, so the file is walked once
+        self._offsets: List[int] = []
+        size = os.path.getsize(path)
+        with open(path, "rb") as f:
+            pos = self._data0
+            while pos < size:
+                f.seek(pos)
+                line = f.readline(256)
+                if not line.startswith(b"FRAME") or not line.endswith(b"\n"):
+                    raise ValueError(f"{path}: malformed frame header at byte {pos}")
+                pos += len(line)
+                if pos + self._frame_bytes > size:
+                    break                                  # truncated last frame: dropped, as decoders do
+                self._offsets.append(pos)
+                pos += self._frame_bytes
+
+    def __len__(self) -> int:
+        return len(self._offsets)
+
+    def get_avg_fps(self) -> float:
+        return self._fps
+
+    def _frame(self, f, i: int) -> np.ndarray:
+        f.seek(self._offsets[i])
+        buf = np.frombuffer(f.read(self._frame_bytes), dtype=np.uint8)
+        w, h, cw, ch = self.width, self.height, self._cw, self._ch
+        y = buf[: w * h].reshape(h, w)
+        if self._key == "mono":
+            u = v = np.full((h, w), 128, np.uint8)
+        else:
+            sx, sy = _Y4M_SUB[self._key]
+            u = buf[w * h: w * h + cw * ch].reshape(ch, cw).repeat(sy, axis=0).repeat(sx, axis=1)[:h, :w]
+            v = buf[w * h + cw * ch:].reshape(ch, cw).repeat(sy, axis=0).repeat(sx, axis=1)[:h, :w]
+        return yuv601_to_rgb(y, u, v)
+
+    def get_batch(self, indices: Sequence[int]) -> _Batch:
+        idx = [int(i) for i in indices]
+        if any(i < 0 or i >= len(self) for i in idx):
+            raise IndexError(f"frame index out of range (0..{len(self) - 1}): {idx}")
+        with open(self.path, "rb") as f:
+            return _Batch(np.stack([self._frame(f, i) for i in idx]) if idx else np.zeros((0, self.height, self.width, 3), np.uint8))
+
+    def __getitem__(self, i: int) -> np.ndarray:
+        return self.get_batch([i]).asnumpy()[0]
+
+
+def write_y4m(path: str, frames_rgb: np.ndarray, fps: Tuple[int, int] = (25, 1), chroma: str = "420") -> None:
+    """uint8 RGB [T, H, W, 3] -> YUV4MPEG2 (BT.601 limited range; 4:2:0 / 4:2:2 chroma = the mean of the covered pixels, rounded)"""
+    fr = np.asarray(frames_rgb)
+    if fr.dtype != np.uint8 or fr.ndim != 4 or fr.shape[-1] != 3:
+        raise ValueError("frames must be uint8 [T, H, W, 3]")
+    sx, sy = _Y4M_SUB[chroma]
+    T, H, W, _ = fr.shape
+    with open(path, "wb") as f:
+        f.write(f"YUV4MPEG2 W{W} H{H} F{fps[0]}:{fps[1]} Ip A1:1 C{chroma}{'jpeg' if chroma == '420' else ''}\n".encode())
+        for t in range(T):
+            y, u, v = rgb_to_yuv601(fr[t])
+            f.write(b"FRAME\n")
+            f.write(y.tobytes())
+            if chroma == "mono":
+                continue
+            for p in (u, v):
+                if sx > 1 or sy > 1:
+                    Hp, Wp = (H + sy - 1) // sy * sy, (W + sx - 1) // sx * sx
+                    q = np.pad(p, ((0, Hp - H), (0, Wp - W)), mode="edge").astype(np.int64)
+                    q = q.reshape(Hp // sy, sy, Wp // sx, sx).sum(axis=(1, 3))
+                    p = ((q + (sx * sy) // 2) // (sx * sy)).astype(np.uint8)
+                f.write(p.tobytes())
+
+
+# ---------------------------------------------------------------------------------------------------------------- AVI (MJPG / DIB)
+def _riff_chunks(buf: memoryview, start: int, end: int):
+    """(fourcc, payload start, payload size) of every chunk in [start, end); LIST chunks are yielded with their list type appended"""
+    pos = start
+    while pos + 8 <= end:
+        cc = bytes(buf[pos:pos + 4])
+        size = struct.unpack_from("<I", buf, pos + 4)[0]
+        yield cc, pos + 8, size
+        pos += 8 + size + (size & 1)
+
+
+class AviReader:
+    """AVI 1.0 with one video stream of independent frames: Motion-JPEG ('MJPG' and its aliases) or uncompressed 24-bit BGR ('DIB ', BI_RGB,
+    bottom-up).  Inter-coded streams (H.264, MPEG-4, ...) are refused with the reason."""
+
+    def __init__(self, path: str):
+        self.path = path
+        with open(path, "rb") as f:
+            data = f.read()
+        buf = memoryview(data)
+        if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"AVI ":
+            raise ValueError(f"{path}: not a RIFF AVI file")
+        self._data = data
+        self._frames: List[Tuple[int, int]] = []
+        self._fps = 0.0
+        self._handler = b""
+        self._compression = b""
+        self.width = self.height = 0
+        self._bits = 24
+        usec = 0
+        for cc, p, n in _riff_chunks(buf, 12, len(data)):
+            if cc != b"LIST":
+                continue
+            kind = bytes(buf[p:p + 4])
+            if kind == b"hdrl":
+                for c2, p2, n2 in _riff_chunks(buf, p + 4, p + n):
+                    if c2 == b"avih":
+                        usec = struct.unpack_from("<I", buf, p2)[0]
+                    elif c2 == b"LIST" and bytes(buf[p2:p2 + 4]) == b"strl":
+                        is_video = False
+                        for c3, p3, n3 in _riff_chunks(buf, p2 + 4, p2 + n2):
+                            if c3 == b"strh":
+                                is_video = bytes(buf[p3:p3 + 4]) == b"vids"
+                                if is_video and not self._handler:
+                                    self._handler = bytes(buf[p3 + 4:p3 + 8])
+                                    scale, rate = struct.unpack_from("<II", buf, p3 + 20)
+                                    if scale and rate:
+                                        self._fps = rate / scale
+                            elif c3 == b"strf" and is_video and not self.width:
+                                self.width, h = struct.unpack_from("<ii", buf, p3 + 4)
+                                self.height = abs(h)
+                                self._flip = h > 0                 # positive height = bottom-up rows (DIB)
+                                self._bits = struct.unpack_from("<H", buf, p3 + 14)[0]
+                                self._compression = bytes(buf[p3 + 16:p3 + 20])
+            elif kind == b"movi":
+                for c2, p2, n2 in _riff_chunks(buf, p + 4, p + n):
+                    if c2[2:] in (b"dc", b"db") and n2 > 0:
+                        self._frames.append((p2, n2))
+        if not self._fps and usec:
+            self._fps = 1e6 / usec
+        comp = self._compression.upper()
+        self._mjpeg = comp in (b"MJPG", b"JPEG", b"AVRN", b"LJPG") or self._handler.upper() in (b"MJPG",)
+        self._dib = comp in (b"\0\0\0\0", b"DIB ", b"RGB ", b"RAW ") and self._bits == 24
+        if not (self._mjpeg or self._dib):
+            raise ValueError(f"{path}: video stream is coded as {self._compression!r} / {self._handler!r}: only streams of independent frames (Motion-JPEG, "
+                             "uncompressed 24-bit) are decoded here; transcode inter-coded video (H.264, ...) with `ffmpeg -i in.mp4 out.y4m`, or install decord")
+        if not self._frames or self.width < 1 or self.height < 1 or self._fps <= 0:
+            raise ValueError(f"{path}: no video frames / bad stream header")
+
+    def __len__(self) -> int:
+        return len(self._frames)
+
+    def get_avg_fps(self) -> float:
+        return self._fps
+
+    def _frame(self, i: int) -> np.ndarray:
+        p, n = self._frames[i]
+        raw = self._data[p:p + n]
+        if self._mjpeg:
+            from PIL import Image
+            with Image.open(io.BytesIO(raw)) as im:
+                return np.asarray(im.convert("RGB"))
+        stride = (self.width * 3 + 3) & ~3
+        a = np.frombuffer(raw, dtype=np.uint8)[: stride * self.height].reshape(self.height, stride)[:, : self.width * 3]
+        a = a.reshape(self.height, self.width, 3)[:, :, ::-1]
+        return np.ascontiguousarray(a[::-1] if self._flip else a)
+
+    def get_batch(self, indices: Sequence[int]) -> _Batch:
+        idx = [int(i) for i in indices]
+        if any(i < 0 or i >= len(self) for i in idx):
+            raise IndexError(f"frame index out of range (0..{len(self) - 1}): {idx}")
+        return _Batch(np.stack([self._frame(i) for i in idx]) if idx else np.zeros((0, self.height, self.width, 3), np.uint8))
+
+    def __getitem__(self, i: int) -> np.ndarray:
+        return self._frame(int(i))
+
+
+def write_avi(path: str, frames_rgb: np.ndarray, fps: Tuple[int, int] = (25, 1), codec: str = "MJPG", quality: int = 95) -> None:
+    """uint8 RGB [T, H, W, 3] -> AVI with Motion-JPEG (Pillow's encoder) or uncompressed bottom-up 24-bit BGR frames ('DIB ')"""
+    fr = np.asarray(frames_rgb)
+    if fr.dtype != np.uint8 or fr.ndim != 4 or fr.shape[-1] != 3:
+        raise ValueError("frames must be uint8 [T, H, W, 3]")
+    T, H, W, _ = fr.shape
+    chunks = []
+    for t in range(T):
+        if codec == "MJPG":
+            from PIL import Image
+            b = io.BytesIO()
+            Image.fromarray(fr[t]).save(b, format="JPEG", quality=quality, subsampling=0)
+            payload = b.getvalue()
+        else:
+            stride = (W * 3 + 3) & ~3
+            rows = np.zeros((H, stride), np.uint8)
+            rows[:, : W * 3] = fr[t][::-1, :, ::-1].reshape(H, W * 3)
+            payload = rows.tobytes()
+        chunks.append(payload)
+
+    def chunk(cc: bytes, payload: bytes) -> bytes:
+        return cc + struct.pack("<I", len(payload)) + payload + (b"\0" if len(payload) & 1 else b"")
+
+    def lst(kind: bytes, body: bytes) -> bytes:
+        return b"LIST" + struct.pack("<I", 4 + len(body)) + kind + body
+
+    comp = b"MJPG" if codec == "MJPG" else b"\0\0\0\0"
+    handler = b"MJPG" if codec == "MJPG" else b"DIB "
+    avih = struct.pack("<14I", int(round(1e6 * fps[1] / fps[0])), 0, 0, 0x10, T, 0, 1, max(len(c) for c in chunks), W, H, 0, 0, 0, 0)
+    strh = b"vids" + handler + struct.pack("<IHHIIIIIIII", 0, 0, 0, 0, fps[1], fps[0], 0, T, max(len(c) for c in chunks), 0xFFFFFFFF, 0) + struct.pack("<4h", 0, 0, W, H)
+    strf = struct.pack("<IiiHH", 40, W, H, 1, 24) + comp + struct.pack("<IiiII", W * H * 3, 0, 0, 0, 0)
+    hdrl = lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf)))
+    movi = lst(b"movi", b"".join(chunk(b"00dc" if codec == "MJPG" else b"00db", c) for c in chunks))
+    body = b"AVI " + hdrl + movi
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def open_container(path: str):
+    """A reader with decord's VideoReader surface for the containers decodable without a codec library, or None (the caller then needs decord)."""
+    low = path.lower()
+    if low.endswith(".y4m"):
+        return Y4MReader(path)
+    if low.endswith(".avi"):
+        return AviReader(path)
+    return None

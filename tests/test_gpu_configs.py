@@ -10,8 +10,9 @@
 
 Tolerances: LOGIT_TOL = 0.15 for the one-layer shapes (the budget of tests/test_gpu_parity.py); FULL_DEPTH_TOL for the
 32-layer stack — independent bf16 roundings (weights, activations, KV cache; fp32 accumulation) grow like sqrt(depth):
-0.13-0.14 measured at 8 layers -> 0.27 expected at 32, 0.32 measured (gpurun_out/parity_measured.txt); the budget is 0.45
-absolute on logits of std 1.29.  Greedy ids must equal the reference's wherever its own top-2 margin exceeds twice the budget;
+0.13-0.14 measured at 8 layers -> 0.27 expected at 32, 0.32 measured (gpurun_out/parity_measured.txt); the budget is 0.40
+absolute on logits of std 1.29 — anchored (round 4) on the reference's OWN bf16 run of the same stream, which deviates 0.49 max / 0.116 rms
+from its fp32 run (`tf_logits_ref_bf16` in the fixture): the HIP path must stay below both figures.  Greedy ids must equal the reference's wherever its own top-2 margin exceeds twice the budget;
 the 13-way time / score head ids are what the timestamps are made of and are checked at every step that qualifies."""
 import dataclasses
 import os
@@ -28,7 +29,7 @@ from trace_amd import config as tcfg, synth  # noqa: E402
 from trace_amd.engine import TraceEngine  # noqa: E402
 
 LOGIT_TOL = 0.15
-FULL_DEPTH_TOL = 0.45
+FULL_DEPTH_TOL = 0.40      # round 4: below the reference's own bf16-vs-fp32 deviation on this stream (0.49 max, tests/golden/full_depth_llm.npz:tf_logits_ref_bf16); HIP measured 0.29-0.32
 
 
 def _teacher_forced(eng, nb, n, forced, graph_tail=False):
@@ -141,4 +142,11 @@ def test_full_depth_32_layers_vs_reference_fixture(golden_dir):
     ref_ids = M["tf_argmax"].tolist()
     assert sum(r > V for r in ref_ids) >= 20
     assert worst > 0.0
+    # the anchor for the budget (round 4): the reference's OWN bf16 run of this stream (model.to(bfloat16), layer-streamed) is 0.49 max / 0.116 rms
+    # from its fp32 run; the HIP path (fp32 accumulation, bf16 only at the storage points) must be no further from fp32 than that, and must not
+    # change more 13-way decisions than the reference's bf16 run does
+    from conftest import bf16_anchor_report
+    r = bf16_anchor_report(torch.stack([x[0] for x in lgs]), M, "full depth (32 layers), bf16 anchor")
+    assert r["hip_rms"] <= r["ref_bf16_rms"] and r["hip_max"] <= r["ref_bf16_max"], r
+    assert r["hip_flips_13way"] <= r["ref_bf16_flips_13way"] + 2 and r["hip_flips_13way_margin_gt_0.5"] <= r["ref_bf16_flips_13way_margin_gt_0.5"] + 1, r
     eng.close()

@@ -101,8 +101,10 @@ def mr_schedule(cfg, n_new, seed):
     return out[:n_new]
 
 
-# BASELINE.json configs with a GPU workload (C1 is the reference's CPU plumbing case, C3 = C2 under --gpus 8)
+# BASELINE.json configs (C1 = the reference's CPU-runnable plumbing case: run_c1 below; C3 = C2 under --gpus 8)
 CONFIGS = {
+    "c1": dict(frames=8, max_new=32, n_text=0, video_pos=0, schedule="none", videos_per_step=1,
+               name="C1: single clip from a file, 8 frames, greedy decode through the drivers' call sequence (scripts/inference/inference.py), tiny-layer model"),
     "c2": dict(frames=128, max_new=256, n_text=176, video_pos=150, schedule="dvc", videos_per_step=128,
                name="C2: TRACE-7B bf16 (CLIP-ViT-L/14-336 23 layers + SpatialSlotPool + Mistral-7B)"),
     "c4": dict(frames=64, max_new=32, n_text=191, video_pos=150, schedule="mr", videos_per_step=128,
@@ -110,6 +112,116 @@ CONFIGS = {
     "c5": dict(frames=256, max_new=16, n_text=251, video_pos=200, schedule="dvc", videos_per_step=32, fp8=True,
                name="C5: VideoMME long video (256 frames, past MAX_FRAMES), TRACE-7B, fp8 (e4m3 W8A8) decoder projections"),
 }
+
+
+def synthetic_clip(T=96, H=120, W=160):
+    """a deterministic moving-pattern clip (uint8 RGB [T, H, W, 3]): stands in for the reference's assets/sora.mp4, which is a missing blob"""
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    t = np.arange(T)[:, None, None]
+    r = (xx[None] * 2 + t * 5) % 256
+    g = (yy[None] * 3 + t * 3) % 256
+    b = ((xx[None] + yy[None]) + t * 7) % 256
+    box = ((xx[None] - (20 + t)) % W < 24) & ((yy[None] - 30) % H < 24)          # a square drifting to the right
+    out = np.stack([r, g, b], -1).astype(np.uint8)
+    out[np.broadcast_to(box, out.shape[:3])] = 255
+    return out
+
+
+def run_c1(args) -> None:
+    """BASELINE config 1 — "single clip, 8 frames, greedy decode on CPU via scripts/inference/inference.py (plumbing)": the drivers' call sequence
+    (inference.py:32-128: process_video from a FILE -> conversation prompt + <sync> -> tokenizer_MMODAL_token_all -> generate(heads=[1]) -> id parser)
+    on a synthetic clip written as YUV4MPEG2 (no decord here; trace_amd/video_io.py), T = 8, 32 greedy tokens, the tiny-layer model of the reference
+    fixtures (hidden 4096 is forced by trace_arch.py:38-40).  Two legs on the same inputs:
+      * CPU: the oracle (the reference path restated, pinned by the reference fixtures) end to end — BASELINE.md section 3's "C1 runs fully on CPU";
+      * GPU (when one is visible): load_pretrained_model -> process_video(file) -> model.generate through the C ABI; ids compared with the oracle's.
+    `value` = the GPU leg's videos/s (file read + preprocessing + generate per step); without a GPU the line reports the CPU leg only."""
+    import tempfile
+    from oracle import trace_oracle as O                      # checker + CPU baseline only
+    from trace_amd import video_io
+    from trace_amd.constants import DEFAULT_MMODAL_TOKEN
+    from trace_amd.conversation import conv_templates
+    from trace_amd.evaluate import parse_output_ids
+    from trace_amd.mm_utils import get_model_name_from_path, process_video, tokenizer_MMODAL_token_all
+    from trace_amd.model import builder
+    cfg = tcfg.tiny(num_frames=args.frames)
+    n_new = args.max_new
+    tmp = tempfile.mkdtemp(prefix="trace_c1_")
+    clip = os.path.join(tmp, "clip.y4m")
+    video_io.write_y4m(clip, synthetic_clip(), fps=(24, 1), chroma="420")
+    ckpt = builder.save_synthetic_checkpoint(os.path.join(tmp, "trace-tiny"), cfg)
+    question = "Find the events of this clip: give the start and end time of each, a score, and one sentence about it."
+
+    def driver_inputs(tokenizer, processor, engine=None):
+        tensor, ts = process_video(clip, processor, "pad", num_frames=args.frames, engine=engine)        # inference.py:34
+        conv = conv_templates["llama_2"].copy()                                                           # inference.py:50-55
+        conv.append_message(conv.roles[0], DEFAULT_MMODAL_TOKEN["VIDEO"] + "\n" + question)
+        conv.append_message(conv.roles[1], None)
+        prompt = conv.get_prompt() + "<sync>"
+        return tensor, ts, tokenizer_MMODAL_token_all(prompt, tokenizer, return_tensors="pt")
+
+    # ---- CPU leg: the oracle end to end on this box's host cores (no extrapolation)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = max(1, min(32, cores))
+    torch.set_num_threads(threads)
+    tok_cpu, proc_cpu = builder.ByteTokenizer(cfg.vocab_size), builder._image_processor(cfg, ckpt)
+    sd = synth.state_dict(cfg)
+    t0 = time.perf_counter()
+    tensor, ts, ids = driver_inputs(tok_cpu, proc_cpu)
+    t_pre_cpu = time.perf_counter() - t0
+    ora = O.Oracle(cfg, {k: v.float() for k, v in sd.items()}, emulate_bf16=False)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ids_fp32 = ora.generate(ids, tensor.float(), ts, head=1, max_new_tokens=n_new, eos_token_id=None)
+        t_gen_cpu = time.perf_counter() - t0
+    cpu = {"value": 1.0 / (t_pre_cpu + t_gen_cpu), "unit": "videos/s", "cores": threads, "kind": "port",
+           "sample": f"the whole C1 workload, no extrapolation: file read + PIL/HF preprocessing {t_pre_cpu * 1e3:.0f} ms, oracle fp32 ViT + slot pool + prefill L={len(ids) - 1 + args.frames * cfg.tokens_per_frame} + {n_new} greedy tokens {t_gen_cpu * 1e3:.0f} ms",
+           "decode_tok_s": None, "ids": ids_fp32}
+    line = {"metric": "videos/sec + decode tok/s, TRACE-7B 128-frame, 1/2/4/8 MI355X", "value": None, "unit": "videos/s", "n_gpus": 0, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{CONFIGS['c1']['name']}: {args.frames} frames sampled from a 96-frame 160x120 y4m file, prefill L={len(ids) - 1 + args.frames * cfg.tokens_per_frame}, {n_new} greedy tokens, heads=[1], EOS off",
+                       "baseline_config": "c1", "videos_per_step_per_gpu": 1, "frames": args.frames, "new_tokens": n_new,
+                       "model": "tiny-layer geometry of the reference fixtures (hidden 4096, 2 decoder layers, 3-layer CLIP at 56x56), synthetic weights"},
+            "cpu_baseline": cpu}
+    if not torch.cuda.is_available():
+        line["config"]["note"] = "no HIP device visible: CPU leg only (the HIP path has no CPU fallback)"
+        print(json.dumps(line), flush=True)
+        return
+    # ---- GPU leg: the drop-in surface over the C ABI
+    el_dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    tokenizer, model, processor, _ = builder.load_pretrained_model(ckpt, None, get_model_name_from_path(ckpt), max_new_tokens=max(64, n_new), torch_dtype=el_dtype)
+
+    def step():
+        tensor_g, ts_g, ids_g = driver_inputs(tokenizer, processor, engine=model)          # frames preprocessed on the device (trace_preprocess_frames)
+        heads = [1]
+        out = model.generate(ids_g.unsqueeze(0), attention_mask=None, images_or_videos=[tensor_g], modal_list=["video"], do_sample=False, temperature=0.0,
+                             max_new_tokens=n_new, use_cache=True, pad_token_id=tokenizer.eos_token_id, eos_token_id=-1, video_timestamps=[ts_g], heads=heads)
+        return out[0].tolist(), ts_g, tensor_g
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids_hip, ts_g, tensor_g = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # ids: against the oracle that rounds where the engine stores 16-bit values, on the frames the device preprocessing produced
+    ora_b = O.Oracle(cfg, sd, emulate_bf16=(True if el_dtype == torch.bfloat16 else el_dtype))
+    with torch.no_grad():
+        ids_emu, lg = ora_b.generate(ids, tensor_g.float().cpu(), ts_g, head=1, max_new_tokens=n_new, eos_token_id=None, return_logits=True)
+    srt = torch.sort(torch.where(torch.isfinite(lg), lg, torch.full_like(lg, -1e30)), dim=-1, descending=True).values
+    margin = (srt[:, 0] - srt[:, 1]).tolist()
+    first_diff = next((i for i, (a, b) in enumerate(zip(ids_hip, ids_emu)) if a != b), None)
+    V = cfg.vocab_size
+    line.update({"value": args.steps / dt, "n_gpus": 1, "ms_per_step": dt / args.steps * 1e3,
+                 "ids": {"hip": ids_hip, "oracle_16bit_emulating": ids_emu, "oracle_fp32_host_preprocessing": ids_fp32, "equal": ids_hip == ids_emu,
+                         "first_difference": first_diff, "oracle_top2_margin_there": (margin[first_diff] if first_diff is not None else None),
+                         "time_score_head_steps": sum(1 for t in ids_emu if t > V)},
+                 "parsed": parse_output_ids(ids_hip, tokenizer, model)})
+    print(json.dumps(line), flush=True)
+    model.engine.close()
 
 
 def self_launch(args) -> None:
@@ -193,6 +305,10 @@ def main():
         args.fp8 = bool(preset.get("fp8", False))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.config == "c1":
+        if args.gpus != 1:
+            raise SystemExit("--config c1 is the single-clip plumbing case: one process, at most one GPU")
+        return run_c1(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)                                       # never returns
 

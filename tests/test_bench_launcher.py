@@ -74,3 +74,18 @@ def test_affinity_plan_and_sysfs_parsing(tmp_path):
     assert td.plan_affinity(allowed, 0, 1, cpus)[0] == allowed          # one rank: unchanged
     assert td.plan_affinity([0, 1, 2], 1, 8, [])[0] == [0, 1, 2]        # fewer CPUs than ranks: unchanged
     assert td.gather_floats([1.5, 2]) == [[1.5, 2.0]]                   # no process group: this rank only
+
+
+def test_c1_cpu_leg_runs_here():
+    """BASELINE config 1's CPU leg ("C1 runs fully on CPU end-to-end"): with no HIP device the line still comes out, from the
+    oracle alone — clip file -> process_video -> llama_2 prompt -> tokenizer_MMODAL_token_all -> 32 greedy ids starting on the time head."""
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present: tests/test_gpu_bench_launch.py runs both legs")
+    r = _run(["--config", "c1", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 0 and d["value"] is None and "CPU leg only" in d["config"]["note"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and len(cb["ids"]) == 32
+    assert 320 < cb["ids"][0] <= 320 + 13                       # generation starts on the time head (heads=[1]); tiny vocabulary V = 320

@@ -30,6 +30,24 @@ def test_bench_tiny_under_torchrun():
     assert d["steps_repeat_exactly"] is True, d.get("steps_repeat_detail")
 
 
+def test_bench_c1_single_clip_from_a_file():
+    """BASELINE config 1 on the GPU box: a clip FILE (y4m) -> process_video -> prompt -> generate through the drop-in surface, 8 frames, 32 greedy
+    tokens; the ids equal the oracle's (the oracle that rounds where the engine stores bf16) at least up to its first near-tie, the CPU leg (the
+    oracle end to end, fp32) is timed beside it, and the line carries the new per-shape roofline fields of the default config's line format."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c1", "--steps", "2", "--warmup", "1"], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["baseline_config"] == "c1" and d["config"]["frames"] == 8
+    ids = d["ids"]
+    assert len(ids["hip"]) == 32 == len(ids["oracle_16bit_emulating"])
+    if not ids["equal"]:
+        assert ids["oracle_top2_margin_there"] < 0.1, ids                 # a near-tie of the random-weight text head may fall either way
+    assert ids["first_difference"] is None or ids["first_difference"] >= 1
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and "no extrapolation" in d["cpu_baseline"]["sample"]
+    assert set(d["parsed"]) >= {"timestamps", "scores", "captions"}
+
+
 def test_evaluate_driver_under_torchrun(tmp_path):
     """python -m trace_amd.evaluate under torch.distributed.run: sharding, device preprocessing, batched decode, the RCCL
     gather of packed ids and the parser, end to end on a synthetic tiny checkpoint and .npy frame files."""

@@ -218,3 +218,40 @@ def test_batch_40_equals_singles():
                 break
             assert out[b][i] == single[0][i], (b, i, out[b], single[0])
     eng.close()
+
+
+def test_batch_128_equals_singles():
+    """The bench's own shape at full geometry (round-3 review: the largest full-size batch-vs-singles check was 40): 128 different 128-frame videos
+    through generate() — 170-frame tower stream across video boundaries, prefill in runs of four, the WIDE decode step (small-M MFMA GEMMs, split-K
+    partial rows, two head passes) through all 32 layers at ctx ~ 2000 — against rows 0 / 63 / 127 decoded alone (batch-1 fused-norm GEMV path) in a
+    spare KV slot: step-0 logits within 0.15, free-running greedy ids equal up to the single run's first near-tie."""
+    cfg = tcfg.trace_7b(128)
+    ids = synth.synth_prompt_ids(cfg, n_text=176, video_pos=150).tolist()
+    L = 176 - 1 + 128 * cfg.tokens_per_frame
+    nb, n_new = 128, 24
+    eng = TraceEngine(cfg, max_batch=nb + 1, max_ctx=(L + n_new + 63) // 64 * 64, max_frames=128, max_new_tokens=n_new)
+    eng.load_weights(synth.iter_weights(cfg, device="cuda:0"))
+    ts = [[float(i)] for i in range(128)]
+    vids = [synth.synth_frames(cfg, 300 + b, num_frames=128).to(torch.bfloat16).cuda() for b in range(nb)]
+    out, heads = eng.generate(vids, [ts] * nb, [ids] * nb, [1] * nb, n_new, eos=-1)
+    assert len(out) == nb and all(len(o) == n_new for o in out) and all(h in (0, 1, 2) for h in heads)
+    lgb = eng.decode_begin(list(range(nb)), [1] * nb, n_new, eos=-1, want_logits=True).float().cpu()      # step-0 logits of the whole batch
+    checked = 0
+    for b in (0, 63, 127):
+        eng.encode_video(vids[b], ts)
+        eng.prefill(nb, eng.splice(ids))                                   # the spare slot: the batch's slots stay as generate() left them
+        lg1 = eng.decode_begin([nb], [1], n_new, eos=-1, want_logits=True).float().cpu()[0]
+        fin = torch.isfinite(lg1)
+        assert torch.equal(torch.isfinite(lgb[b]), fin)
+        err = (lgb[b][fin] - lg1[fin]).abs().max().item()
+        assert err < LOGIT_TOL, (b, err)
+        lgs = [lg1] + [eng.decode_steps(1, use_graph=False, want_logits=True).float().cpu()[0] for _ in range(n_new - 1)]
+        single, _ = eng.decode_read()
+        for i in range(n_new):
+            top = torch.topk(torch.where(torch.isfinite(lgs[i]), lgs[i], torch.full_like(lgs[i], -1e30)), 2).values
+            if float(top[0] - top[1]) < 2 * LOGIT_TOL:
+                break
+            assert out[b][i] == single[0][i], (b, i, out[b], single[0])
+            checked += 1
+    assert checked >= 6, checked                                           # (random-weight logits: a near-tie usually arrives within a few tokens)
+    eng.close()

@@ -675,6 +675,95 @@ def bf16_anchor_goldens(tmp):
     print("32 layers, reference bf16 (streamed) vs fp32: max %.3f rms %.4f; arg-max differs on %d of %d steps" % (e32.max(), e32.pow(2).mean().sqrt(), flips, lg32.shape[0]))
 
 
+def stc_goldens(tmp):
+    """STCConnector (north_star names it; multimodal_projector/builder.py:138-249), as far as it can be pinned without timm: the REFERENCE's own
+    `STCConnector.__init__` / `.forward` run here — its einops layouts ('b t (h w) d -> b d t h w', '(b t) d h w', '(t h w) d' token order), its
+    `Conv3d(k = s = (2, 2, 2), padding = 1) + SiLU` sampler and its `Linear - GELU - Linear` readout are torch / einops code inside the reference — with
+    timm's `RegStage` (un-vendored, not installed) replaced by the restatement below.  So two of the four stages and all of the data movement are the
+    reference's; the RegStage block arithmetic stays this build's reading of timm 0.6.13 (UNPINNED, said so wherever STC is mentioned)."""
+    import dataclasses
+    import torch.nn.functional as F
+    from trace_amd import config as tcfg, synth
+    from Trace.trace.model.multimodal_projector import builder as pb
+
+    class LN2d(nn.LayerNorm):                      # timm LayerNorm2d: LayerNorm over the channels of an NCHW tensor, eps 1e-6
+        def __init__(s, c, eps=1e-6):
+            super().__init__(c, eps=eps)
+
+        def forward(s, x):
+            return F.layer_norm(x.permute(0, 2, 3, 1), s.normalized_shape, s.weight, s.bias, s.eps).permute(0, 3, 1, 2)
+
+    class ConvNormAct(nn.Module):
+        def __init__(s, cin, cout, k, groups=1, act=True):
+            super().__init__()
+            s.conv = nn.Conv2d(cin, cout, k, padding=k // 2, groups=groups, bias=False)
+            s.bn = LN2d(cout)
+            s.act = act
+
+        def forward(s, x):
+            x = s.bn(s.conv(x))
+            return F.silu(x) if s.act else x
+
+    class SE(nn.Module):
+        def __init__(s, c, rd):
+            super().__init__()
+            s.fc1, s.fc2 = nn.Conv2d(c, rd, 1), nn.Conv2d(rd, c, 1)
+
+        def forward(s, x):
+            g = x.mean((2, 3), keepdim=True)
+            return x * torch.sigmoid(s.fc2(F.silu(s.fc1(g))))
+
+    class Bottleneck(nn.Module):                   # regnet Bottleneck at bottle_ratio 1, group_size 1 (depthwise), se_ratio 0.25 of the INPUT width
+        def __init__(s, cin, cout):
+            super().__init__()
+            s.conv1 = ConvNormAct(cin, cout, 1)
+            s.conv2 = ConvNormAct(cout, cout, 3, groups=cout)
+            s.se = SE(cout, int(round(cin * 0.25)))
+            s.conv3 = ConvNormAct(cout, cout, 1, act=False)
+            s.downsample = ConvNormAct(cin, cout, 1, act=False) if cin != cout else None
+
+        def forward(s, x):
+            sc = x if s.downsample is None else s.downsample(x)
+            return F.silu(s.conv3(s.se(s.conv2(s.conv1(x)))) + sc)
+
+    class RegStageRestated(nn.Module):
+        def __init__(s, depth, in_chs, out_chs, stride=1, dilation=1, act_layer=None, norm_layer=None):
+            super().__init__()
+            assert stride == 1 and dilation == 1 and act_layer is nn.SiLU
+            for i in range(depth):
+                s.add_module(f"b{i + 1}", Bottleneck(in_chs if i == 0 else out_chs, out_chs))
+
+        def forward(s, x):
+            for m in s.children():
+                x = m(x)
+            return x
+
+    pb.RegStage, pb.LayerNorm2d = RegStageRestated, LN2d
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), mm_projector_type="stc_connector", vision_image_size=84, vision_hidden_size=256,
+                              vision_num_heads=4, mm_hidden_size=256)                       # the geometry of tests/test_gpu_stc.py: 6 x 6 patches
+    conn = pb.STCConnector(types.SimpleNamespace(mm_hidden_size=cfg.mm_hidden_size, hidden_size=cfg.hidden_size, downsample_num=1)).float().eval()
+    sd = synth.state_dict(cfg)
+    P = "model.mm_projector."
+    mine = {k[len(P):]: v.float() for k, v in sd.items() if k.startswith(P)}
+    assert set(mine) == set(conn.state_dict()), set(mine) ^ set(conn.state_dict())
+    conn.load_state_dict(mine, strict=True)
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(4, cfg.vision_patches, cfg.vision_hidden_size, generator=g).to(torch.bfloat16).float()
+    with torch.no_grad():
+        out = conn(feats[None], h=6, w=6)[0]                                                 # [3 * 4 * 4, 4096]
+        # the same forward with BOTH RegStages switched to identity-width stand-ins is not possible (s1 changes the width), so the pinned part is
+        # also captured on its own: sampler + readout applied to a given [1, C, t, h, w] tensor through the reference's modules
+        z = torch.randn(1, cfg.hidden_size, 4, 6, 6, generator=g) * 0.5
+        zs = conn.sampler(z)
+        zr = conn.readout(zs[0].permute(1, 2, 3, 0).reshape(-1, cfg.hidden_size))
+    cols = np.arange(0, cfg.hidden_size, 8)
+    np.savez_compressed(os.path.join(OUT, "stc_connector.npz"), seed=np.array(3), out_cols=cols, out=out.numpy()[:, cols].astype(np.float32),
+                        out_shape=np.array(out.shape), sampler_in_seed_note=np.array("z = randn(1, C, 4, 6, 6, same generator after feats) * 0.5"),
+                        sampler_out_shape=np.array(zs.shape), sampler_readout=zr.numpy()[:, cols].astype(np.float32),
+                        out_absmax=np.array(float(out.abs().max())))
+    print("stc_connector: out", tuple(out.shape), "absmax %.3f" % out.abs().max().item(), "sampler out", tuple(zs.shape))
+
+
 def tokenizer_goldens():
     """SURVEY 8f.2, tokenizer hookup: a tiny sentencepiece LlamaTokenizer (trained here on this repo's own SURVEY.md + DESIGN.md text,
     vocabulary 512 — the GPU test widens the tiny config's embedding table to match; the trained model file is committed as data) loaded the way the reference loads its tokenizer
@@ -785,6 +874,9 @@ if __name__ == "__main__":
         medium_llm_goldens(tmp, torch.float16)
         deep_llm_goldens(tmp, torch.float16)
         sys.exit(0)
+    if "--stc-only" in sys.argv:
+        stc_goldens(tmp)
+        sys.exit(0)
     if "--bf16-anchor-only" in sys.argv:
         bf16_anchor_goldens(tmp)
         sys.exit(0)
@@ -805,5 +897,6 @@ if __name__ == "__main__":
     videomme_goldens(tmp)
     full_depth_goldens(tmp)
     bf16_anchor_goldens(tmp)
+    stc_goldens(tmp)
     tokenizer_goldens()
     preprocess_goldens()

@@ -365,3 +365,29 @@ def test_real_width_f16_fixtures_pin_the_oracle(golden_dir, name, layers):
     if "tf_logits_ref_fp16" in M:
         fin = np.isfinite(M["tf_logits"])
         assert np.abs(M["tf_logits_ref_fp16"][fin] - M["tf_logits"][fin]).max() < (0.025 if layers == 1 else 0.045)
+
+
+def test_stc_connector_matches_reference_forward(golden_dir):
+    """STC connector: the oracle against the REFERENCE's own STCConnector.forward (stc_connector.npz — its einops layouts, Conv3d
+    sampler + SiLU, GELU readout and '(t h w)' token order run as the reference wrote them; timm's RegStage replaced by the restated block, so the
+    block arithmetic itself stays unpinned)."""
+    import dataclasses
+    import torch.nn.functional as F
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=4), mm_projector_type="stc_connector", vision_image_size=84, vision_hidden_size=256,
+                              vision_num_heads=4, mm_hidden_size=256)
+    M = np.load(os.path.join(golden_dir, "stc_connector.npz"))
+    sd = {k: v.float() for k, v in synth.state_dict(cfg).items()}
+    ora = O.Oracle(cfg, sd, emulate_bf16=False)
+    g = torch.Generator().manual_seed(int(M["seed"]))
+    feats = torch.randn(4, cfg.vision_patches, cfg.vision_hidden_size, generator=g).to(torch.bfloat16).float()
+    out = ora.stc_connector(feats)
+    assert list(out.shape) == M["out_shape"].tolist() == [48, 4096]
+    np.testing.assert_allclose(out.numpy()[:, M["out_cols"]], M["out"], rtol=2e-4, atol=2e-4 * float(M["out_absmax"]))
+    # the part that is the reference's own arithmetic, on its own: Conv3d(k = s = 2, p = 1) + SiLU, then Linear - GELU(erf) - Linear over '(t h w)' rows
+    z = torch.randn(1, cfg.hidden_size, 4, 6, 6, generator=g) * 0.5
+    P = "model.mm_projector."
+    zs = F.silu(F.conv3d(z, sd[P + "sampler.0.weight"], sd[P + "sampler.0.bias"], stride=2, padding=1))
+    assert list(zs.shape) == M["sampler_out_shape"].tolist() == [1, 4096, 3, 4, 4]
+    rows = zs[0].permute(1, 2, 3, 0).reshape(-1, cfg.hidden_size)
+    zr = F.gelu(rows @ sd[P + "readout.0.weight"].t() + sd[P + "readout.0.bias"]) @ sd[P + "readout.2.weight"].t() + sd[P + "readout.2.bias"]
+    np.testing.assert_allclose(zr.numpy()[:, M["out_cols"]], M["sampler_readout"], rtol=2e-4, atol=2e-4)

@@ -484,6 +484,11 @@ def main():
                          "ms_per_step_min_median_max": [float(np.min([r[0] for r in per_rank])), float(np.median([r[0] for r in per_rank])), float(np.max([r[0] for r in per_rank]))],
                          "host_placement_rank0": place,
                          "note": "ms_per_step per rank = that rank's own K steps up to its own synchronize (before the closing barrier); `ms_per_step` of the line is the max over ranks with the barrier; stage times are re-timed per rank after the timed region"},
+            # what the ids of this configuration are worth (profiles/r04_fp8_error_growth.txt: no e4m3 scheme — W8A8, weight-only, 128-k block-scaled —
+            # keeps the 32-layer 13-way time / score decisions within twice the flip count of the reference's own bf16 run; the bf16 / fp16 paths do)
+            "parity": ("fp8 tolerance only: logits within the a-priori e4m3 budget of the bf16 path (tests/test_gpu_fp8.py); about a third of the 13-way time / score "
+                       "arg-max decisions of a random-weight 32-layer stack differ from the reference's — use the bf16 path where ids must match" if args.fp8 else
+                       "reference-anchored: logits inside the reference's own 16-bit-vs-fp32 deviation, 13-way ids bit-exact vs the 16-bit-emulating oracle (tests/test_gpu_*.py)"),
             "steps_repeat_exactly": bool(steps_repeat), **({"steps_repeat_detail": repeat_detail[:12]} if repeat_detail else {}),
             "decode_tok_s": world * B * (n_new - 1) / (t_dec * 1e-3),
             "stages_ms": {"vit_slotpool_per_video": t_enc, "prefill_per_video": t_pre, f"decode_{n_new - 1}_steps_batch{B}": t_dec,

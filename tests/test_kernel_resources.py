@@ -93,9 +93,12 @@ def test_round3_kernels_keep_their_budgets(res):
     assert len(dec) >= 2, list(res["gemm"])
     for k, v in dec.items():
         assert v["ScratchSize"] == 0, (k, v)
-    pro = {k: v for k, v in _pick(res["decode"], "skinny_lds_kernel").items() if k.rstrip("E").endswith("ELb1EEvPKtiS2_iPtiS2_iiiiiiiiPfPjiiNS_9SkinnyPro") or "ELb1EE" in k}
-    assert pro, list(res["decode"])[:4]
-    for k, v in pro.items():
+    import re
+    # skinny_lds_kernel<EPI, NB, NT, PRO>: PRO = 1 (RMSNorm prologue, round 3) and PRO = 2 (SwiGLU prologue, round 4) instantiations
+    pro = {k: (v, int(m.group(1))) for k, v in _pick(res["decode"], "skinny_lds_kernel").items()
+           for m in [re.search(r"skinny_lds_kernelILi\d+ELi\d+ELi\d+ELi([12])EE", k)] if m}
+    assert {kind for _, kind in pro.values()} == {1, 2}, list(res["decode"])[:6]
+    for k, (v, _) in pro.items():
         assert v["ScratchSize"] == 0, (k, v)
 
 

@@ -60,7 +60,7 @@ struct SkinnyPro {
 };
 constexpr int SKINNY_PRO_ROWS = 4;
 
-template <int EPI, int NB, int NT, bool PRO = false>
+template <int EPI, int NB, int NT, int PRO = 0>
 __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W, int ldw,
                                                          bf16_t* __restrict__ out, int ldo, const bf16_t* __restrict__ R, int ldr,
                                                          int B, int K, int chunk_units, int KS, int T, int WPT, int ntiles,
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restric
 
     // ---- park X[:, chunk] in LDS in fragment order: combo c = (unit*2 + half)*NB + nb, lane (r, g) holds
     //      X[16 nb + r][(u_beg + unit)*64 + g*16 + half*8 .. +8]  (zeros for rows >= B) ----
-    if constexpr (PRO) {
+    if constexpr (PRO == 1) {
         if (!parked) {
             __shared__ float s_ss[SKINNY_PRO_ROWS][8];
             const int nthr = blockDim.x, ngrp = K >> 3;          // 8-element groups per row
@@ -177,6 +177,40 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(const bf16_t* __restric
                         }
                     }
                 }
+            }
+            __syncthreads();
+            parked = true;
+        }
+    }
+    if constexpr (PRO == 2) {
+        // SwiGLU prologue (round 4, batch 1 .. SKINNY_PRO_ROWS): this GEMV (down) takes its activations from the gate|up GEMV's fp32 partial rows
+        // [pro.ks][SK_ROWS][2 K] (16-row interleaved: columns [32p, 32p+16) gate, [32p+16, 32p+32) up of activation columns [16p, 16p+16)) and does
+        // swiglu_combine_kernel's work for ITS K-chunk while it parks: sums in chunk order, silu(gate) * up in fp32, one bf16 rounding — the same
+        // arithmetic, so the products are bit-identical to the two-kernel form; one launch and one kernel boundary less per layer.  The row groups
+        // of a chunk each redo it (B x chunk x 2 x ks floats from L2: 15 MB per launch at one row).
+        if (!parked) {
+            const int ngrp = nu * 8, N2 = 2 * K;
+            for (int idx = tid; idx < B * ngrp; idx += blockDim.x) {
+                const int b = idx / ngrp, e8l = idx - b * ngrp, e8 = u_beg * 8 + e8l;
+                const float* base = pro.part + (size_t)b * N2 + (size_t)(e8 >> 1) * 32 + (e8 & 1) * 8;
+                f32x4_t g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f}, u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f};
+                for (int k2 = 0; k2 < pro.ks; ++k2) {          // chunk order
+                    const float* q = base + (size_t)k2 * SK_ROWS * N2;
+                    g0 += *reinterpret_cast<const f32x4_t*>(q);
+                    g1 += *reinterpret_cast<const f32x4_t*>(q + 4);
+                    u0 += *reinterpret_cast<const f32x4_t*>(q + 16);
+                    u1 += *reinterpret_cast<const f32x4_t*>(q + 20);
+                }
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = g0[e] / (1.f + __expf(-g0[e])) * u0[e];
+                    o[4 + e] = g1[e] / (1.f + __expf(-g1[e])) * u1[e];
+                }
+                const u32x4_t y = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+                // fragment order, as in the RMSNorm prologue: combo (unit, half) -> 1 KB image, lane (r = b, g): X[b][unit*64 + g*16 + half*8 .. +8]
+                const int unit = e8l >> 3, g2 = (e8l & 7) >> 1, half = e8l & 1;
+                xs[((unit * 2 + half) * NB) * 64 + g2 * 16 + b] = y;
             }
             __syncthreads();
             parked = true;
@@ -982,7 +1016,7 @@ size_t skinny_ws_floats(int N, int K, int epi) {
 }
 int skinny_ks(int N, int K, int epi, int B) { return skinny_plan(N, K, epi, B).KS; }
 
-template <int EPI, int NB, int NT, bool PRO = false>
+template <int EPI, int NB, int NT, int PRO = 0>
 static int skinny_lds_launch(const SkinnyPlan& p, const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo,
                              const bf16_t* R, int ldr, int B, int K, float* ws, unsigned int* tickets, int tiled, hipStream_t s,
                              const SkinnyPro& pro = SkinnyPro{}) {
@@ -1012,8 +1046,19 @@ int launch_skinny_gemm_fused_norm(const float* part_in, int ks_in, const bf16_t*
     if (!ws || ws_floats < skinny_plan_ws(p, N, EPI_PARTIAL, B)) return TRACE_ERR_ARG;
     if ((K >> 3) > 2 * p.threads) return TRACE_ERR_STATE;                     // MAXG groups per thread: the caller keeps the unfused pair for this shape
     const SkinnyPro pro{part_in, ks_in, R, ldr, xout, ldx, w, eps};
-    return skinny_nt(N, EPI_PARTIAL) == 2 ? skinny_lds_launch<EPI_PARTIAL, 1, 2, true>(p, nullptr, K, Wtiled, K, nullptr, N, nullptr, 0, B, K, ws, nullptr, 1, s, pro)
-                                           : skinny_lds_launch<EPI_PARTIAL, 1, 1, true>(p, nullptr, K, Wtiled, K, nullptr, N, nullptr, 0, B, K, ws, nullptr, 1, s, pro);
+    return skinny_nt(N, EPI_PARTIAL) == 2 ? skinny_lds_launch<EPI_PARTIAL, 1, 2, 1>(p, nullptr, K, Wtiled, K, nullptr, N, nullptr, 0, B, K, ws, nullptr, 1, s, pro)
+                                           : skinny_lds_launch<EPI_PARTIAL, 1, 1, 1>(p, nullptr, K, Wtiled, K, nullptr, N, nullptr, 0, B, K, ws, nullptr, 1, s, pro);
+}
+
+// The down GEMV with the SwiGLU prologue (SkinnyPro, PRO == 2): out-partials[ks][SK_ROWS][N] = (silu(sum_k gate) * sum_k up) . Wtiled^T from the
+// gate|up GEMV's partial rows part_gu [ks_gu][SK_ROWS][2 K].  B <= SKINNY_PRO_ROWS, tiled weights, part_gu and ws must not alias.
+int launch_skinny_gemm_fused_swiglu(const float* part_gu, int ks_gu, const bf16_t* Wtiled, int B, int N, int K, float* ws, size_t ws_floats, hipStream_t s) {
+    if (B < 1 || B > SKINNY_PRO_ROWS || K % 64 || N % 16 || ks_gu < 1 || !part_gu || part_gu == ws) return TRACE_ERR_ARG;
+    const SkinnyPlan p = skinny_plan(N, K, EPI_PARTIAL, B);
+    if (!ws || ws_floats < skinny_plan_ws(p, N, EPI_PARTIAL, B)) return TRACE_ERR_ARG;
+    const SkinnyPro pro{part_gu, ks_gu, nullptr, 0, nullptr, 0, nullptr, 0.f};
+    return skinny_nt(N, EPI_PARTIAL) == 2 ? skinny_lds_launch<EPI_PARTIAL, 1, 2, 2>(p, nullptr, K, Wtiled, K, nullptr, N, nullptr, 0, B, K, ws, nullptr, 1, s, pro)
+                                           : skinny_lds_launch<EPI_PARTIAL, 1, 1, 2>(p, nullptr, K, Wtiled, K, nullptr, N, nullptr, 0, B, K, ws, nullptr, 1, s, pro);
 }
 
 // EPI_PARTIAL: `out` is unused, ldo = N, the fp32 partial rows [KS = skinny_ks()][SK_ROWS][N] land in ws.

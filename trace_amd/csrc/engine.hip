@@ -1112,13 +1112,15 @@ static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
     return head_and_select(c, c->dH, 1, logits_out, s);
 }
 
+int g_decode_fuse_swiglu = 1;      // decode_step_fused: SwiGLU inside the down GEMV (bit-identical to swiglu_combine + GEMV; A/B: trace_op_set_gemm_variant(180 + x))
 int g_decode_fuse_norm_rows = 1;   // batches up to this size take decode_step_fused (0 = never; A/B: trace_op_set_gemm_variant(170 + rows)).  Measured, ms per step,
                                    // unfused / fused (profiles/r03_decode_small_ab.txt): batch 1 3.596 / 3.531, batch 2 3.698 / 3.781, batch 4 3.888 / 4.327 — every
                                    // workgroup redoes the row sums, which only a single row repays
 // One decode step for 1..4 sequences (the reference drivers' own call shape is 1): the two "sum the partial rows + residual -> new residual, RMSNorm"
-// kernels of a layer are folded into the GEMVs that consume their output (decode.hip, SkinnyPro) — 5 launches per layer instead of 7:
+// kernels of a layer are folded into the GEMVs that consume their output (decode.hip, SkinnyPro), and (round 4) the SwiGLU combine into the down
+// GEMV — 4 launches per layer instead of 7:
 //   qkv GEMV [sums the previous layer's down partials + residual, input norm] -> attention (RoPE / append / attention) -> o GEMV
-//   -> gate|up GEMV [sums the o partials + residual, post-attention norm] -> SwiGLU combine -> down GEMV
+//   -> gate|up GEMV [sums the o partials + residual, post-attention norm] -> down GEMV [sums the gate|up partials, SwiGLU]
 // Partial rows alternate between sk_ws (written by o / down, read by the fused GEMVs) and sk_ws2 (written by the fused GEMVs, read by the attention /
 // the combine); the residual rows alternate between dX and dX2 (a fused GEMV reads one and writes the other: its workgroups all read the whole row).
 static int decode_step_fused(trace_ctx* c, float* logits_out, hipStream_t s) {
@@ -1146,8 +1148,12 @@ static int decode_step_fused(trace_ctx* c, float* logits_out, hipStream_t s) {
         LCHK(launch_skinny_gemm_fused_norm(c->sk_ws, ks_o, xa, H, xb, H, W.rms2, c->c.rms_eps, W.wgu_d, B, 2 * I, H, c->sk_ws2, c->sk_ws_floats, s));
         if (e1) hipEventRecord(e1, s);
         std::swap(xa, xb);
-        LCHK(launch_swiglu_combine(c->sk_ws2, ks_g, 2 * I, c->dACT, I, B, s));
-        LCHK(launch_skinny_gemm(c->dACT, I, W.wd_d, I, nullptr, H, nullptr, 0, B, H, I, EPI_PARTIAL, 1, SKWS(c), s));
+        if (g_decode_fuse_swiglu) {        // SwiGLU folded into the down GEMV's parking step (round 4): 4 launches per layer
+            LCHK(launch_skinny_gemm_fused_swiglu(c->sk_ws2, ks_g, W.wd_d, B, H, I, c->sk_ws, c->sk_ws_floats, s));
+        } else {
+            LCHK(launch_swiglu_combine(c->sk_ws2, ks_g, 2 * I, c->dACT, I, B, s));
+            LCHK(launch_skinny_gemm(c->dACT, I, W.wd_d, I, nullptr, H, nullptr, 0, B, H, I, EPI_PARTIAL, 1, SKWS(c), s));
+        }
     }
     // an even number of fused GEMVs: the residual rows are back in dX; the last layer's down partials + residual -> final norm -> heads
     LCHK(launch_add_rmsnorm(c->sk_ws, ks_d, xa, H, xa, H, c->final_norm, c->dH, H, B, H, c->c.rms_eps, s));
@@ -1443,6 +1449,7 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
     if (variant >= 150 && variant <= 151) { g_vit_ln_fold = variant - 150; return TRACE_OK; }
     if (variant >= 170 && variant <= 174) { g_decode_fuse_norm_rows = variant - 170; return TRACE_OK; }
+    if (variant >= 180 && variant <= 181) { g_decode_fuse_swiglu = variant - 180; return TRACE_OK; }
     if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : 32; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }

@@ -133,6 +133,8 @@ int launch_skinny_gemm(const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_
 // result as its activations — add_rmsnorm folded into the next GEMV (B <= 4; decode.hip SkinnyPro); output = EPI_PARTIAL rows in ws (!= part_in)
 int launch_skinny_gemm_fused_norm(const float* part_in, int ks_in, const bf16_t* R, int ldr, bf16_t* xout, int ldx, const bf16_t* w, float eps,
                                   const bf16_t* Wtiled, int B, int N, int K, float* ws, size_t ws_floats, hipStream_t s);
+// the down GEMV fed by the gate|up GEMV's partial rows [ks_gu][SK_ROWS][2 K]: SwiGLU (swiglu_combine's arithmetic) folded into its parking step (B <= 4)
+int launch_skinny_gemm_fused_swiglu(const float* part_gu, int ks_gu, const bf16_t* Wtiled, int B, int N, int K, float* ws, size_t ws_floats, hipStream_t s);
 bool skinny_fused_norm_ok(int N, int K, int B);      // false: this shape keeps the GEMV + add_rmsnorm pair
 size_t skinny_ws_floats(int N, int K, int epi);
 int skinny_ks(int N, int K, int epi, int B);

@@ -483,3 +483,75 @@ def test_real_vocabulary_vs_reference_fixture(golden_dir):
                 if ref_top[i, 0] - ref_top[i, 1] > 2 * LOGIT_TOL:
                     assert out[b][i] == int(ref_idx[i, 0]), (nb, b, i)
     eng.close()
+
+
+def test_batch1_swiglu_fold_is_bit_identical(golden_dir):
+    """Round 4: at batch 1 the down GEMV does the SwiGLU combine itself while it parks its activations (decode.hip, SkinnyPro PRO = 2).  Same sums in
+    the same order, same fp32 silu * up, one bf16 rounding: the logits of every teacher-forced step must equal the two-kernel form's bit for bit —
+    at the real Mistral-7B MLP width (K = 14336 cut in chunks, two layers) and at the tiny geometry (one chunk)."""
+    import dataclasses
+    from trace_amd.engine import ops
+    for cfg in (dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336, num_hidden_layers=2), tcfg.tiny(num_frames=4)):
+        M = np.load(os.path.join(golden_dir, "medium_llm.npz"))
+        eng = TraceEngine(cfg, max_batch=1, max_ctx=192, max_frames=4, max_new_tokens=64)
+        eng.load_weights(synth.iter_weights(cfg))
+        frames = synth.synth_frames(cfg, 0).to(torch.bfloat16)
+        forced = M["forced_ids"].tolist()[:20]
+        n = len(forced) + 1
+        runs = {}
+        try:
+            for fold in (1, 0):
+                ops.set_gemm_variant(180 + fold)
+                eng.encode_video(frames, M["timestamps"].tolist())
+                eng.prefill(0, eng.splice(M["input_ids"].tolist()))
+                lgs = [eng.decode_begin([0], [1], n, eos=-1, forced=[forced], want_logits=True).float().cpu()]
+                for _ in range(n - 1):
+                    lgs.append(eng.decode_steps(1, use_graph=False, want_logits=True).float().cpu())
+                runs[fold] = (torch.stack(lgs), eng.decode_read()[0])
+        finally:
+            ops.set_gemm_variant(181)
+        assert torch.equal(runs[1][0], runs[0][0]), (runs[1][0] - runs[0][0]).abs().max()
+        assert runs[1][1] == runs[0][1]
+        eng.close()
+
+
+@pytest.mark.parametrize("geometry", ["vit_l_14_336", "tiny"])
+def test_fused_patch_embed_matches_three_pass_front_end(geometry):
+    """Round 4: the ViT front end as one kernel — patches read straight from the frame tensor (no im2col matrix), MFMA GEMM, CLS / position
+    embeddings, pre_layrnorm and the first layer's LayerNorm-fold statistics in the epilogue (patch_embed.hip) — against the round-1 path it
+    replaces (im2col -> GEMM -> assemble [-> row statistics], trace_op_set_gemm_variant(160)).  Same rounding points, another fp32 summation
+    order: through ONE encoder layer the features agree to a bf16 ulp here and there.  Both frame dtypes the ABI takes (16-bit, fp32), a small
+    call (LayerNorm kernels) and a 24-frame call (LayerNorm fold: the statistics the fused kernel leaves are consumed by the first qkv GEMM)."""
+    import dataclasses
+    from trace_amd.engine import ops
+    if geometry == "tiny":
+        cfg = dataclasses.replace(tcfg.tiny(num_frames=24), vision_num_layers=2)
+    else:
+        cfg = dataclasses.replace(tcfg.tiny(num_frames=24), vision_hidden_size=1024, vision_intermediate_size=4096, vision_num_layers=2,
+                                  vision_num_heads=16, vision_image_size=336, vision_patch_size=14, mm_hidden_size=1024)
+    sd = synth.state_dict(cfg)
+    eng = TraceEngine(cfg, max_batch=1, max_ctx=512, max_frames=24, max_new_tokens=8)
+    eng.load_weights(sd.items())
+    frames = torch.cat([synth.synth_frames(cfg, 50 + i, num_frames=8) for i in range(3)]).to(torch.bfloat16)          # 24 different frames
+    ora = O.Oracle(cfg, {k: v for k, v in sd.items() if "vision_tower" in k}, emulate_bf16=True)
+    want = ora.vit_forward(frames[:3].float()).reshape(3, cfg.vision_patches, cfg.vision_hidden_size)
+    for n in (3, 24):
+        got = {}
+        try:
+            for fused in (1, 0):
+                ops.set_gemm_variant(160 + fused)
+                got[fused] = eng.vit_forward(frames[:n]).float().cpu()
+                if fused:
+                    got["fp32 frames"] = eng.vit_forward(frames[:n].float()).float().cpu()
+        finally:
+            ops.set_gemm_variant(161)
+        assert torch.isfinite(got[1]).all()
+        assert torch.equal(got[1], got["fp32 frames"]), n                    # bf16-representable pixels: the fp32 path rounds them back to the same bits
+        d = (got[1] - got[0]).abs()
+        scale = got[0].abs().mean().item()
+        print(f"{geometry}, {n} frames: fused vs three-pass front end: max {d.max().item():.4f} mean {d.mean().item():.6f} (|x| mean {scale:.3f}), "
+              f"identical {float((d == 0).float().mean()):.3f}")
+        assert d.mean().item() < 2e-3 * max(scale, 1e-3) and d.max().item() < 0.1 * max(1.0, got[0].abs().max().item()), (n, d.max().item(), d.mean().item())
+        e = (got[1][:3] - want).abs()
+        assert (e > 3e-2 + 3e-2 * want.abs()).float().mean().item() < 2e-3, (n, e.max().item())
+    eng.close()

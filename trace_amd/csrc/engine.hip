@@ -59,6 +59,7 @@ struct trace_ctx {
     bool counted = false;            // in g_ctx_per_dev (the last context of a device frees the persistent GEMM's ticket counters)
     // weights
     bf16_t *patch_w, *cls, *pos_emb, *pre_w, *pre_b;
+    bf16_t *patch_wp = nullptr, *cls_row = nullptr; float* cls_stats = nullptr;      // fused patch embedding (patch_embed.hip): repacked conv weight, the CLS row, its fold statistics
     std::vector<VitLayer> vit;
     bf16_t *sl_lnw, *sl_lnb, *sl_slots, *sl_readout;
     // STC connector (projector_type == 1)
@@ -191,6 +192,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
 #define A(p, n) if (rc == TRACE_OK) rc = dalloc(c, &(p), (size_t)(n))
     // --- weights ---
     A(c->patch_w, vh * c->Kpad); A(c->cls, vh); A(c->pos_emb, (size_t)c->NT * vh); A(c->pre_w, vh); A(c->pre_b, vh);
+    if (patch_embed_supported(cfg->v_image, c->P, (int)vh)) { A(c->patch_wp, patch_embed_packed_elems(c->P, (int)vh)); A(c->cls_row, vh); A(c->cls_stats, 2); }
     c->vit.resize(c->vL);
     for (auto& l : c->vit) {
         A(l.ln1w, vh); A(l.ln1b, vh); A(l.wqkv, 3 * vh * vh); A(l.bqkv, 3 * vh); A(l.wo, vh * vh); A(l.bo, vh);
@@ -518,6 +520,11 @@ extern "C" int trace_ctx_finalize(trace_ctx* c) {
         HIPCHK(hipMemcpy(c->rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
     }
+    // fused patch embedding: the conv weight in the kernel's k order / fragment layout, and the CLS row (the same for every frame)
+    if (c->patch_wp) {
+        LCHK(launch_patch_pack(c->patch_w, c->Kpad, c->patch_wp, c->vh, c->P, 0));
+        LCHK(launch_cls_row(c->cls, c->pos_emb, c->pre_w, c->pre_b, c->cls_row, c->cls_stats, c->vh, c->c.v_eps, c->c.v_eps, 0));
+    }
     // LayerNorm fold of the ViT: qkv and fc1 weights pre-multiplied by the preceding LayerNorm's weight, with the two correction rows
     for (auto& l : c->vit) {
         LCHK(launch_ln_fold_weights(l.wqkv, c->vh, l.ln1w, l.ln1b, l.bqkv, l.wqkv_f, l.c1q, l.c2q, 3 * c->vh, c->vh, 0));
@@ -556,6 +563,7 @@ extern "C" int trace_ctx_finalize(trace_ctx* c) {
 
 // ------------------------------------------------------------------------------------------------ ViT
 int g_vit_ln_fold = 1;      // 0: the ViT keeps its LayerNorm kernels at every size (A/B: trace_op_set_gemm_variant(150 + x))
+int g_vit_patch_fused = 1;  // 0: im2col matrix -> GEMM -> assemble instead of the fused front end (A/B: trace_op_set_gemm_variant(160 + x))
 static unsigned long long* g_gemm_trace = nullptr;      // tools/gemm_trace.py
 extern "C" int trace_op_set_gemm_trace(void* buf) { g_gemm_trace = (unsigned long long*)buf; return TRACE_OK; }
 static int gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* C, int ldc, const bf16_t* bias, const bf16_t* R,
@@ -581,11 +589,26 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
     if (!frames || T < 1 || T > c->vit_frames) return fail(TRACE_ERR_ARG, "bad frames / T (more than max_frames / vit_batch_frames)");
     hipStream_t s = (hipStream_t)stream;
     const int vh = c->vh, vi = c->vi, NT = c->NT, GG = c->GG, Mv = T * NT;
-    bf16_t* im2 = c->vMLP;                       // [T*GG, Kpad]
-    bf16_t* pe = c->vH;                          // [T*GG, vh]
-    LCHK(launch_im2col(frames, frames_dtype == 1, im2, T, c->c.v_image, c->P, c->Kpad, s));
-    TRY(gemm(im2, c->Kpad, c->patch_w, c->Kpad, pe, vh, nullptr, nullptr, 0, T * GG, vh, c->Kpad, EPI_NONE, s));
-    LCHK(launch_vit_assemble(pe, c->cls, c->pos_emb, c->pre_w, c->pre_b, c->vX, T, GG, vh, c->c.v_eps, s));
+    // LayerNorm fold (round 3): when this call's shapes run on the kernels that carry it — qkv / fc1 on the persistent GEMM, out-proj / fc2 on the
+    // loader-wave GEMM — neither LayerNorm of a layer is a pass of its own: the residual GEMMs' epilogues leave the row sums of what they store,
+    // a finalize kernel turns them into (rstd, -mean rstd), and the next GEMM runs on the raw residual stream with pre-scaled weights and applies
+    // rstd (acc - mean c1) + c2 in its epilogue.  Smaller calls (a few frames) keep the LayerNorm kernel.
+    const bool fold = g_vit_ln_fold && vh % 256 == 0 && gemm_routes_to_pers(Mv, 3 * vh, vh) && gemm_routes_to_pers(Mv, vi, vh) &&
+                      gemm_routes_to_ldr(Mv, vh, vh) && gemm_routes_to_ldr(Mv, vh, vi);
+    // front end: one kernel reads the frame tensor, multiplies the patches on the MFMA, adds CLS / position embeddings, applies
+    // pre_layrnorm and leaves the first layer's row statistics (patch_embed.hip).  g_vit_patch_fused = 0 (A/B) or a patch size / width the
+    // kernel does not take: the round-1 path, im2col matrix -> GEMM -> assemble (+ a row-statistics pass for the fold).
+    const bool fused_pe = g_vit_patch_fused && c->patch_wp;
+    if (fused_pe) {
+        LCHK(launch_patch_embed(frames, frames_dtype == 1, c->patch_wp, c->pos_emb, c->pre_w, c->pre_b, c->cls_row, c->cls_stats, c->vX,
+                                fold ? c->vStats : nullptr, T, c->c.v_image, c->P, vh, c->c.v_eps, c->c.v_eps, s));
+    } else {
+        bf16_t* im2 = c->vMLP;                       // [T*GG, Kpad]
+        bf16_t* pe = c->vH;                          // [T*GG, vh]
+        LCHK(launch_im2col(frames, frames_dtype == 1, im2, T, c->c.v_image, c->P, c->Kpad, s));
+        TRY(gemm(im2, c->Kpad, c->patch_w, c->Kpad, pe, vh, nullptr, nullptr, 0, T * GG, vh, c->Kpad, EPI_NONE, s));
+        LCHK(launch_vit_assemble(pe, c->cls, c->pos_emb, c->pre_w, c->pre_b, c->vX, T, GG, vh, c->c.v_eps, s));
+    }
     AttnArgs a{};
     a.Q = c->vQKV; a.K = c->vQKV + vh; a.V = c->vVT; a.O = c->vH;
     a.q_bs = (long)NT * 3 * vh; a.q_hs = 64; a.q_rs = 3 * vh;
@@ -596,12 +619,6 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
     a.scale = 0.125f; a.causal = 0;
     a.Vrow = c->vQKV + 2 * vh; a.vr_bs = a.q_bs; a.vr_hs = 64; a.vr_rs = 3 * vh;
     a.v_perm = attn_vit_wants_perm(NT, true) ? (attn_vit_rowmajor_v() ? 2 : 1) : 0;     // 2: V read row-major from vQKV, no transpose pass
-    // LayerNorm fold (round 3): when this call's shapes run on the kernels that carry it — qkv / fc1 on the persistent GEMM, out-proj / fc2 on the
-    // loader-wave GEMM — neither LayerNorm of a layer is a pass of its own: the residual GEMMs' epilogues leave the row sums of what they store,
-    // a finalize kernel turns them into (rstd, -mean rstd), and the next GEMM runs on the raw residual stream with pre-scaled weights and applies
-    // rstd (acc - mean c1) + c2 in its epilogue.  Smaller calls (a few frames) keep the LayerNorm kernel.
-    const bool fold = g_vit_ln_fold && vh % 256 == 0 && gemm_routes_to_pers(Mv, 3 * vh, vh) && gemm_routes_to_pers(Mv, vi, vh) &&
-                      gemm_routes_to_ldr(Mv, vh, vh) && gemm_routes_to_ldr(Mv, vh, vi);
     auto fgemm = [&](const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* Cc, int ldc, const bf16_t* c2, const float* c1, const bf16_t* R,
                      int N, int K, int epi, float* stats_part) -> int {
         GemmArgs g{A, lda, W, ldw, Cc, ldc, c2, R, R ? vh : 0, Mv, N, K, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, 0, c1 ? c->vStats : nullptr, c1, stats_part};
@@ -609,7 +626,7 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
         if (rc != TRACE_OK) return fail(rc, "ViT GEMM launch failed (LayerNorm fold)");
         return TRACE_OK;
     };
-    if (fold) LCHK(launch_ln_row_stats(c->vX, vh, Mv, vh, c->c.v_eps, c->vStats, s));       // layer 0's input came from vit_assemble, not from a GEMM
+    if (fold && !fused_pe) LCHK(launch_ln_row_stats(c->vX, vh, Mv, vh, c->c.v_eps, c->vStats, s));       // layer 0's input came from vit_assemble, not from a GEMM
     for (int l = 0; l < c->vL; ++l) {
         const VitLayer& L = c->vit[l];
         // MFMA roofline probe (profile == 2): HIP events around ONE launch of each of the layer's four GEMM shapes, in layer 0, per call — of the
@@ -1448,6 +1465,7 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
     if (variant >= 150 && variant <= 151) { g_vit_ln_fold = variant - 150; return TRACE_OK; }
+    if (variant >= 160 && variant <= 161) { g_vit_patch_fused = variant - 160; return TRACE_OK; }
     if (variant >= 170 && variant <= 174) { g_decode_fuse_norm_rows = variant - 170; return TRACE_OK; }
     if (variant >= 180 && variant <= 181) { g_decode_fuse_swiglu = variant - 180; return TRACE_OK; }
     if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : 32; return TRACE_OK; }

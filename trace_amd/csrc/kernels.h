@@ -66,6 +66,15 @@ bool gemm_routes_to_ldr(int M, int N, int K);
 
 // ---- ViT front end (vit.hip) ----
 // frames [T,3,S,S] (bf16 or fp32) -> im2col patches A [T*G*G, Kpad] bf16 (k = c*P*P + py*P + px, zero padded)
+// ---- patch_embed.hip (round 4): the ViT front end as one kernel, reading the frame tensor directly ----
+bool patch_embed_supported(int S, int P, int D);                   // P in {14, 16}, D in {128, 256, 512, 1024}; other geometries keep the three-pass path below
+size_t patch_embed_packed_elems(int P, int D);                     // elements of the repacked conv weight
+int launch_patch_pack(const bf16_t* W, int ldw, bf16_t* wp, int D, int P, hipStream_t s);          // at load: [D][ldw] (k = c P P + ky P + j) -> fragment order, j padded to 16
+int launch_cls_row(const bf16_t* cls, const bf16_t* pos, const bf16_t* lw, const bf16_t* lb, bf16_t* out, float* st, int D, float eps, float eps_fold,
+                   hipStream_t s);                                 // at load: the CLS row every frame gets + its LayerNorm-fold statistics
+int launch_patch_embed(const void* frames, int frames_fp32, const bf16_t* wp, const bf16_t* pos, const bf16_t* lw, const bf16_t* lb,
+                       const bf16_t* cls_row, const float* cls_stats, bf16_t* X, float* stats, int T, int S, int P, int D, float eps, float eps_fold,
+                       hipStream_t s);                             // frames -> X = pre_layrnorm(cat(CLS, conv) + pos) [T (G G + 1), D] (+ row statistics)
 int launch_im2col(const void* frames, int frames_fp32, bf16_t* A, int T, int S, int P, int Kpad, hipStream_t s);
 // X[t, 0] = cls + pos[0];  X[t, 1+p] = PE[t*GG + p] + pos[1+p]      (PE = patch-embed GEMM output)
 //   then X = LayerNorm(X) (pre_layrnorm), fused

@@ -282,12 +282,12 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the captured hipGraph for decode steps (default: eager launches, which run at the same speed "
                          "— the step is GPU-bound — and allow the per-launch HIP-event roofline probe in the timed region)")
-    ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=False,
-                    help="two-stage pipeline over the timed steps — batch k decodes on one stream while batch k+1 runs its ViT + prefill on another "
-                         "(TraceEngine.generate_stream): +2-3 %% videos/s.  NOT the default: a stress run of 60 short pipelined steps produced ONE step in "
-                         "which one of the 128 sequences had a different arg-max from token 6 on (profiles/r03_pipeline_stress_ids_differ.txt; 40 "
-                         "sequential steps: none), a 25-step run at the C2 shape likewise; not root-caused, so the steps run one after the other")
-    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="(the default) timed steps strictly one after the other")
+    ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=True,
+                    help="(the default since round 4) two-stage pipeline over the timed steps — batch k decodes on one stream while batch k+1 runs its ViT + prefill "
+                         "on another (TraceEngine.generate_stream): +2-3 %% videos/s.  Round 3 kept it off: over ~100 pipelined steps one video's ViT features came "
+                         "out different a few times — the persistent GEMM's ticket counter was re-armed with a plain store; it is an agent-scope atomic now "
+                         "(profiles/r04_pipeline_stress.txt: the old form differs, the new one does not)")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="timed steps strictly one after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
                     help="element type: bf16 (BASELINE's configs; libtrace_hip.so) or fp16 (the reference's own inference dtype; libtrace_hip_f16.so)")
@@ -331,7 +331,7 @@ def main():
     n_text = 24 if args.tiny else preset["n_text"]
     ids = synth.synth_prompt_ids(cfg, n_text=n_text, video_pos=10 if args.tiny else preset["video_pos"]).tolist()
     L = n_text - 1 + args.frames * cfg.tokens_per_frame
-    pipelined = args.pipeline and 2 * B <= 256 and args.steps > 1
+    pipelined = args.pipeline and 2 * B <= 512 and args.steps > 1          # two banks of KV slots (the engine holds at most 512)
     el_dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     if args.fp8 and args.dtype != "bf16":
         sys.exit("bench: the fp8 weight path exists in the bf16 library only (--config c5 --dtype fp16 needs --no-fp8)")

@@ -228,8 +228,6 @@ def test_vit_large_geometry_f16():
     eng.close()
 
 
-@pytest.mark.skipif(os.environ.get("TRACE_TEST_F16_WIDE") != "1",
-                    reason="written after round 3's GPU budget was spent: not yet run on hardware (set TRACE_TEST_F16_WIDE=1)")
 @pytest.mark.parametrize("name,layers,tol,tol16", [("medium_llm_f16.npz", 1, 0.03, 0.05), ("deep_llm_f16.npz", 8, 0.06, 0.10)])
 def test_real_width_layers_f16(golden_dir, name, layers, tol, tol16):
     """1 and 8 decoder layers at the real Mistral-7B widths in fp16, teacher-forced, alone and inside batches of 40 / 100 (decode GEMV with four row
@@ -270,8 +268,6 @@ def test_real_width_layers_f16(golden_dir, name, layers, tol, tol16):
     eng.close()
 
 
-@pytest.mark.skipif(os.environ.get("TRACE_TEST_F16_WIDE") != "1",
-                    reason="written after round 3's GPU budget was spent: not yet run on hardware (set TRACE_TEST_F16_WIDE=1)")
 @pytest.mark.parametrize("name,layers", [("medium_llm_f16.npz", 1), ("deep_llm_f16.npz", 8)])
 def test_fp16_checkpoint_argmax_agreement(golden_dir, name, layers):
     """What the fp16 library is for: an fp16 checkpoint, and the reference's own fp16 run (model.half()) as the answer key.  The same fp16 weights go

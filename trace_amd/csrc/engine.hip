@@ -1471,6 +1471,7 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : 32; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
+    if (variant >= 510 && variant <= 511) { g_ln_stats_plain = variant - 510; return TRACE_OK; }   // LayerNorm-fold statistics: 0 = agent-scope atomics, 1 = round 3's plain accesses
     if (variant >= 500 && variant <= 502) { g_gemm_pers_walk = variant - 500; return TRACE_OK; }   // the persistent GEMM's tile walk on every route (gemm_pers.hip)
     if (variant >= 400 && variant < 404) { g_gemm_ldr_opt = variant - 400; return TRACE_OK; }   // microbench: attention phase cut-offs
     if (variant < 0 || variant > 7) return fail(TRACE_ERR_ARG, "variant must be 0..7");

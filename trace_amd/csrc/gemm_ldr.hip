@@ -297,7 +297,11 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
                 LDR_DPP_ADD(s1, 0x140, 0xf); LDR_DPP_ADD(s2, 0x140, 0xf);      // row_mirror: every lane of a 16-lane row holds the row's sum
                 LDR_DPP_ADD(s1, 0x142, 0xa); LDR_DPP_ADD(s2, 0x142, 0xa);      // row_bcast15 into rows 1, 3: lanes 16..31 / 48..63 hold their half's sum
 #undef LDR_DPP_ADD
-                if (ch == 16) *reinterpret_cast<float2*>(p.stats_part + ((size_t)(n0 / BN) * p.M + m) * 2) = make_float2(s1, s2);
+                if (ch == 16) {
+                    float* dst = p.stats_part + ((size_t)(n0 / BN) * p.M + m) * 2;
+                    if (p.opt & 2) *reinterpret_cast<float2*>(dst) = make_float2(s1, s2);       // round-3 form (A/B)
+                    else st_agent_f2(dst, s1, s2);                                              // written through: common.h
+                }
             }
         }
     }
@@ -318,7 +322,7 @@ void launch_one(const GemmArgs& p, int nblk, size_t lds, hipStream_t s) {
 int g_gemm_ldr_opt = 0;            // A/B: bit 0 = no residual touches (trace_op_set_gemm_variant(400 + opt))
 int launch_gemm_ldr(const GemmArgs& p0, int epi, hipStream_t s) {
     GemmArgs p = p0;
-    p.opt = g_gemm_ldr_opt;
+    p.opt = g_gemm_ldr_opt | (g_ln_stats_plain ? 2 : 0);
     if (p.M < 1 || p.N % BN || p.K % BK) return TRACE_ERR_ARG;
     constexpr size_t LOOPB = 2 * STAGE, OBYTES = (size_t)TOUCH_OFF + 4 * 256;      // staged tile + the fp8 scale rows + the touch scratch
     const size_t lds = LOOPB > OBYTES ? LOOPB : OBYTES;

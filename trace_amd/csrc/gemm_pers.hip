@@ -398,7 +398,8 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
         }                                                                                                                              \
         if (!GLU && lw == 3 && p.bias) bias2 = *reinterpret_cast<const uint2*>(p.bias + n0_ + lane * 4);  /* else stays zero */       \
         if (LNF) {                                                                                                                     \
-            st2 = *reinterpret_cast<const float2*>(p.stats + 2 * (size_t)min(m0_ + lw * 64 + lane, p.M - 1));                           \
+            const float* sp_ = p.stats + 2 * (size_t)min(m0_ + lw * 64 + lane, p.M - 1);                                                \
+            st2 = (p.opt & 32) ? *reinterpret_cast<const float2*>(sp_) : ld_agent_f2(sp_);  /* coherent across the XCDs' L2s: common.h */    \
             if (lw == 2) c1v = *reinterpret_cast<const float4*>(p.c1 + n0_ + lane * 4);                                                \
         }                                                                                                                              \
         if (toucher)                                                                                                                   \
@@ -694,7 +695,9 @@ void gemm_pers_release(int dev) {
 }
 
 // TRACE_ERR_STATE: no ticket counters for this stream and none can be made now (capturing): the caller falls back to gemm_ldr
-int launch_gemm_pers(const GemmArgs& p, int epi, hipStream_t s) {
+int launch_gemm_pers(const GemmArgs& p0, int epi, hipStream_t s) {
+    GemmArgs p = p0;
+    p.opt = g_ln_stats_plain ? 32 : 0;              // bit 5: round-3 plain loads of the fold's row statistics (A/B)
     if (p.M < 1 || p.N % BN || p.K % BK || p.K < 2 * BK || p.fp8) return TRACE_ERR_ARG;
     if (p.stats && (!p.c1 || !p.bias || (epi != EPI_NONE && epi != EPI_QUICKGELU))) return TRACE_ERR_ARG;      // LN fold: c1, c2 (= bias) and the row statistics
     if ((long)p.M * p.ldc >= (1L << 30) || (epi == EPI_RESIDUAL && (long)p.M * p.ldr >= (1L << 30))) return TRACE_ERR_ARG;   // 32-bit byte offsets

@@ -54,6 +54,7 @@ int launch_rmsnorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w
 
 // ---- LayerNorm fold (ViT): C = LN(A) W^T + b as one GEMM on the raw rows (GemmArgs::stats / c1 / stats_part; gemm_pers.hip, gemm_ldr.hip) ----
 // part [NT][M][2] (sum, sum of squares per 256-column tile, from the residual GEMM's epilogue) -> stats [M][2] = (rstd, -mean * rstd)
+extern int g_ln_stats_plain;                                       // norm.hip: 1 = plain (round-3) stores / loads of the fold's statistics instead of agent-scope atomics
 int launch_ln_stats_finalize(const float* part, int NT, int M, int D, float eps, float* stats, hipStream_t s);
 int launch_ln_row_stats(const bf16_t* x, int ldx, int M, int D, float eps, float* stats, hipStream_t s);      // the same from the rows themselves
 // Wf = bf16(W * gamma), c1 = row sums of Wf, c2 = W . beta + b   (at load)

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512) void patch_embed_kernel(const TIN* __restrict_
                 if (patch < GG) {
                     const float mu = t1[i] / (float)D;
                     const float rs = rsqrtf(fmaxf(t2[i] / (float)D - mu * mu, 0.f) + eps_fold);
-                    *reinterpret_cast<float2*>(stats + 2 * ((size_t)t * NT + 1 + patch)) = make_float2(rs, -mu * rs);
+                    st_agent_f2(stats + 2 * ((size_t)t * NT + 1 + patch), rs, -mu * rs);
                 }
             }
         }
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512) void patch_embed_kernel(const TIN* __restrict_
     if (m0 == 0) {
         for (int c = tid; c < (D >> 3); c += 512)
             *reinterpret_cast<uint4*>(X + (size_t)t * NT * D + c * 8) = *reinterpret_cast<const uint4*>(cls_row + c * 8);
-        if (stats && tid == 0) *reinterpret_cast<float2*>(stats + 2 * (size_t)t * NT) = make_float2(cls_stats[0], cls_stats[1]);
+        if (stats && tid == 0) st_agent_f2(stats + 2 * (size_t)t * NT, cls_stats[0], cls_stats[1]);
     }
 }
 

@@ -464,6 +464,8 @@ def main():
         if g_traffic is not None and g_traffic_M != g_M:
             g_traffic = None                                    # the committed PMC pass measured another launch shape
         g_tf = (g_gf / g_ms) if g_ms > 0 else None             # GFLOP / ms = TFLOP/s
+        fold_tag = ", LN fold" if prof[9] else ""              # the engine says which instantiations the brackets timed (the fold is opt-in since round 4)
+        stat_tag = " (+ row statistics)" if prof[9] else ""
         line = {
             "metric": "videos/sec + decode tok/s, TRACE-7B 128-frame, 1/2/4/8 MI355X",
             "value": vps, "unit": "videos/s", "n_gpus": world, "rccl_ranks": ranks_seen[0], "steps": args.steps, "warmup": args.warmup,
@@ -497,17 +499,17 @@ def main():
             "mfma_util": {"vit": vit_flops / (t_enc * 1e-3) / 2.5e15, "prefill": pre_flops / (t_pre * 1e-3) / 2.5e15},
             # dominant kernel of the run: the 256x256 MFMA GEMM (its four epilogue variants are ~half of GPU time; the probe
             # brackets its largest instance, the ViT fc1 projection, once per video inside the timed region)
-            "roofline": {"bound": "mfma", "kernel": f"256x256-tile loader-wave MFMA GEMM family (8 MFMA + 4 loader waves per workgroup): by total time the run's top symbol is gemm_ldr_kernel<EPI_RESIDUAL> (ViT out-proj + fc2, prefill o / down); achieved / frac below are its largest single launch, gemm_pers_kernel<EPI_QUICKGELU, LN fold> = ViT fc1 {g_M}x4096x1024 of one {eng.vit_batch_frames if B >= 2 else args.frames}-frame tower call (1 bracketed launch per call); every ViT shape of the family is in `shapes`",
+            "roofline": {"bound": "mfma", "kernel": f"256x256-tile loader-wave MFMA GEMM family (8 MFMA + 4 loader waves per workgroup): by total time the run's top symbol is gemm_ldr_kernel<EPI_RESIDUAL> (ViT out-proj + fc2, prefill o / down); achieved / frac below are its largest single launch, gemm_pers_kernel<EPI_QUICKGELU{fold_tag}> = ViT fc1 {g_M}x4096x1024 of one {eng.vit_batch_frames if B >= 2 else args.frames}-frame tower call (1 bracketed launch per call); every ViT shape of the family is in `shapes`",
                          "achieved": g_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": (g_tf / 2500.0) if g_tf else None,
                          "traffic": g_traffic, "algorithmic_gflop_per_launch": g_gf, "algorithmic_bytes_per_launch": g_M * 1024 * 2 + 4096 * 1024 * 2 + g_M * 4096 * 2,
                          "avg_launch_ms": g_ms, "samples": g_n,
                          "shapes": {name: {"kernel": sym, "MxNxK": f"{g_M}x{N_}x{K_}", "avg_launch_ms": ms_, "tflops": (gf_ / ms_) if ms_ > 0 else None,
                                            "frac": (gf_ / ms_ / 2500.0) if ms_ > 0 else None}
                                     for name, sym, N_, K_, ms_, gf_ in (
-                                        ("vit_qkv", "gemm_pers_kernel<EPI_NONE, LN fold>", 3072, 1024, prof[12], prof[15]),
-                                        ("vit_out_proj", "gemm_ldr_kernel<EPI_RESIDUAL> (+ row statistics)", 1024, 1024, prof[13], prof[16]),
-                                        ("vit_fc1", "gemm_pers_kernel<EPI_QUICKGELU, LN fold>", 4096, 1024, g_ms, g_gf),
-                                        ("vit_fc2", "gemm_ldr_kernel<EPI_RESIDUAL> (+ row statistics)", 1024, 4096, prof[14], prof[17]))}},
+                                        ("vit_qkv", "gemm_pers_kernel<EPI_NONE" + fold_tag + ">", 3072, 1024, prof[12], prof[15]),
+                                        ("vit_out_proj", "gemm_ldr_kernel<EPI_RESIDUAL>" + stat_tag, 1024, 1024, prof[13], prof[16]),
+                                        ("vit_fc1", "gemm_pers_kernel<EPI_QUICKGELU" + fold_tag + ">", 4096, 1024, g_ms, g_gf),
+                                        ("vit_fc2", "gemm_ldr_kernel<EPI_RESIDUAL>" + stat_tag, 1024, 4096, prof[14], prof[17]))}},
         }
         # dominant HBM-bound kernel of the decode phase
         # whole decode step: algorithmic bytes = the decoder weights once + the heads on the steps that stream them (not counted) + every sequence's KV rows

@@ -160,6 +160,7 @@ int trace_debug_buffers(trace_ctx* ctx, void** kcache, void** vcache, void** xla
 /* out[0..n) (n <= 20): [0] ms per decode step of the last trace_decode_steps call, [1] its steps, [2] average ms of the bracketed decode launch,
  * [3] its samples, [4] its algorithmic bytes, [5] average ms of the bracketed ViT fc1 GEMM launch, [6] its samples, [7] its GFLOP,
  * [8] which decode launch took the bracket: 1 = gate|up GEMV, 2 = batch-1 fused-norm gate|up GEMV, 3 = the wide step's layer-0 decode attention,
+ * [9] 1 if the bracketed ViT GEMMs ran with the LayerNorm fold (opt-in), 0 with LayerNorm kernels,
  * [12..14] average ms of the bracketed ViT qkv / out-proj / fc2 GEMM launches (layer 0, the same calls as [5]), [15..17] their GFLOP. */
 int trace_get_profile(trace_ctx* ctx, float* out, int n);
 /* Which per-launch brackets profiling mode 2 takes: bit 0 = the ViT fc1 GEMM, bit 1 = the decode step's dominant kernel.  A pipelined caller

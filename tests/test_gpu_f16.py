@@ -212,7 +212,11 @@ def test_vit_large_geometry_f16():
     eng = TraceEngine(cfg, max_batch=1, max_ctx=512, max_frames=24, max_new_tokens=8, dtype=F16)
     eng.load_weights(sd.items())
     one = eng.vit_forward(frames).float().cpu()[0]
-    many = eng.vit_forward(frames.expand(24, -1, -1, -1).contiguous()).float().cpu()
+    try:
+        eng.lib.trace_op_set_gemm_variant(151)     # the LayerNorm fold is opt-in since round 4 (a switch of THIS library: the fp16 .so has its own)
+        many = eng.vit_forward(frames.expand(24, -1, -1, -1).contiguous()).float().cpu()
+    finally:
+        eng.lib.trace_op_set_gemm_variant(150)
     assert all(torch.equal(many[0], many[i]) for i in range(1, 24))
     assert not torch.equal(many[0], one), "the LayerNorm fold did not engage at 24 frames"
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")

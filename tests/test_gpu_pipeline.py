@@ -97,3 +97,18 @@ def test_persistent_gemm_capped_grid_is_bit_identical():
             assert torch.equal(ops.gemm(A, W, bias=bias, epilogue=2), ref), cap
     finally:
         ops.set_gemm_variant(1000)
+
+
+def test_pipelined_full_size_steps_repeat_exactly_under_overlap():
+    """Regression guard for round 3's rare wrong ViT row panel: identical full-geometry steps (TRACE-7B, 128 videos x 32 frames) through
+    the two-stage pipeline on the SHIPPED configuration (LayerNorm fold off: the only configuration the wrong panel was ever seen in is fold-on, about
+    once per 100 steps) must reproduce step 0 at every level the stress tool checksums (ViT features, prefilled K / V^T / last hidden rows, ids).
+    Bounded: 14 steps, about a minute — a guard against a regression of the default, not a proof (the proof is the long runs in profiles/)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pipeline_stress.py"), "--steps", "14", "--max-new", "200", "--plan", "0"],
+                       capture_output=True, text=True, timeout=420, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "phase [0]: all steps identical" in r.stdout, r.stdout[-3000:]

@@ -100,7 +100,7 @@ def run_phase(variants, steps):
                   f"ids differ for (sequence, first token, count) {id_bad[:8]}")
     print(f"phase {variants}: " + ("all steps identical" if not bad else f"{bad} of {steps - 1} steps differ from step 0"), flush=True)
     for v in variants:                      # back to the defaults
-        _lib.check(eng.lib.trace_op_set_gemm_variant({500: 500, 501: 500, 502: 500, 510: 510, 511: 510, 150: 151, 151: 151}.get(v, 0)))
+        _lib.check(eng.lib.trace_op_set_gemm_variant({500: 500, 501: 500, 502: 500, 510: 510, 511: 510, 150: 150, 151: 150}.get(v, 0)))
     return bad
 
 
@@ -109,7 +109,7 @@ def run_phase(variants, steps):
 # 4 = no persistent kernel).  --adaptive: if a shipped-walk phase (500) shows a difference, add the phases that localise it.
 # Sensitivity: the wrong tile only ever appeared while the OTHER stage's kernels shared the GPU with the tower; --max-new 200 makes the decode stage as
 # long as the encode stage (24 tokens: a tenth of it), i.e. ~10x the exposure per step.
-plan = [[int(x) for x in ph.split("+")] for ph in (a.plan.split(",") if a.plan else [str(a.gemm_variant or 500)])]
+plan = [[int(x) for x in ph.split("+")] for ph in (a.plan.split(",") if a.plan else [str(a.gemm_variant or 0)])]       # 0 = the shipped defaults
 res = []
 for ph in plan:
     res.append((ph, run_phase(ph, a.steps)))

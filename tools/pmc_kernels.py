@@ -1,5 +1,5 @@
 """Small fixed workload for rocprofv3 --pmc passes: the two roofline kernels of bench.py at the launch shapes it brackets — the ViT fc1 GEMM of one
-170-frame tower call (round 3: the LayerNorm-fold form, gemm_pers_kernel<2, 16>) and the decode attention of a 128-sequence step at ctx 2100 — plus
+170-frame tower call (gemm_pers_kernel<2, 0>; round 3 measured the LayerNorm-fold form <2, 16>) and the decode attention of a 128-sequence step at ctx 2100 — plus
 the ViT attention and the batch-64 gate|up GEMV of the earlier rounds.   python tools/pmc_kernels.py [attn] [gemm] [attn_decode] [gemv]"""
 import math, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,9 +14,8 @@ if "all" in what or "attn" in what:
         ops.attention(q, k, v, False, 0.125)
 if "all" in what or "gemm" in what:
     A, W, b = rnd(170 * 577, 1024), rnd(4096, 1024, scale=0.02), rnd(4096)      # the bench's probe shape: one 170-frame ViT call
-    g, be = (1 + 0.1 * torch.randn(1024, device=dev)).to(torch.bfloat16), rnd(1024, scale=0.1)
-    for _ in range(3):
-        ops.gemm_lnfold(A, W, g, be, b, 1e-5, epilogue=E.EPI_QUICKGELU)
+    for _ in range(3):                                   # as shipped since round 4: the LayerNorm is a kernel of its own, the GEMM is gemm_pers_kernel<2, 0>
+        ops.gemm(A, W, bias=b, epilogue=E.EPI_QUICKGELU)
 if "all" in what or "attn_decode" in what:      # the wide decode step's dominant kernel: 128 sequences x ctx 2100, 8 kv heads (1.10 GB of K + V^T rows)
     Bn, ctx, mc = 128, 2100, 2112
     kc, vt = rnd(Bn, 8, mc, 128, scale=0.5), rnd(Bn, 8, 128, mc, scale=0.5)

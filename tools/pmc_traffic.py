@@ -40,7 +40,7 @@ json.dump({
     "gemm_fc1_bytes_per_launch": g_total,
     "gemm_fc1_M": FC1_M,
     "gemm_fc1_detail": {
-        "kernel": "gemm_pers_kernel<EPI_QUICKGELU, LayerNorm fold> (ViT fc1, M=%d N=4096 K=1024), 3 launches" % FC1_M,
+        "kernel": "gemm_pers_kernel<EPI_QUICKGELU> (ViT fc1 as shipped in round 4: no LayerNorm fold; M=%d N=4096 K=1024), 3 launches" % FC1_M,
         "FETCH_SIZE_KB_mean": gf_kb, "WRITE_SIZE_KB_mean": gw_kb, "launches": [g1, g2],
         "correction": "FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 (same gfx950 corrections as below; operand panels re-read by "
                       "other column tiles are served by L2 / infinity cache and only partly reach the memory-side counters)",

@@ -562,7 +562,11 @@ extern "C" int trace_ctx_finalize(trace_ctx* c) {
 }
 
 // ------------------------------------------------------------------------------------------------ ViT
-int g_vit_ln_fold = 1;      // 0: the ViT keeps its LayerNorm kernels at every size (A/B: trace_op_set_gemm_variant(150 + x))
+int g_vit_ln_fold = 0;      // 1: the ViT's LayerNorms folded into the qkv / fc1 GEMMs (round 3; trace_op_set_gemm_variant(150 + x)).  OFF since round 4: with the
+                            // fold on, one 256-row panel of one tower GEMM came out wrong about once per 100 stress steps whenever the tower ran on a side
+                            // stream with the host running ahead (8 wrong steps in 752, pipelined), never in 355+ steps without it; the tickets are cleared
+                            // (the static tile deal fails too) and so is the coherence of the statistics buffers (agent-scope atomics fail too) — DESIGN 5a.
+                            // It bought 1.2 % of a layer; until the cause is found the LayerNorm kernels stay.
 int g_vit_patch_fused = 1;  // 0: im2col matrix -> GEMM -> assemble instead of the fused front end (A/B: trace_op_set_gemm_variant(160 + x))
 static unsigned long long* g_gemm_trace = nullptr;      // tools/gemm_trace.py
 extern "C" int trace_op_set_gemm_trace(void* buf) { g_gemm_trace = (unsigned long long*)buf; return TRACE_OK; }
@@ -687,6 +691,7 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
         c->prof[5] = (float)(c->msum_ms / c->msamples);
         c->prof[6] = (float)c->msamples;
         c->prof[7] = (float)(c->mflops / 1e9);               // GFLOP of the bracketed launch
+        c->prof[9] = fold ? 1.f : 0.f;                        // which instantiations the brackets timed (LayerNorm fold on / off)
         for (int i = 0; i < 3; ++i) { c->prof[12 + i] = (float)(c->vsum_ms[i] / c->msamples); c->prof[15 + i] = (float)(c->vflops[i] / 1e9); }
     }
     if (feats_out)   // drop CLS: [T, GG, vh]

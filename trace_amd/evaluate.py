@@ -92,7 +92,7 @@ def parse_output_ids(ids: Sequence[int], tokenizer, model, stop_str: Optional[st
 @torch.no_grad()
 def evaluate_videos(model, tokenizer, processor, items: Sequence[dict], prompt: str, *, num_frames: Optional[int] = None,
                     max_new_tokens: int = 512, batch_size: Optional[int] = None, conv_mode: str = "llama_2",
-                    device_preprocess: bool = True, pipeline: bool = False) -> List[dict]:
+                    device_preprocess: bool = True, pipeline: bool = True) -> List[dict]:
     """items: dicts with "video" (decoded frames array / list / a reader with get_batch), optional "fps", "id", "query"
     (formatted into `prompt` as the tvg / vhd tasks do, evaluate.py:303-306).  Returns one result dict per item, in order, on
     every rank: {"video", "id", "timestamps", "scores", "captions", "output_ids"}."""
@@ -101,8 +101,8 @@ def evaluate_videos(model, tokenizer, processor, items: Sequence[dict], prompt: 
     eng = model.engine
     # videos decoded together: the decode batch limit (128; 64 on the fp8 path).  When the engine holds two such banks of KV slots (max_batch >= 2 bs)
     # the chunks go through the two-stage pipeline: chunk k decodes on one stream while chunk k+1 is preprocessed, encoded and prefilled on another
-    # (opt-in: `pipeline=True`.  Bit-identical to the chunk-by-chunk loop in every test, but a 60-step stress run showed one step with one
-    # sequence's arg-max differing from the sequential run's — not root-caused, profiles/r03_pipeline_stress_ids_differ.txt — so it is not the default)
+    # (the default since round 4; `pipeline=False`: chunk by chunk.  Bit-identical to the chunk-by-chunk loop in every test.  Round 3 kept it opt-in
+    # because a rare wrong ViT row panel showed up under it; that needs the ViT's LayerNorm fold, which is off by default now — DESIGN 5a)
     bs = max(1, min(batch_size or eng.decode_batch_max, eng.decode_batch_max, eng.max_batch))
     pipelined = pipeline and eng.max_batch >= 2 * bs
     nf = num_frames or getattr(model.config, "num_frames", 128)
@@ -158,7 +158,8 @@ def main():
     ap.add_argument("--num-frames", type=int, default=None)
     ap.add_argument("--max-new-tokens", type=int, default=512)
     ap.add_argument("--batch-size", type=int, default=128, help="videos decoded together")
-    ap.add_argument("--pipeline", action="store_true", help="two-stage pipeline over the chunks (two banks of KV slots; experimental, see evaluate_videos)")
+    ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=True, help="(default) two-stage pipeline over the chunks: two banks of KV slots, a chunk decodes while the next is encoded")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="chunk by chunk, one bank of KV slots")
     args = ap.parse_args()
     from .mm_utils import get_model_name_from_path
     from .model.builder import load_pretrained_model

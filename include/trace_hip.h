@@ -157,6 +157,11 @@ int trace_set_profile(trace_ctx* ctx, int on);
 /* Debugging aid: device addresses of the K cache, the V^T cache and the prefill's last-position hidden rows, with strides[8] = layer, slot, kv-head
  * strides (elements), ctx_pad, layers, kv heads, head_dim, hidden (tools/pipeline_stress.py checksums them between the pipeline's stages). */
 int trace_debug_buffers(trace_ctx* ctx, void** kcache, void** vcache, void** xlast, int64_t* strides);
+/* Debugging aid (tools/pipeline_stress.py --trace): with `buf` set, every trace_vit_forward call that runs with the LayerNorm fold leaves one record of
+ * 64-bit checksums — [layer][stage: 0 qkv out, 1 attention out, 2 out-proj out, 3 row statistics, 4 fc1 out, 5 fc2 out, 6 row statistics][256-row
+ * panel] — in record (call index % capacity_calls) of `buf` (device memory, launched on the call's stream).  Returns the words per record (also with
+ * buf == NULL, which switches the tracing off); every call resets the call index. */
+int64_t trace_debug_vit_trace(trace_ctx* ctx, void* buf, int64_t capacity_calls);
 /* out[0..n) (n <= 20): [0] ms per decode step of the last trace_decode_steps call, [1] its steps, [2] average ms of the bracketed decode launch,
  * [3] its samples, [4] its algorithmic bytes, [5] average ms of the bracketed ViT fc1 GEMM launch, [6] its samples, [7] its GFLOP,
  * [8] which decode launch took the bracket: 1 = gate|up GEMV, 2 = batch-1 fused-norm gate|up GEMV, 3 = the wide step's layer-0 decode attention,

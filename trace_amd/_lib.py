@@ -60,6 +60,7 @@ SIGNATURES = {
     "trace_set_gemm_cus": (I, [P, I]),
     "trace_set_profile": (I, [P, I]),
     "trace_debug_buffers": (I, [P, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(C.c_int64)]),
+    "trace_debug_vit_trace": (C.c_int64, [P, P, C.c_int64]),
     "trace_get_profile": (I, [P, P, I]),
     "trace_set_profile_brackets": (I, [P, I]),
     "trace_op_gemm": (I, [P, I, P, I, P, I, P, P, I, I, I, I, I, P]),

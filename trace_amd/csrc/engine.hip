@@ -119,6 +119,9 @@ struct trace_ctx {
     int kev_used = 0;
     hipEvent_t gev0 = nullptr, gev1 = nullptr;   // pair recorded from inside the captured graph
     double ksum_ms = 0.0; int ksamples = 0;
+    // debugging aid (trace_debug_vit_trace, tools/pipeline_stress.py --trace): per tower call one record [layer][stage][256-row panel] of checksums of
+    // what every stage of every layer left (qkv out, attention out, out-proj out, statistics, fc1 out, fc2 out, statistics)
+    unsigned long long* vtrace = nullptr; long vtrace_cap = 0, vtrace_idx = 0;
     hipEvent_t mev0 = nullptr, mev1 = nullptr;   // bracket of one ViT fc1 GEMM launch per trace_vit_forward (profile == 2)
     double msum_ms = 0.0; int msamples = 0; double mflops = 0.0; int mM = 0;
     // the other three GEMM shapes of the layer (qkv, out-proj, fc2), bracketed the same way in layer 0: the 256x256 MFMA GEMM family is the run's
@@ -588,6 +591,33 @@ static int gemm_fp8(trace_ctx* c, const bf16_t* A, int lda, const uint8_t* W8, c
     return TRACE_OK;
 }
 
+// One workgroup per 256-row panel: position-weighted sum of the 32-bit words of rows [256 p, 256 p + 256) (valid rows only) of a row-major buffer
+__global__ __launch_bounds__(256) void panel_checksum_kernel(const uint32_t* __restrict__ x, long ld_words, int rows, int row_words,
+                                                             unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long s_part[256];
+    const int p = blockIdx.x, r0 = p * 256, r1 = min(rows, r0 + 256);
+    unsigned long long acc = 0;
+    for (int r = r0; r < r1; ++r)
+        for (int w = threadIdx.x; w < row_words; w += 256)
+            acc += (unsigned long long)x[(size_t)r * ld_words + w] * (unsigned long long)(1 + ((r - r0) * 131 + w) % 65521);
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[p] = s_part[0];
+}
+constexpr int VTRACE_STAGES = 7;
+extern "C" int64_t trace_debug_vit_trace(trace_ctx* c, void* buf, int64_t capacity_calls) {
+    // buf: capacity_calls records of trace_debug_vit_trace(c, nullptr, 0) unsigned 64-bit words each (the return value: words per record); buf == null
+    // switches the tracing off.  Every call resets the record index to 0 (the caller compares / copies the records on the stream between steps).
+    if (!c) return -1;
+    const long panels = ((long)c->vit_frames * c->NT + 255) / 256;
+    c->vtrace = (unsigned long long*)buf; c->vtrace_cap = buf ? (long)capacity_calls : 0; c->vtrace_idx = 0;
+    return (int64_t)c->vL * VTRACE_STAGES * panels;
+}
+
 extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dtype, int T, void* feats_out, void* stream) {
     if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
     if (!frames || T < 1 || T > c->vit_frames) return fail(TRACE_ERR_ARG, "bad frames / T (more than max_frames / vit_batch_frames)");
@@ -630,6 +660,15 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
         if (rc != TRACE_OK) return fail(rc, "ViT GEMM launch failed (LayerNorm fold)");
         return TRACE_OK;
     };
+    const long vt_panels = ((long)c->vit_frames * NT + 255) / 256;
+    unsigned long long* vt_rec = nullptr;
+    if (c->vtrace && c->vtrace_cap > 0) { vt_rec = c->vtrace + (size_t)(c->vtrace_idx % c->vtrace_cap) * c->vL * VTRACE_STAGES * vt_panels; c->vtrace_idx += 1; }
+#define VTRACE(L_, ST_, PTR_, LD_ELEMS_, COLS_)                                                                                                    \
+    if (vt_rec) hipLaunchKernelGGL(panel_checksum_kernel, dim3((Mv + 255) / 256), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(PTR_),       \
+                                   (long)(LD_ELEMS_) / 2, Mv, (COLS_) / 2, vt_rec + ((size_t)(L_) * VTRACE_STAGES + (ST_)) * vt_panels)
+#define VTRACE_STATS(L_, ST_)                                                                                                                      \
+    if (vt_rec && fold) hipLaunchKernelGGL(panel_checksum_kernel, dim3((Mv + 255) / 256), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(c->vStats), \
+                                           2L, Mv, 2, vt_rec + ((size_t)(L_) * VTRACE_STAGES + (ST_)) * vt_panels)
     if (fold && !fused_pe) LCHK(launch_ln_row_stats(c->vX, vh, Mv, vh, c->c.v_eps, c->vStats, s));       // layer 0's input came from vit_assemble, not from a GEMM
     for (int l = 0; l < c->vL; ++l) {
         const VitLayer& L = c->vit[l];
@@ -645,20 +684,26 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
             VPROBE_BEGIN(0);
             TRY(fgemm(c->vX, vh, L.wqkv_f, vh, c->vQKV, 3 * vh, L.c2q, L.c1q, nullptr, 3 * vh, vh, EPI_NONE, nullptr));
             VPROBE_END(0, 3 * vh, vh);
+            VTRACE(l, 0, c->vQKV, 3 * vh, 3 * vh);
             if (a.v_perm != 2)
                 LCHK(launch_transpose_v(c->vQKV + 2 * vh, (long)NT * 3 * vh, 64, 3 * vh, c->vVT, a.v_bs, a.v_hs, c->tokpad, NT, 64, c->vheads, T, s, a.v_perm));
             LCHK(launch_attn_vit(a, s));
+            VTRACE(l, 1, c->vH, vh, vh);
             VPROBE_BEGIN(1);
             TRY(fgemm(c->vH, vh, L.wo, vh, c->vX, vh, L.bo, nullptr, c->vX, vh, vh, EPI_RESIDUAL, c->vStatsPart));
             VPROBE_END(1, vh, vh);
+            VTRACE(l, 2, c->vX, vh, vh);
             LCHK(launch_ln_stats_finalize(c->vStatsPart, vh / 256, Mv, vh, c->c.v_eps, c->vStats, s));
+            VTRACE_STATS(l, 3);
             if (probe) hipEventRecord(c->mev0, s);
             TRY(fgemm(c->vX, vh, L.w1_f, vh, c->vMLP, vi, L.c2f, L.c1f, nullptr, vi, vh, EPI_QUICKGELU, nullptr));
             if (probe) { hipEventRecord(c->mev1, s); c->mflops = 2.0 * Mv * (double)vi * vh; }
+            VTRACE(l, 4, c->vMLP, vi, vi);
             VPROBE_BEGIN(2);
             TRY(fgemm(c->vMLP, vi, L.w2, vi, c->vX, vh, L.b2, nullptr, c->vX, vh, vi, EPI_RESIDUAL, c->vStatsPart));
             VPROBE_END(2, vh, vi);
-            if (l + 1 < c->vL) LCHK(launch_ln_stats_finalize(c->vStatsPart, vh / 256, Mv, vh, c->c.v_eps, c->vStats, s));
+            VTRACE(l, 5, c->vX, vh, vh);
+            if (l + 1 < c->vL) { LCHK(launch_ln_stats_finalize(c->vStatsPart, vh / 256, Mv, vh, c->c.v_eps, c->vStats, s)); VTRACE_STATS(l, 6); }
             continue;
         }
         LCHK(launch_layernorm(c->vX, vh, c->vH, vh, L.ln1w, L.ln1b, Mv, vh, c->c.v_eps, s));
@@ -682,6 +727,8 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
 #undef VPROBE_BEGIN
 #undef VPROBE_END
     }
+#undef VTRACE
+#undef VTRACE_STATS
     if (c->profile == 2 && (c->bracket_mask & 1) && c->vL > 0 && Mv == c->mM) {
         hipEventSynchronize(c->vev[5]);                       // layer 0's fc2: the last of the bracketed launches
         float ms = 0.f;

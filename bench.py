@@ -185,9 +185,11 @@ def run_c1(args) -> None:
                        "baseline_config": "c1", "videos_per_step_per_gpu": 1, "frames": args.frames, "new_tokens": n_new,
                        "model": "tiny-layer geometry of the reference fixtures (hidden 4096, 2 decoder layers, 3-layer CLIP at 56x56), synthetic weights"},
             "cpu_baseline": cpu}
+    import shutil
     if not torch.cuda.is_available():
         line["config"]["note"] = "no HIP device visible: CPU leg only (the HIP path has no CPU fallback)"
         print(json.dumps(line), flush=True)
+        shutil.rmtree(tmp, ignore_errors=True)
         return
     # ---- GPU leg: the drop-in surface over the C ABI
     el_dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
@@ -222,6 +224,7 @@ def run_c1(args) -> None:
                  "parsed": parse_output_ids(ids_hip, tokenizer, model)})
     print(json.dumps(line), flush=True)
     model.engine.close()
+    shutil.rmtree(tmp, ignore_errors=True)
 
 
 def self_launch(args) -> None:

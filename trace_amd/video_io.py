@@ -178,11 +178,17 @@ class AviReader:
     bottom-up).  Inter-coded streams (H.264, MPEG-4, ...) are refused with the reason."""
 
     def __init__(self, path: str):
+        import mmap
         self.path = path
-        with open(path, "rb") as f:
-            data = f.read()
+        self._file = open(path, "rb")
+        try:                                               # mapped, not read: a Motion-JPEG clip can be gigabytes, and only the sampled frames are touched
+            data = mmap.mmap(self._file.fileno(), 0, access=mmap.ACCESS_READ)
+        except ValueError:                                 # (an empty file cannot be mapped)
+            self._file.close()
+            raise ValueError(f"{path}: not a RIFF AVI file")
         buf = memoryview(data)
         if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"AVI ":
+            buf.release(); data.close(); self._file.close()
             raise ValueError(f"{path}: not a RIFF AVI file")
         self._data = data
         self._frames: List[Tuple[int, int]] = []
@@ -220,6 +226,7 @@ class AviReader:
                 for c2, p2, n2 in _riff_chunks(buf, p + 4, p + n):
                     if c2[2:] in (b"dc", b"db") and n2 > 0:
                         self._frames.append((p2, n2))
+        buf.release()
         if not self._fps and usec:
             self._fps = 1e6 / usec
         comp = self._compression.upper()
@@ -233,6 +240,17 @@ class AviReader:
 
     def __len__(self) -> int:
         return len(self._frames)
+
+    def close(self) -> None:
+        if getattr(self, "_data", None) is not None:
+            self._data.close(); self._file.close()
+            self._data = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def get_avg_fps(self) -> float:
         return self._fps

@@ -391,3 +391,48 @@ def test_stc_connector_matches_reference_forward(golden_dir):
     rows = zs[0].permute(1, 2, 3, 0).reshape(-1, cfg.hidden_size)
     zr = F.gelu(rows @ sd[P + "readout.0.weight"].t() + sd[P + "readout.0.bias"]) @ sd[P + "readout.2.weight"].t() + sd[P + "readout.2.bias"]
     np.testing.assert_allclose(zr.numpy()[:, M["out_cols"]], M["sampler_readout"], rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("cin,cout", [(8, 16), (16, 16)])
+def test_stc_regstage_block_topology_vs_transformers_regnet(cin, cout):
+    """The one part of the STC connector that no fixture can pin here is timm 0.6.13's RegStage block (timm is absent).  A second, independent public
+    implementation of the RegNet-Y block exists in this container: transformers' `RegNetYLayer` (its port of Facebook's pycls RegNet).  With the two
+    choices timm's STC call makes — `norm_layer = LayerNorm2d` (eps 1e-6) instead of BatchNorm, `act_layer = nn.SiLU` (which timm's Bottleneck also hands
+    to its squeeze-excite module) — and depthwise 3x3 (timm's default group_size = 1 = transformers' groups_width = 1), the oracle's restated block must
+    compute what that implementation computes: 1x1 conv-norm-act, 3x3 depthwise conv-norm-act, SE with round(in_channels / 4) reduced channels on the 3x3
+    output, 1x1 conv-norm, + shortcut (1x1 conv-norm only when the width changes), activation.  This cross-checks the block's wiring against a published
+    implementation; that timm 0.6.13 makes exactly these choices stays this build's reading of it (UNPINNED)."""
+    import torch.nn as nn
+    from transformers import RegNetConfig
+    from transformers.models.regnet.modeling_regnet import RegNetYLayer
+
+    class LN2d(nn.Module):
+        def __init__(self, c):
+            super().__init__()
+            self.weight, self.bias = nn.Parameter(torch.ones(c)), nn.Parameter(torch.zeros(c))
+
+        def forward(self, x):
+            return torch.nn.functional.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), self.weight, self.bias, 1e-6).permute(0, 3, 1, 2)
+
+    torch.manual_seed(cin * 100 + cout)
+    layer = RegNetYLayer(RegNetConfig(hidden_act="silu", groups_width=1), cin, cout, stride=1).eval()
+    convs = [layer.layer[0], layer.layer[1], layer.layer[3]]
+    for m in convs + ([layer.shortcut] if cin != cout else []):
+        m.normalization = LN2d(cout)
+        nn.init.normal_(m.normalization.weight, 1.0, 0.1); nn.init.normal_(m.normalization.bias, 0.0, 0.1)
+    se = layer.layer[2]
+    se.attention[1] = nn.SiLU()
+    assert se.attention[0].out_channels == int(round(cin * 0.25)) and layer.layer[1].convolution.groups == cout
+    W = {"conv1.conv.weight": convs[0].convolution.weight, "conv1.bn.weight": convs[0].normalization.weight, "conv1.bn.bias": convs[0].normalization.bias,
+         "conv2.conv.weight": convs[1].convolution.weight, "conv2.bn.weight": convs[1].normalization.weight, "conv2.bn.bias": convs[1].normalization.bias,
+         "se.fc1.weight": se.attention[0].weight, "se.fc1.bias": se.attention[0].bias, "se.fc2.weight": se.attention[2].weight, "se.fc2.bias": se.attention[2].bias,
+         "conv3.conv.weight": convs[2].convolution.weight, "conv3.bn.weight": convs[2].normalization.weight, "conv3.bn.bias": convs[2].normalization.bias}
+    if cin != cout:
+        W.update({"downsample.conv.weight": layer.shortcut.convolution.weight, "downsample.bn.weight": layer.shortcut.normalization.weight,
+                  "downsample.bn.bias": layer.shortcut.normalization.bias})
+    ora = O.Oracle(tcfg.tiny(), {"blk." + k: v.detach() for k, v in W.items()}, emulate_bf16=False)
+    x = torch.randn(3, cin, 5, 5)
+    with torch.no_grad():
+        want = layer(x.clone())
+        got = ora._reg_block(x, "blk.")
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-5)

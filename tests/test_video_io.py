@@ -123,8 +123,45 @@ def test_process_video_from_a_file_equals_process_video_from_its_frames(tmp_path
     assert a.seen[0].shape == (64, 64, 3)                                         # expand2square of 48 x 64 frames
 
 
+def test_mp4_with_still_image_samples_round_trip(tmp_path):
+    """ISO-BMFF with a Photo-JPEG / Motion-JPEG video track: the sample table (stsd / stts / stsc / stsz / stco) is parsed here, the samples go to Pillow"""
+    fr = _clip(T=11, H=46, W=62)
+    p = str(tmp_path / "c.mp4")
+    vio.write_mjpeg_mp4(p, fr, fps=(30000, 1001))
+    vr = vio.open_container(p)
+    assert isinstance(vr, vio.Mp4Reader) and len(vr) == 11 and abs(vr.get_avg_fps() - 29.97) < 1e-2 and (vr.width, vr.height) == (62, 46)
+    got = vr.get_batch([10, 0, 5]).asnumpy()
+    assert got.shape == (3, 46, 62, 3) and np.abs(got.astype(int) - fr[[10, 0, 5]].astype(int)).mean() < 2.0
+    with pytest.raises(IndexError):
+        vr.get_batch([11])
+    a, b = _Proc(), _Proc()
+    _, ts_file = process_video(p, a, "pad", 4)
+    _, ts_arr = process_video(vr.get_batch(range(11)).asnumpy(), b, "pad", 4, fps=vr.get_avg_fps())
+    assert ts_file == ts_arr and all(np.array_equal(x, y) for x, y in zip(a.seen, b.seen))
+
+
 def test_containers_that_need_a_codec_say_so(tmp_path):
-    p = tmp_path / "clip.mp4"
-    p.write_bytes(b"\0\0\0\x18ftypisom")
-    with pytest.raises(ImportError, match="decord"):
-        process_video(str(p), _Proc(), "pad", 8)
+    """an inter-coded track is named by its fourcc and handed to decord as the reference does (mm_utils.py:421) — without decord: ImportError saying so;
+    something that is not a media file at all: ValueError"""
+    fr = _clip(T=3)
+    p = str(tmp_path / "clip.mp4")
+    vio.write_mjpeg_mp4(p, fr, fourcc=b"avc1")
+    with pytest.raises(ValueError, match="avc1"):
+        vio.Mp4Reader(p)
+    try:
+        import decord  # noqa: F401
+        has_decord = True
+    except ImportError:
+        has_decord = False
+    if not has_decord:
+        with pytest.raises(ImportError, match="decord"):
+            process_video(p, _Proc(), "pad", 8)
+    q = tmp_path / "junk.mp4"
+    q.write_bytes(b"\0\0\0\x18ftypisom")
+    with pytest.raises(ValueError, match="not an ISO base media file"):
+        process_video(str(q), _Proc(), "pad", 8)
+    w = tmp_path / "clip.webm"
+    w.write_bytes(b"\x1aE\xdf\xa3")
+    if not has_decord:
+        with pytest.raises(ImportError, match="decord"):
+            process_video(str(w), _Proc(), "pad", 8)

@@ -2,7 +2,9 @@
 through those packages; none of them exists in this image, and a codec such as H.264 is out of this build's scope).  What is read here:
 
 * `.y4m` (YUV4MPEG2, the uncompressed interchange format `ffmpeg -i clip.mp4 clip.y4m` writes): 4:2:0 / 4:2:2 / 4:4:4 / mono, 8 bit;
-* `.avi` holding Motion-JPEG (`MJPG`) or uncompressed 24-bit (`DIB `) frames: every frame is an independent image, decoded with Pillow.
+* `.avi` holding Motion-JPEG (`MJPG`) or uncompressed 24-bit (`DIB `) frames: every frame is an independent image, decoded with Pillow;
+* `.mp4 / .mov / .m4v` (ISO-BMFF) whose video track holds still images (Motion-JPEG / Photo-JPEG / PNG samples): the sample table is parsed here,
+  the samples decoded with Pillow; an inter-coded track (avc1, hvc1, vp09, ...) is named and handed to decord, as the reference does.
 
 Both readers present decord's `VideoReader` surface as far as `process_video` uses it — `len(vr)`, `vr.get_avg_fps()`,
 `vr.get_batch(indices).asnumpy()` -> uint8 `[n, H, W, 3]` RGB (mm_utils.py:421-431) — so the sampling / timestamp code above them is the
@@ -315,6 +317,194 @@ def write_avi(path: str, frames_rgb: np.ndarray, fps: Tuple[int, int] = (25, 1),
         f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
 
 
+# ---------------------------------------------------------------------------------------------------------------- MP4 / MOV (intra-only codecs)
+_MP4_INTRA = {b"jpeg", b"mjpa", b"mjpg", b"MJPG", b"png "}         # sample = one still image Pillow decodes (Photo-JPEG / Motion-JPEG A / PNG)
+
+
+def _boxes(buf, start: int, end: int):
+    """(type, payload start, payload end) of the ISO-BMFF boxes in [start, end)"""
+    pos = start
+    while pos + 8 <= end:
+        size, typ = struct.unpack_from(">I4s", buf, pos)
+        hdr = 8
+        if size == 1:
+            size = struct.unpack_from(">Q", buf, pos + 8)[0]
+            hdr = 16
+        elif size == 0:
+            size = end - pos
+        if size < hdr or pos + size > end:
+            break
+        yield typ, pos + hdr, pos + size
+        pos += size
+
+
+class Mp4Reader:
+    """ISO-BMFF (`.mp4 / .mov / .m4v`) with a video track of independent still images (Motion-JPEG / Photo-JPEG / PNG samples): sample table -> byte
+    ranges -> Pillow.  A track coded with an inter-frame codec (avc1 = H.264, hvc1 = HEVC, vp09, av01, mp4v ...) is refused with its fourcc: that
+    needs a video decoder (decord in the reference), not a container parser."""
+
+    def __init__(self, path: str):
+        import mmap
+        self.path = path
+        self._file = open(path, "rb")
+        try:
+            data = mmap.mmap(self._file.fileno(), 0, access=mmap.ACCESS_READ)
+        except ValueError:
+            self._file.close()
+            raise ValueError(f"{path}: not an ISO base media file")
+        self._data = data
+        buf = memoryview(data)
+        try:
+            self._parse(buf, path)
+        except Exception:
+            buf.release(); self.close()
+            raise
+        buf.release()
+
+    def _parse(self, buf, path):
+        n = len(buf)
+        top = {t: (a, b) for t, a, b in _boxes(buf, 0, n)}
+        if b"moov" not in top:
+            raise ValueError(f"{path}: not an ISO base media file (no moov box)")
+        track = None
+        for t, a, b in _boxes(buf, *top[b"moov"]):
+            if t != b"trak":
+                continue
+            mdia = next(((x, y) for tt, x, y in _boxes(buf, a, b) if tt == b"mdia"), None)
+            if mdia is None:
+                continue
+            sub = {tt: (x, y) for tt, x, y in _boxes(buf, *mdia)}
+            if b"hdlr" not in sub or bytes(buf[sub[b"hdlr"][0] + 8: sub[b"hdlr"][0] + 12]) != b"vide" or b"minf" not in sub:
+                continue
+            minf = {tt: (x, y) for tt, x, y in _boxes(buf, *sub[b"minf"])}
+            if b"stbl" not in minf:
+                continue
+            track = (sub, {tt: (x, y) for tt, x, y in _boxes(buf, *minf[b"stbl"])})
+            break
+        if track is None:
+            raise ValueError(f"{path}: no video track")
+        sub, stbl = track
+        m0 = sub[b"mdhd"][0]
+        ver = buf[m0]
+        timescale, duration = (struct.unpack_from(">IQ", buf, m0 + 20) if ver == 1 else struct.unpack_from(">II", buf, m0 + 12))
+        s0 = stbl[b"stsd"][0]
+        fourcc = bytes(buf[s0 + 12: s0 + 16])
+        self.width, self.height = struct.unpack_from(">HH", buf, s0 + 8 + 8 + 24)
+        if fourcc not in _MP4_INTRA:
+            raise ValueError(f"{path}: the video track is coded as {fourcc!r}: only tracks of independent still images (Motion-JPEG / Photo-JPEG / PNG samples) "
+                             "are decoded here; inter-coded video (avc1 = H.264, hvc1, vp09, av01, ...) needs a decoder — `ffmpeg -i in.mp4 out.y4m`, or install decord")
+        z0 = stbl[b"stsz"][0]
+        uniform, count = struct.unpack_from(">II", buf, z0 + 4)
+        sizes = [uniform] * count if uniform else list(struct.unpack_from(f">{count}I", buf, z0 + 12))
+        if b"stco" in stbl:
+            c0 = stbl[b"stco"][0]
+            nch = struct.unpack_from(">I", buf, c0 + 4)[0]
+            chunks = list(struct.unpack_from(f">{nch}I", buf, c0 + 8))
+        else:
+            c0 = stbl[b"co64"][0]
+            nch = struct.unpack_from(">I", buf, c0 + 4)[0]
+            chunks = list(struct.unpack_from(f">{nch}Q", buf, c0 + 8))
+        c0 = stbl[b"stsc"][0]
+        nsc = struct.unpack_from(">I", buf, c0 + 4)[0]
+        runs = [struct.unpack_from(">III", buf, c0 + 8 + 12 * i) for i in range(nsc)]          # (first chunk, samples per chunk, description)
+        self._frames: List[Tuple[int, int]] = []
+        si = 0
+        for ci in range(nch):
+            per = next(r[1] for r in reversed(runs) if r[0] <= ci + 1)
+            off = chunks[ci]
+            for _ in range(per):
+                if si >= count:
+                    break
+                self._frames.append((off, sizes[si]))
+                off += sizes[si]
+                si += 1
+        if si != count or not count:
+            raise ValueError(f"{path}: sample table does not add up ({si} of {count} samples placed)")
+        # average frame rate = samples / (sum of the stts deltas / timescale); the media duration as the fallback
+        t0 = stbl[b"stts"][0]
+        nts = struct.unpack_from(">I", buf, t0 + 4)[0]
+        total = sum(c * d for c, d in (struct.unpack_from(">II", buf, t0 + 8 + 8 * i) for i in range(nts))) or duration
+        if not total or not timescale:
+            raise ValueError(f"{path}: no timing information")
+        self._fps = count * timescale / total
+
+    def __len__(self) -> int:
+        return len(self._frames)
+
+    def get_avg_fps(self) -> float:
+        return self._fps
+
+    def close(self) -> None:
+        if getattr(self, "_data", None) is not None:
+            self._data.close(); self._file.close()
+            self._data = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __getitem__(self, i: int) -> np.ndarray:
+        from PIL import Image
+        p, n = self._frames[int(i)]
+        with Image.open(io.BytesIO(self._data[p:p + n])) as im:
+            return np.asarray(im.convert("RGB"))
+
+    def get_batch(self, indices: Sequence[int]) -> _Batch:
+        idx = [int(i) for i in indices]
+        if any(i < 0 or i >= len(self) for i in idx):
+            raise IndexError(f"frame index out of range (0..{len(self) - 1}): {idx}")
+        return _Batch(np.stack([self[i] for i in idx]) if idx else np.zeros((0, self.height, self.width, 3), np.uint8))
+
+
+def write_mjpeg_mp4(path: str, frames_rgb: np.ndarray, fps: Tuple[int, int] = (25, 1), quality: int = 95, fourcc: bytes = b"jpeg") -> None:
+    """uint8 RGB [T, H, W, 3] -> a minimal ISO-BMFF file with one Photo-JPEG video track (one chunk per sample) — for the tests and for round trips"""
+    from PIL import Image
+    fr = np.asarray(frames_rgb)
+    if fr.dtype != np.uint8 or fr.ndim != 4 or fr.shape[-1] != 3:
+        raise ValueError("frames must be uint8 [T, H, W, 3]")
+    T, H, W, _ = fr.shape
+    samples = []
+    for t in range(T):
+        b = io.BytesIO()
+        Image.fromarray(fr[t]).save(b, format="JPEG", quality=quality, subsampling=0)
+        samples.append(b.getvalue())
+
+    def box(typ: bytes, payload: bytes) -> bytes:
+        return struct.pack(">I4s", 8 + len(payload), typ) + payload
+
+    def full(typ: bytes, payload: bytes, version: int = 0, flags: int = 0) -> bytes:
+        return box(typ, struct.pack(">I", (version << 24) | flags) + payload)
+
+    ftyp = box(b"ftyp", b"isom" + struct.pack(">I", 0x200) + b"isomiso2mp41")
+    mdat_payload = b"".join(samples)
+    data0 = len(ftyp) + 8
+    offs, o = [], data0
+    for sm in samples:
+        offs.append(o)
+        o += len(sm)
+    timescale, delta = fps[0], fps[1]
+    matrix = struct.pack(">9I", 0x10000, 0, 0, 0, 0x10000, 0, 0, 0, 0x40000000)
+    mvhd = full(b"mvhd", struct.pack(">IIII", 0, 0, timescale, T * delta) + struct.pack(">IH", 0x10000, 0x100) + bytes(10) + matrix + bytes(24) + struct.pack(">I", 2))
+    tkhd = full(b"tkhd", struct.pack(">IIIII", 0, 0, 1, 0, T * delta) + bytes(8) + struct.pack(">HHHH", 0, 0, 0, 0) + matrix + struct.pack(">II", W << 16, H << 16), flags=3)
+    mdhd = full(b"mdhd", struct.pack(">IIII", 0, 0, timescale, T * delta) + struct.pack(">HH", 0x55C4, 0))
+    hdlr = full(b"hdlr", struct.pack(">I4s", 0, b"vide") + bytes(12) + b"VideoHandler\0")
+    entry = bytes(6) + struct.pack(">H", 1) + bytes(16) + struct.pack(">HH", W, H) + struct.pack(">II", 0x480000, 0x480000) + struct.pack(">I", 0) + \
+        struct.pack(">H", 1) + bytes(32) + struct.pack(">Hh", 24, -1)
+    stsd = full(b"stsd", struct.pack(">I", 1) + struct.pack(">I4s", 8 + len(entry), fourcc) + entry)
+    stts = full(b"stts", struct.pack(">III", 1, T, delta))
+    stsc = full(b"stsc", struct.pack(">IIII", 1, 1, 1, 1))
+    stsz = full(b"stsz", struct.pack(">II", 0, T) + struct.pack(f">{T}I", *[len(x) for x in samples]))
+    stco = full(b"stco", struct.pack(">I", T) + struct.pack(f">{T}I", *offs))
+    stbl = box(b"stbl", stsd + stts + stsc + stsz + stco)
+    dinf = box(b"dinf", full(b"dref", struct.pack(">I", 1) + full(b"url ", b"", flags=1)))
+    minf = box(b"minf", full(b"vmhd", bytes(8), flags=1) + dinf + stbl)
+    moov = box(b"moov", mvhd + box(b"trak", tkhd + box(b"mdia", mdhd + hdlr + minf)))
+    with open(path, "wb") as f:
+        f.write(ftyp + box(b"mdat", mdat_payload) + moov)
+
+
 def open_container(path: str):
     """A reader with decord's VideoReader surface for the containers decodable without a codec library, or None (the caller then needs decord)."""
     low = path.lower()
@@ -322,4 +512,16 @@ def open_container(path: str):
         return Y4MReader(path)
     if low.endswith(".avi"):
         return AviReader(path)
+    if low.endswith((".mp4", ".mov", ".m4v")):
+        # a track of still images is read here; an inter-coded one (the usual case) goes to decord like in the reference — with the codec named if it is absent
+        try:
+            return Mp4Reader(path)
+        except ValueError as e:
+            if "needs a decoder" not in str(e):
+                raise
+            try:
+                import decord  # noqa: F401
+            except ImportError:
+                raise ImportError(str(e)) from e
+            return None
     return None

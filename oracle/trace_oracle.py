@@ -11,8 +11,11 @@ oracle is pinned against outputs of the reference itself, run in the build conta
 dumps `tests/golden/*.npz|json`).  `tests/test_oracle_golden.py` checks every function here against
 those fixtures.  The third-party arithmetic the reference delegates to (transformers 4.40.1
 CLIPVisionModel / MistralModel; container has 5.15.0, same eager math) is restated from the
-published architecture and anchored by the same fixtures.  STC connector: parity unpinned
-(timm.RegStage is not importable here) -> not restated.
+published architecture and anchored by the same fixtures.  STC connector: pinned against the
+reference's own `STCConnector.forward` (tests/golden/stc_connector.npz: layouts, Conv3d sampler,
+readout MLP, token order) EXCEPT for the RegStage block — timm 0.6.13 is not importable here; the
+block is restated from its published structure, cross-checked against transformers' independent
+RegNet-Y block (tests/test_oracle_golden.py), and that part says "parity unpinned".
 
 `emulate_bf16=True` rounds activations to bf16 at the points where the HIP engine stores bf16
 tensors to HBM (same points a bf16 reference model rounds at, minus the ones fused away), so GPU
@@ -311,7 +314,8 @@ class Oracle:
         return r(res @ W["model.mm_projector.readout.weight"].t())               # :467
 
     # -- STCConnector (multimodal_projector/builder.py:138-249), legacy trace.infer() path -----------
-    # PARITY UNPINNED: timm.models.regnet.RegStage is not importable in the build container, so the block
+    # stc_connector() as a whole is pinned by tests/golden/stc_connector.npz (the reference's own forward with this block substituted for timm's).
+    # PARITY UNPINNED for the block itself: timm.models.regnet.RegStage is not importable in the build container, so the block
     # below follows timm 0.6.x `Bottleneck` from memory (1x1 conv -> LN2d -> SiLU; depthwise 3x3 -> LN2d -> SiLU;
     # SE with rd = round(in_chs/4), SiLU, sigmoid gate; 1x1 conv -> LN2d; + shortcut (1x1 conv + LN2d when the
     # channel count changes); SiLU).  It pins the HIP path against THIS restatement only.

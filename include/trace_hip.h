@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define TRACE_ABI_VERSION 3
+#define TRACE_ABI_VERSION 4
 
 typedef struct trace_ctx trace_ctx;
 
@@ -157,15 +157,10 @@ int trace_set_profile(trace_ctx* ctx, int on);
 /* Debugging aid: device addresses of the K cache, the V^T cache and the prefill's last-position hidden rows, with strides[8] = layer, slot, kv-head
  * strides (elements), ctx_pad, layers, kv heads, head_dim, hidden (tools/pipeline_stress.py checksums them between the pipeline's stages). */
 int trace_debug_buffers(trace_ctx* ctx, void** kcache, void** vcache, void** xlast, int64_t* strides);
-/* Debugging aid (tools/pipeline_stress.py --trace): with `buf` set, every trace_vit_forward call that runs with the LayerNorm fold leaves one record of
- * 64-bit checksums — [layer][stage: 0 qkv out, 1 attention out, 2 out-proj out, 3 row statistics, 4 fc1 out, 5 fc2 out, 6 row statistics][256-row
- * panel] — in record (call index % capacity_calls) of `buf` (device memory, launched on the call's stream).  Returns the words per record (also with
- * buf == NULL, which switches the tracing off); every call resets the call index. */
-int64_t trace_debug_vit_trace(trace_ctx* ctx, void* buf, int64_t capacity_calls);
 /* out[0..n) (n <= 20): [0] ms per decode step of the last trace_decode_steps call, [1] its steps, [2] average ms of the bracketed decode launch,
  * [3] its samples, [4] its algorithmic bytes, [5] average ms of the bracketed ViT fc1 GEMM launch, [6] its samples, [7] its GFLOP,
  * [8] which decode launch took the bracket: 1 = gate|up GEMV, 2 = batch-1 fused-norm gate|up GEMV, 3 = the wide step's layer-0 decode attention,
- * [9] 1 if the bracketed ViT GEMMs ran with the LayerNorm fold (opt-in), 0 with LayerNorm kernels,
+ * [9] always 0 (rounds 3-4: whether the bracketed ViT GEMMs ran with the LayerNorm fold; the fold left the product in round 5),
  * [12..14] average ms of the bracketed ViT qkv / out-proj / fc2 GEMM launches (layer 0, the same calls as [5]), [15..17] their GFLOP. */
 int trace_get_profile(trace_ctx* ctx, float* out, int n);
 /* Which per-launch brackets profiling mode 2 takes: bit 0 = the ViT fc1 GEMM, bit 1 = the decode step's dominant kernel.  A pipelined caller
@@ -180,12 +175,6 @@ int trace_op_set_gemm_variant(int variant);
 /* profiling: device buffer of 8 x uint64 per workgroup receiving phase time stamps of every later GEMM launch (NULL = off) */
 int trace_op_set_gemm_trace(void* buf);
 int trace_op_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, float eps, void* stream);
-/* The ViT's LayerNorm fold, piece by piece: C = act(LayerNorm(X) . W^T + bias) as one GEMM on the raw rows (epilogue 0 / 2 = QuickGELU; N % 256 == 0,
-   K % 64 == 0), and C = A . W^T + bias + R with the row statistics (rstd, -mean * rstd) of C [M][2] that the next such GEMM takes */
-int trace_op_gemm_lnfold(const void* X, const void* W, const void* gamma, const void* beta, const void* bias, void* C, int M, int N, int K, float eps,
-                         int epilogue, void* stream);
-int trace_op_gemm_residual_stats(const void* A, const void* W, const void* bias, const void* R, void* C, float* stats_out, int M, int N, int K, float eps,
-                                 void* stream);
 int trace_op_rmsnorm(const void* x, void* y, const void* w, int rows, int D, float eps, void* stream);
 int trace_op_attention(const void* Q, const void* K, const void* V, void* O, void* vt_scratch, int batch, int heads,
                        int kv_heads, int nq, int nkv, int head_dim, int causal, float scale, void* stream);

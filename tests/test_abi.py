@@ -26,7 +26,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.trace_abi_version() == 3
+    assert lib.trace_abi_version() == 4
     assert lib.trace_element_type() == 0
     assert isinstance(lib.trace_last_error(), (bytes, type(None)))
 
@@ -36,7 +36,7 @@ def test_fp16_library_exports_the_same_abi(lib):
     the bf16 library in one process."""
     from trace_amd import _lib
     l16 = _lib.load("f16")
-    assert l16 is not lib and l16.trace_abi_version() == 3 and l16.trace_element_type() == 1
+    assert l16 is not lib and l16.trace_abi_version() == 4 and l16.trace_element_type() == 1
     for name in _lib.SIGNATURES:
         assert hasattr(l16, name), name
     assert lib.trace_element_type() == 0

@@ -83,12 +83,8 @@ def test_decode_gemv_does_not_spill(res):
 
 
 def test_round3_kernels_keep_their_budgets(res):
-    """The LayerNorm-fold instantiations of the persistent GEMM (OPT 16: the first builds of that epilogue spilled 40-116 bytes per lane) and the
-    decode GEMMs of the wide decode step (128x128 tiles, tiled weights, 4-stage ring: 128 KB of LDS = one workgroup per CU by design, no scratch)."""
-    lnf = {k: v for k, v in _pick(res["gemm_pers"], "gemm_pers_kernel").items() if "ELi16E" in k}
-    assert len(lnf) >= 2, list(res["gemm_pers"])
-    for k, v in lnf.items():
-        assert v["ScratchSize"] == 0 and v["VGPRs"] + v.get("AGPRs", 0) <= 168, (k, v)
+    """The decode GEMMs of the wide decode step (128x128 tiles, tiled weights, 4-stage ring: 128 KB of LDS = one workgroup per CU by design, no
+    scratch) and the batch-1 GEMVs with a prologue."""
     dec = {k: v for k, v in _pick(res["gemm"], "gemm_glds_kernel").items() if "ELb1ELi4E" in k}      # <..., WT = true, NSTAGE = 4>
     assert len(dec) >= 2, list(res["gemm"])
     for k, v in dec.items():

@@ -60,14 +60,11 @@ SIGNATURES = {
     "trace_set_gemm_cus": (I, [P, I]),
     "trace_set_profile": (I, [P, I]),
     "trace_debug_buffers": (I, [P, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(C.c_int64)]),
-    "trace_debug_vit_trace": (C.c_int64, [P, P, C.c_int64]),
     "trace_get_profile": (I, [P, P, I]),
     "trace_set_profile_brackets": (I, [P, I]),
     "trace_op_gemm": (I, [P, I, P, I, P, I, P, P, I, I, I, I, I, P]),
     "trace_op_set_gemm_variant": (I, [I]),
     "trace_op_layernorm": (I, [P, P, P, P, I, I, F, P]),
-    "trace_op_gemm_lnfold": (I, [P, P, P, P, P, P, I, I, I, F, I, P]),
-    "trace_op_gemm_residual_stats": (I, [P, P, P, P, P, P, I, I, I, F, P]),
     "trace_op_rmsnorm": (I, [P, P, P, I, I, F, P]),
     "trace_op_attention": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "trace_op_skinny_gemm": (I, [P, P, P, P, I, I, I, I, I, P]),
@@ -125,7 +122,7 @@ def load(element: str = "bf16"):
         fn.argtypes = args
         if res is I and name not in NOT_A_STATUS:
             fn.errcheck = errcheck
-    if lib.trace_abi_version() != 3:
+    if lib.trace_abi_version() != 4:
         raise TraceHipError(f"{os.path.basename(path)} ABI version mismatch")
     if lib.trace_element_type() != {"bf16": 0, "f16": 1}[element]:
         raise TraceHipError(f"{os.path.basename(path)} was not built for {element} elements")

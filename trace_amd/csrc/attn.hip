@@ -575,11 +575,8 @@ template <int HD, bool GQA>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
     constexpr int BUF = BKV * HD * 2 + HD * VROW;
     const size_t lds = 2 * BUF;
-    static bool done = false;
-    if (!done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<HD, GQA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        done = true;
-    }
+    static LdsGrant grant;
+    if (!grant_dynamic_lds(grant, reinterpret_cast<const void*>(attn_kernel<HD, GQA>), (int)lds)) return TRACE_ERR_HIP;
     const int nqt = (a.nq_rows + 31) / 32;
     const long nblk = (long)(GQA ? nqt : (nqt + 3) / 4) * a.kv_heads * a.batch;
     if (nblk > 0x7fffffffL) return TRACE_ERR_ARG;
@@ -605,12 +602,9 @@ int launch_attn_vit(const AttnArgs& a_, hipStream_t s) {
     if (a.v_perm) {
         if (a.causal || !attn_vit_wants_perm(a.nkv_rows, a.Vrow != nullptr)) return TRACE_ERR_ARG;
         if (a.v_perm == 2 && (!a.Vrow || (a.vr_rs % 8) || (a.vr_hs % 8) || (a.vr_bs % 8))) return TRACE_ERR_ARG;
-        static bool done = false;
-        if (!done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_vit_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DSTAGES * DSTAGE);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_vit_dma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DSTAGES * DSTAGE);
-            done = true;
-        }
+        static LdsGrant grant_t, grant_r;
+        if (!grant_dynamic_lds(grant_t, reinterpret_cast<const void*>(attn_vit_dma_kernel<false>), DSTAGES * DSTAGE) ||
+            !grant_dynamic_lds(grant_r, reinterpret_cast<const void*>(attn_vit_dma_kernel<true>), DSTAGES * DSTAGE)) return TRACE_ERR_HIP;
         const int nqt = (a.nq_rows + 31) / 32;
         const long nblk = (long)((nqt + 3) / 4) * a.kv_heads * a.batch;
         if (nblk > 0x7fffffffL) return TRACE_ERR_ARG;

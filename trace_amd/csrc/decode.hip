@@ -1021,12 +1021,8 @@ static int skinny_lds_launch(const SkinnyPlan& p, const bf16_t* X, int ldx, cons
                              const bf16_t* R, int ldr, int B, int K, float* ws, unsigned int* tickets, int tiled, hipStream_t s,
                              const SkinnyPro& pro = SkinnyPro{}) {
     const size_t lds = (size_t)p.chunk_units * 2 * NB * 1024 + (p.WPT > 1 ? (size_t)p.T * p.WPT * NT * NB * 1024 : 0);
-    static size_t granted = 0;
-    if (lds > granted) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_lds_kernel<EPI, NB, NT, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) return TRACE_ERR_HIP;
-        granted = lds;
-    }
+    static LdsGrantSized grant;
+    if (!grant_dynamic_lds(grant, reinterpret_cast<const void*>(skinny_lds_kernel<EPI, NB, NT, PRO>), lds)) return TRACE_ERR_HIP;
     hipLaunchKernelGGL((skinny_lds_kernel<EPI, NB, NT, PRO>), dim3(p.grid), dim3(p.threads), lds, s, X, ldx, W, ldw, out, ldo, R, ldr, B, K,
                        p.chunk_units, p.KS, p.T, p.WPT, p.ntiles, ws, tickets, tiled, g_skinny_debug, pro);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;

@@ -25,9 +25,6 @@ static int fail(int code, const std::string& m) { g_err = m; return code; }
 
 struct VitLayer {
     bf16_t *ln1w, *ln1b, *wqkv, *bqkv, *wo, *bo, *ln2w, *ln2b, *w1, *b1, *w2, *b2;
-    // LayerNorm fold (made at finalize): weights pre-multiplied by the LayerNorm weight, their row sums c1 and the folded bias c2
-    bf16_t *wqkv_f, *c2q, *w1_f, *c2f;
-    float *c1q, *c1f;
 };
 struct LlmLayer {
     bf16_t *rms1, *wqkv, *wo, *rms2, *wgu, *wd;
@@ -59,7 +56,7 @@ struct trace_ctx {
     bool counted = false;            // in g_ctx_per_dev (the last context of a device frees the persistent GEMM's ticket counters)
     // weights
     bf16_t *patch_w, *cls, *pos_emb, *pre_w, *pre_b;
-    bf16_t *patch_wp = nullptr, *cls_row = nullptr; float* cls_stats = nullptr;      // fused patch embedding (patch_embed.hip): repacked conv weight, the CLS row, its fold statistics
+    bf16_t *patch_wp = nullptr, *cls_row = nullptr;      // fused patch embedding (patch_embed.hip): repacked conv weight, the CLS row
     std::vector<VitLayer> vit;
     bf16_t *sl_lnw, *sl_lnb, *sl_slots, *sl_readout;
     // STC connector (projector_type == 1)
@@ -75,7 +72,6 @@ struct trace_ctx {
     size_t kv_head_stride, slot_stride, layer_stride;
     // ViT workspaces
     bf16_t *vX, *vH, *vQKV, *vVT, *vMLP;
-    float *vStats = nullptr, *vStatsPart = nullptr;      // LayerNorm fold: (rstd, -mean rstd) per token row; per-column-tile (sum, sum of squares)
     bf16_t *sl_res, *sl_out, *video;     // [T*S, vh], [T*S, H], [T*TPF, H]
     float* sl_ws = nullptr; size_t sl_ws_floats = 0;   // slot pool: per-part softmax partials
     int video_rows = 0;
@@ -121,7 +117,6 @@ struct trace_ctx {
     double ksum_ms = 0.0; int ksamples = 0;
     // debugging aid (trace_debug_vit_trace, tools/pipeline_stress.py --trace): per tower call one record [layer][stage][256-row panel] of checksums of
     // what every stage of every layer left (qkv out, attention out, out-proj out, statistics, fc1 out, fc2 out, statistics)
-    unsigned long long* vtrace = nullptr; long vtrace_cap = 0, vtrace_idx = 0;
     hipEvent_t mev0 = nullptr, mev1 = nullptr;   // bracket of one ViT fc1 GEMM launch per trace_vit_forward (profile == 2)
     double msum_ms = 0.0; int msamples = 0; double mflops = 0.0; int mM = 0;
     // the other three GEMM shapes of the layer (qkv, out-proj, fc2), bracketed the same way in layer 0: the 256x256 MFMA GEMM family is the run's
@@ -195,12 +190,11 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
 #define A(p, n) if (rc == TRACE_OK) rc = dalloc(c, &(p), (size_t)(n))
     // --- weights ---
     A(c->patch_w, vh * c->Kpad); A(c->cls, vh); A(c->pos_emb, (size_t)c->NT * vh); A(c->pre_w, vh); A(c->pre_b, vh);
-    if (patch_embed_supported(cfg->v_image, c->P, (int)vh)) { A(c->patch_wp, patch_embed_packed_elems(c->P, (int)vh)); A(c->cls_row, vh); A(c->cls_stats, 2); }
+    if (patch_embed_supported(cfg->v_image, c->P, (int)vh)) { A(c->patch_wp, patch_embed_packed_elems(c->P, (int)vh)); A(c->cls_row, vh); }
     c->vit.resize(c->vL);
     for (auto& l : c->vit) {
         A(l.ln1w, vh); A(l.ln1b, vh); A(l.wqkv, 3 * vh * vh); A(l.bqkv, 3 * vh); A(l.wo, vh * vh); A(l.bo, vh);
         A(l.ln2w, vh); A(l.ln2b, vh); A(l.w1, vi * vh); A(l.b1, vi); A(l.w2, vh * vi); A(l.b2, vh);
-        A(l.wqkv_f, 3 * vh * vh); A(l.c1q, 3 * vh); A(l.c2q, 3 * vh); A(l.w1_f, vi * vh); A(l.c1f, vi); A(l.c2f, vi);
     }
     if (!c->stc) { A(c->sl_lnw, vh); A(c->sl_lnb, vh); A(c->sl_slots, vh * c->S); A(c->sl_readout, H * vh); }
     else {
@@ -243,7 +237,6 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     // --- ViT workspaces ---
     const size_t Tm = cfg->max_frames, Tv_ = c->vit_frames, Mv = Tv_ * c->NT;      // tower workspaces: vit_batch_frames at a time
     A(c->vX, Mv * vh); A(c->vH, Mv * vh); A(c->vQKV, Mv * 3 * vh); A(c->vVT, Tv_ * vh * c->tokpad);
-    A(c->vStats, Mv * 2); A(c->vStatsPart, Mv * 2 * std::max<size_t>(1, vh / 256));
     {
         const size_t mlp = Mv * vi, im2 = Tv_ * c->GG * c->Kpad;
         A(c->vMLP, mlp > im2 ? mlp : im2);
@@ -318,6 +311,7 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
 
 extern "C" int trace_ctx_destroy(trace_ctx* c) {
     if (!c) return TRACE_OK;
+    (void)hipSetDevice(c->dev);       // the calling thread's current device may be another GPU: everything below (and the counters' key) is this context's
     hipDeviceSynchronize();
     for (auto& st : c->streams) { gemm_pers_forget(st); hipStreamDestroy(st); }
     for (auto& g : c->graphs) if (g) hipGraphExecDestroy(g);
@@ -526,12 +520,7 @@ extern "C" int trace_ctx_finalize(trace_ctx* c) {
     // fused patch embedding: the conv weight in the kernel's k order / fragment layout, and the CLS row (the same for every frame)
     if (c->patch_wp) {
         LCHK(launch_patch_pack(c->patch_w, c->Kpad, c->patch_wp, c->vh, c->P, 0));
-        LCHK(launch_cls_row(c->cls, c->pos_emb, c->pre_w, c->pre_b, c->cls_row, c->cls_stats, c->vh, c->c.v_eps, c->c.v_eps, 0));
-    }
-    // LayerNorm fold of the ViT: qkv and fc1 weights pre-multiplied by the preceding LayerNorm's weight, with the two correction rows
-    for (auto& l : c->vit) {
-        LCHK(launch_ln_fold_weights(l.wqkv, c->vh, l.ln1w, l.ln1b, l.bqkv, l.wqkv_f, l.c1q, l.c2q, 3 * c->vh, c->vh, 0));
-        LCHK(launch_ln_fold_weights(l.w1, c->vh, l.ln2w, l.ln2b, l.b1, l.w1_f, l.c1f, l.c2f, c->vi, c->vh, 0));
+        LCHK(launch_cls_row(c->cls, c->pos_emb, c->pre_w, c->pre_b, c->cls_row, c->vh, c->c.v_eps, 0));
     }
     // decode copies of the LLM matrices in the GEMV tile layout (288 GB of HBM: +14.5 GB buys ~25% on the weight stream)
     for (auto& l : c->llm) {
@@ -565,11 +554,6 @@ extern "C" int trace_ctx_finalize(trace_ctx* c) {
 }
 
 // ------------------------------------------------------------------------------------------------ ViT
-int g_vit_ln_fold = 0;      // 1: the ViT's LayerNorms folded into the qkv / fc1 GEMMs (round 3; trace_op_set_gemm_variant(150 + x)).  OFF since round 4: with the
-                            // fold on, one 256-row panel of one tower GEMM came out wrong about once per 100 stress steps whenever the tower ran on a side
-                            // stream with the host running ahead (8 wrong steps in 752, pipelined), never in 355+ steps without it; the tickets are cleared
-                            // (the static tile deal fails too) and so is the coherence of the statistics buffers (agent-scope atomics fail too) — DESIGN 5a.
-                            // It bought 1.2 % of a layer; until the cause is found the LayerNorm kernels stay.
 int g_vit_patch_fused = 1;  // 0: im2col matrix -> GEMM -> assemble instead of the fused front end (A/B: trace_op_set_gemm_variant(160 + x))
 static unsigned long long* g_gemm_trace = nullptr;      // tools/gemm_trace.py
 extern "C" int trace_op_set_gemm_trace(void* buf) { g_gemm_trace = (unsigned long long*)buf; return TRACE_OK; }
@@ -591,51 +575,18 @@ static int gemm_fp8(trace_ctx* c, const bf16_t* A, int lda, const uint8_t* W8, c
     return TRACE_OK;
 }
 
-// One workgroup per 256-row panel: position-weighted sum of the 32-bit words of rows [256 p, 256 p + 256) (valid rows only) of a row-major buffer
-__global__ __launch_bounds__(256) void panel_checksum_kernel(const uint32_t* __restrict__ x, long ld_words, int rows, int row_words,
-                                                             unsigned long long* __restrict__ out) {
-    __shared__ unsigned long long s_part[256];
-    const int p = blockIdx.x, r0 = p * 256, r1 = min(rows, r0 + 256);
-    unsigned long long acc = 0;
-    for (int r = r0; r < r1; ++r)
-        for (int w = threadIdx.x; w < row_words; w += 256)
-            acc += (unsigned long long)x[(size_t)r * ld_words + w] * (unsigned long long)(1 + ((r - r0) * 131 + w) % 65521);
-    s_part[threadIdx.x] = acc;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[p] = s_part[0];
-}
-constexpr int VTRACE_STAGES = 7;
-extern "C" int64_t trace_debug_vit_trace(trace_ctx* c, void* buf, int64_t capacity_calls) {
-    // buf: capacity_calls records of trace_debug_vit_trace(c, nullptr, 0) unsigned 64-bit words each (the return value: words per record); buf == null
-    // switches the tracing off.  Every call resets the record index to 0 (the caller compares / copies the records on the stream between steps).
-    if (!c) return -1;
-    const long panels = ((long)c->vit_frames * c->NT + 255) / 256;
-    c->vtrace = (unsigned long long*)buf; c->vtrace_cap = buf ? (long)capacity_calls : 0; c->vtrace_idx = 0;
-    return (int64_t)c->vL * VTRACE_STAGES * panels;
-}
-
 extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dtype, int T, void* feats_out, void* stream) {
     if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
     if (!frames || T < 1 || T > c->vit_frames) return fail(TRACE_ERR_ARG, "bad frames / T (more than max_frames / vit_batch_frames)");
     hipStream_t s = (hipStream_t)stream;
     const int vh = c->vh, vi = c->vi, NT = c->NT, GG = c->GG, Mv = T * NT;
-    // LayerNorm fold (round 3): when this call's shapes run on the kernels that carry it — qkv / fc1 on the persistent GEMM, out-proj / fc2 on the
-    // loader-wave GEMM — neither LayerNorm of a layer is a pass of its own: the residual GEMMs' epilogues leave the row sums of what they store,
-    // a finalize kernel turns them into (rstd, -mean rstd), and the next GEMM runs on the raw residual stream with pre-scaled weights and applies
-    // rstd (acc - mean c1) + c2 in its epilogue.  Smaller calls (a few frames) keep the LayerNorm kernel.
-    const bool fold = g_vit_ln_fold && vh % 256 == 0 && gemm_routes_to_pers(Mv, 3 * vh, vh) && gemm_routes_to_pers(Mv, vi, vh) &&
-                      gemm_routes_to_ldr(Mv, vh, vh) && gemm_routes_to_ldr(Mv, vh, vi);
-    // front end: one kernel reads the frame tensor, multiplies the patches on the MFMA, adds CLS / position embeddings, applies
-    // pre_layrnorm and leaves the first layer's row statistics (patch_embed.hip).  g_vit_patch_fused = 0 (A/B) or a patch size / width the
-    // kernel does not take: the round-1 path, im2col matrix -> GEMM -> assemble (+ a row-statistics pass for the fold).
+    // front end: one kernel reads the frame tensor, multiplies the patches on the MFMA, adds CLS / position embeddings and applies
+    // pre_layrnorm (patch_embed.hip).  g_vit_patch_fused = 0 (A/B) or a patch size / width the kernel does not take: the round-1 path,
+    // im2col matrix -> GEMM -> assemble.
     const bool fused_pe = g_vit_patch_fused && c->patch_wp;
     if (fused_pe) {
-        LCHK(launch_patch_embed(frames, frames_dtype == 1, c->patch_wp, c->pos_emb, c->pre_w, c->pre_b, c->cls_row, c->cls_stats, c->vX,
-                                fold ? c->vStats : nullptr, T, c->c.v_image, c->P, vh, c->c.v_eps, c->c.v_eps, s));
+        LCHK(launch_patch_embed(frames, frames_dtype == 1, c->patch_wp, c->pos_emb, c->pre_w, c->pre_b, c->cls_row, c->vX, T, c->c.v_image, c->P, vh,
+                                c->c.v_eps, s));
     } else {
         bf16_t* im2 = c->vMLP;                       // [T*GG, Kpad]
         bf16_t* pe = c->vH;                          // [T*GG, vh]
@@ -653,23 +604,6 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
     a.scale = 0.125f; a.causal = 0;
     a.Vrow = c->vQKV + 2 * vh; a.vr_bs = a.q_bs; a.vr_hs = 64; a.vr_rs = 3 * vh;
     a.v_perm = attn_vit_wants_perm(NT, true) ? (attn_vit_rowmajor_v() ? 2 : 1) : 0;     // 2: V read row-major from vQKV, no transpose pass
-    auto fgemm = [&](const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* Cc, int ldc, const bf16_t* c2, const float* c1, const bf16_t* R,
-                     int N, int K, int epi, float* stats_part) -> int {
-        GemmArgs g{A, lda, W, ldw, Cc, ldc, c2, R, R ? vh : 0, Mv, N, K, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, 0, c1 ? c->vStats : nullptr, c1, stats_part};
-        const int rc = launch_gemm_bf16(g, epi, s);
-        if (rc != TRACE_OK) return fail(rc, "ViT GEMM launch failed (LayerNorm fold)");
-        return TRACE_OK;
-    };
-    const long vt_panels = ((long)c->vit_frames * NT + 255) / 256;
-    unsigned long long* vt_rec = nullptr;
-    if (c->vtrace && c->vtrace_cap > 0) { vt_rec = c->vtrace + (size_t)(c->vtrace_idx % c->vtrace_cap) * c->vL * VTRACE_STAGES * vt_panels; c->vtrace_idx += 1; }
-#define VTRACE(L_, ST_, PTR_, LD_ELEMS_, COLS_)                                                                                                    \
-    if (vt_rec) hipLaunchKernelGGL(panel_checksum_kernel, dim3((Mv + 255) / 256), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(PTR_),       \
-                                   (long)(LD_ELEMS_) / 2, Mv, (COLS_) / 2, vt_rec + ((size_t)(L_) * VTRACE_STAGES + (ST_)) * vt_panels)
-#define VTRACE_STATS(L_, ST_)                                                                                                                      \
-    if (vt_rec && fold) hipLaunchKernelGGL(panel_checksum_kernel, dim3((Mv + 255) / 256), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(c->vStats), \
-                                           2L, Mv, 2, vt_rec + ((size_t)(L_) * VTRACE_STAGES + (ST_)) * vt_panels)
-    if (fold && !fused_pe) LCHK(launch_ln_row_stats(c->vX, vh, Mv, vh, c->c.v_eps, c->vStats, s));       // layer 0's input came from vit_assemble, not from a GEMM
     for (int l = 0; l < c->vL; ++l) {
         const VitLayer& L = c->vit[l];
         // MFMA roofline probe (profile == 2): HIP events around ONE launch of each of the layer's four GEMM shapes, in layer 0, per call — of the
@@ -680,32 +614,6 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
         const bool probe = (l == 0 && vprof && Mv == c->mM);
 #define VPROBE_BEGIN(i) if (probe) hipEventRecord(c->vev[2 * (i)], s)
 #define VPROBE_END(i, N_, K_) if (probe) { hipEventRecord(c->vev[2 * (i) + 1], s); c->vflops[i] = 2.0 * Mv * (double)(N_) * (K_); }
-        if (fold) {
-            VPROBE_BEGIN(0);
-            TRY(fgemm(c->vX, vh, L.wqkv_f, vh, c->vQKV, 3 * vh, L.c2q, L.c1q, nullptr, 3 * vh, vh, EPI_NONE, nullptr));
-            VPROBE_END(0, 3 * vh, vh);
-            VTRACE(l, 0, c->vQKV, 3 * vh, 3 * vh);
-            if (a.v_perm != 2)
-                LCHK(launch_transpose_v(c->vQKV + 2 * vh, (long)NT * 3 * vh, 64, 3 * vh, c->vVT, a.v_bs, a.v_hs, c->tokpad, NT, 64, c->vheads, T, s, a.v_perm));
-            LCHK(launch_attn_vit(a, s));
-            VTRACE(l, 1, c->vH, vh, vh);
-            VPROBE_BEGIN(1);
-            TRY(fgemm(c->vH, vh, L.wo, vh, c->vX, vh, L.bo, nullptr, c->vX, vh, vh, EPI_RESIDUAL, c->vStatsPart));
-            VPROBE_END(1, vh, vh);
-            VTRACE(l, 2, c->vX, vh, vh);
-            LCHK(launch_ln_stats_finalize(c->vStatsPart, vh / 256, Mv, vh, c->c.v_eps, c->vStats, s));
-            VTRACE_STATS(l, 3);
-            if (probe) hipEventRecord(c->mev0, s);
-            TRY(fgemm(c->vX, vh, L.w1_f, vh, c->vMLP, vi, L.c2f, L.c1f, nullptr, vi, vh, EPI_QUICKGELU, nullptr));
-            if (probe) { hipEventRecord(c->mev1, s); c->mflops = 2.0 * Mv * (double)vi * vh; }
-            VTRACE(l, 4, c->vMLP, vi, vi);
-            VPROBE_BEGIN(2);
-            TRY(fgemm(c->vMLP, vi, L.w2, vi, c->vX, vh, L.b2, nullptr, c->vX, vh, vi, EPI_RESIDUAL, c->vStatsPart));
-            VPROBE_END(2, vh, vi);
-            VTRACE(l, 5, c->vX, vh, vh);
-            if (l + 1 < c->vL) { LCHK(launch_ln_stats_finalize(c->vStatsPart, vh / 256, Mv, vh, c->c.v_eps, c->vStats, s)); VTRACE_STATS(l, 6); }
-            continue;
-        }
         LCHK(launch_layernorm(c->vX, vh, c->vH, vh, L.ln1w, L.ln1b, Mv, vh, c->c.v_eps, s));
         VPROBE_BEGIN(0);
         TRY(gemm(c->vH, vh, L.wqkv, vh, c->vQKV, 3 * vh, L.bqkv, nullptr, 0, Mv, 3 * vh, vh, EPI_NONE, s));
@@ -727,8 +635,6 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
 #undef VPROBE_BEGIN
 #undef VPROBE_END
     }
-#undef VTRACE
-#undef VTRACE_STATS
     if (c->profile == 2 && (c->bracket_mask & 1) && c->vL > 0 && Mv == c->mM) {
         hipEventSynchronize(c->vev[5]);                       // layer 0's fc2: the last of the bracketed launches
         float ms = 0.f;
@@ -738,7 +644,7 @@ extern "C" int trace_vit_forward(trace_ctx* c, const void* frames, int frames_dt
         c->prof[5] = (float)(c->msum_ms / c->msamples);
         c->prof[6] = (float)c->msamples;
         c->prof[7] = (float)(c->mflops / 1e9);               // GFLOP of the bracketed launch
-        c->prof[9] = fold ? 1.f : 0.f;                        // which instantiations the brackets timed (LayerNorm fold on / off)
+        c->prof[9] = 0.f;                                     // (was: LayerNorm fold on / off — the fold left the product in round 5)
         for (int i = 0; i < 3; ++i) { c->prof[12 + i] = (float)(c->vsum_ms[i] / c->msamples); c->prof[15 + i] = (float)(c->vflops[i] / 1e9); }
     }
     if (feats_out)   // drop CLS: [T, GG, vh]
@@ -1457,6 +1363,7 @@ extern "C" int trace_stream_destroy(trace_ctx* c, void* stream) {
     if (!c || !stream) return fail(TRACE_ERR_ARG, "null argument");
     auto it = std::find(c->streams.begin(), c->streams.end(), (hipStream_t)stream);
     if (it == c->streams.end()) return fail(TRACE_ERR_ARG, "not a stream of this context");
+    HIPCHK(hipSetDevice(c->dev));
     HIPCHK(hipStreamSynchronize(*it));
     gemm_pers_forget(*it);
     HIPCHK(hipStreamDestroy(*it));
@@ -1465,6 +1372,7 @@ extern "C" int trace_stream_destroy(trace_ctx* c, void* stream) {
 }
 extern "C" int trace_set_gemm_cus(trace_ctx* c, int n) {
     if (!c || n < 0) return fail(TRACE_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(c->dev));
     // per stream, and only this context's streams (trace_stream_create already sets a CU-masked stream's cap to its CU count; this overrides it).
     // Until round 3 this wrote a process-wide number that nothing reset: every later persistent GEMM of the process stayed capped.
     for (hipStream_t st : c->streams)
@@ -1516,15 +1424,13 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
-    if (variant >= 150 && variant <= 151) { g_vit_ln_fold = variant - 150; return TRACE_OK; }
     if (variant >= 160 && variant <= 161) { g_vit_patch_fused = variant - 160; return TRACE_OK; }
     if (variant >= 170 && variant <= 174) { g_decode_fuse_norm_rows = variant - 170; return TRACE_OK; }
     if (variant >= 180 && variant <= 181) { g_decode_fuse_swiglu = variant - 180; return TRACE_OK; }
     if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : 32; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
-    if (variant >= 510 && variant <= 511) { g_ln_stats_plain = variant - 510; return TRACE_OK; }   // LayerNorm-fold statistics: 0 = agent-scope atomics, 1 = round 3's plain accesses
-    if (variant >= 500 && variant <= 502) { g_gemm_pers_walk = variant - 500; return TRACE_OK; }   // the persistent GEMM's tile walk on every route (gemm_pers.hip)
+    if (variant >= 500 && variant <= 501) { g_gemm_pers_walk = variant - 500; return TRACE_OK; }   // the persistent GEMM's tile walk on every route (gemm_pers.hip)
     if (variant >= 400 && variant < 404) { g_gemm_ldr_opt = variant - 400; return TRACE_OK; }   // microbench: attention phase cut-offs
     if (variant < 0 || variant > 7) return fail(TRACE_ERR_ARG, "variant must be 0..7");
     g_gemm_variant = variant;
@@ -1673,43 +1579,6 @@ extern "C" int trace_op_skinny_fused_norm(const float* part_in, int ks_in, const
     hipStreamSynchronize(s);
     hipFree(wt); hipFree(ws);
     if (rc != TRACE_OK) return fail(rc, "fused-norm GEMV failed");
-    return TRACE_OK;
-}
-
-// ---- LayerNorm-fold hooks (tests/test_gpu_kernels.py) ----
-// C = act(LayerNorm(X; gamma, beta, eps) . W^T + bias) as ONE persistent GEMM on the raw rows: row statistics of X, weights pre-multiplied by gamma,
-// the fold epilogue (gemm_pers.hip).  epilogue 0 none / 2 QuickGELU.  M >= 1, N % 256 == 0, K % 64 == 0, K >= 128.
-extern "C" int trace_op_gemm_lnfold(const void* X, const void* W, const void* gamma, const void* beta, const void* bias, void* C, int M, int N, int K,
-                                    float eps, int epilogue, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    bf16_t *wf = nullptr, *c2 = nullptr; float *c1 = nullptr, *st = nullptr;
-    HIPCHK(hipMalloc((void**)&wf, (size_t)N * K * 2)); HIPCHK(hipMalloc((void**)&c1, (size_t)N * 4)); HIPCHK(hipMalloc((void**)&c2, (size_t)N * 2));
-    HIPCHK(hipMalloc((void**)&st, (size_t)M * 8));
-    int rc = launch_ln_fold_weights((const bf16_t*)W, K, (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)bias, wf, c1, c2, N, K, s);
-    if (rc == TRACE_OK) rc = launch_ln_row_stats((const bf16_t*)X, K, M, K, eps, st, s);
-    if (rc == TRACE_OK) {
-        GemmArgs g{(const bf16_t*)X, K, wf, K, (bf16_t*)C, N, c2, nullptr, 0, M, N, K, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, 0, st, c1, nullptr};
-        rc = launch_gemm_bf16(g, epilogue, s);
-    }
-    hipStreamSynchronize(s);
-    hipFree(wf); hipFree(c1); hipFree(c2); hipFree(st);
-    if (rc != TRACE_OK) return fail(rc, "LayerNorm-fold GEMM failed");
-    return TRACE_OK;
-}
-// C = A . W^T + bias + R on the loader-wave GEMM with the producer epilogue, then the finalize kernel: stats_out [M][2] = (rstd, -mean * rstd) of the
-// rows of C.  N % 256 == 0.
-extern "C" int trace_op_gemm_residual_stats(const void* A, const void* W, const void* bias, const void* R, void* C, float* stats_out, int M, int N,
-                                            int K, float eps, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    float* part = nullptr;
-    HIPCHK(hipMalloc((void**)&part, (size_t)(N / 256) * M * 8));
-    GemmArgs g{(const bf16_t*)A, K, (const bf16_t*)W, K, (bf16_t*)C, N, (const bf16_t*)bias, (const bf16_t*)R, N, M, N, K, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, 0,
-               nullptr, nullptr, part};
-    int rc = launch_gemm_bf16(g, EPI_RESIDUAL, s);
-    if (rc == TRACE_OK) rc = launch_ln_stats_finalize(part, N / 256, M, N, eps, stats_out, s);
-    hipStreamSynchronize(s);
-    hipFree(part);
-    if (rc != TRACE_OK) return fail(rc, "residual GEMM with row statistics failed");
     return TRACE_OK;
 }
 

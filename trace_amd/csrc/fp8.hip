@@ -298,13 +298,8 @@ template <int NB, int NT, bool WONLY = false>
 int fp8_launch(const Fp8Plan& p, const uint8_t* X8, long ldx, const float* sx, const uint8_t* W, const float* sw, int B, int N, int K, float* ws,
                hipStream_t s) {
     const size_t lds = (size_t)p.chunk_units * (WONLY ? 4 : 2) * NB * 1024 + (p.WPT > 1 ? (size_t)p.T * p.WPT * NT * NB * 1024 : 0);
-    static size_t granted = 0;
-    if (lds > granted) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_fp8_kernel<NB, NT, WONLY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return TRACE_ERR_HIP;
-        granted = lds;
-    }
+    static LdsGrantSized grant;
+    if (!grant_dynamic_lds(grant, reinterpret_cast<const void*>(skinny_fp8_kernel<NB, NT, WONLY>), lds)) return TRACE_ERR_HIP;
     hipLaunchKernelGGL((skinny_fp8_kernel<NB, NT, WONLY>), dim3(p.grid), dim3(p.threads), lds, s, X8, ldx, sx, W, sw, B, K, p.chunk_units, p.KS, p.T,
                        p.WPT, p.ntiles, ws, N);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;

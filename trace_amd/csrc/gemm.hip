@@ -351,14 +351,11 @@ int launch_glds(const GemmArgs& p, int epi, hipStream_t s) {
     constexpr size_t lds = (LOOPB > OBYTES) ? LOOPB : OBYTES;
     constexpr int NTHR = WM * WN * 64;
     const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_NONE, FP8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_RESIDUAL, FP8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_QUICKGELU, FP8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_SWIGLU, FP8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static LdsGrant g0, g1, g2, g3;
+    if (!grant_dynamic_lds(g0, reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_NONE, FP8>), (int)lds) ||
+        !grant_dynamic_lds(g1, reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_RESIDUAL, FP8>), (int)lds) ||
+        !grant_dynamic_lds(g2, reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_QUICKGELU, FP8>), (int)lds) ||
+        !grant_dynamic_lds(g3, reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WM, WN, EPI_SWIGLU, FP8>), (int)lds)) return TRACE_ERR_HIP;
     switch (epi) {
         case EPI_NONE: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_NONE, FP8>), dim3(nblk), dim3(NTHR), lds, s, p); break;
         case EPI_RESIDUAL: hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, EPI_RESIDUAL, FP8>), dim3(nblk), dim3(NTHR), lds, s, p); break;
@@ -379,11 +376,8 @@ extern int g_gemm_pers_static;
 template <int EPI, bool WT, int NSTAGE>
 static int launch_dec(const GemmArgs& p, int nblk, hipStream_t s) {
     constexpr int STAGE = (128 + 128) * 128, LOOPB = NSTAGE * STAGE, OBYTES = 128 * (128 * 2 + 16), LDSB = LOOPB > OBYTES ? LOOPB : OBYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<128, 128, 2, 2, EPI, false, WT, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-        attr_done = true;
-    }
+    static LdsGrant grant;
+    if (!grant_dynamic_lds(grant, reinterpret_cast<const void*>(gemm_glds_kernel<128, 128, 2, 2, EPI, false, WT, NSTAGE>), LDSB)) return TRACE_ERR_HIP;
     hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, EPI, false, WT, NSTAGE>), dim3(nblk), dim3(256), LDSB, s, p);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
@@ -410,26 +404,9 @@ int gemm_partial_ks(int N, int K) {
     return ks;
 }
 
-// the dispatch rule below, for callers that need to know which kernel a shape gets (the ViT's LayerNorm fold lives in two of them)
-static bool routes_256(int M, int N, int K) {
-    if (g_gemm_variant != 0 || M <= 0 || N % 256 || K % BK) return false;
-    const long blocks256 = (long)((M + 255) / 256) * (N / 256);
-    const long rounds = (blocks256 + 255) / 256;
-    return M >= 1024 && blocks256 * 10 >= rounds * 256 * 7;
-}
-bool gemm_routes_to_pers(int M, int N, int K) { return routes_256(M, N, K) && K >= 128 && (long)M * N < (1L << 30); }
-bool gemm_routes_to_ldr(int M, int N, int K) { return routes_256(M, N, K); }
-
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
     if (epi == EPI_PARTIAL) return launch_partial(p, s);
     if (p.w_tiled) return epi == EPI_SWIGLU ? launch_swiglu_tiled(p, s) : TRACE_ERR_ARG;
-    // LayerNorm fold: only the persistent kernel has the consumer epilogue, only the loader-wave kernel the producer one — no silent fall-back
-    if (p.stats) {
-        if (p.fp8 || p.N % 256 || p.K % BK || p.K < 128 || (long)p.M * p.ldc >= (1L << 30)) return TRACE_ERR_ARG;
-        g_gemm_pers_static = 0;
-        return launch_gemm_pers(p, epi, s);
-    }
-    if (p.stats_part) return (epi == EPI_RESIDUAL && !p.fp8 && p.N % 256 == 0 && p.K % BK == 0) ? launch_gemm_ldr(p, epi, s) : TRACE_ERR_ARG;
     if (p.M <= 0 || p.N % BN || p.K % BK || p.K < BK) return TRACE_ERR_ARG;
     if (p.fp8 && (p.K % 128 || (p.lda % 16) || (p.ldw % 16) || !p.sa || !p.sw || p.bias || epi == EPI_QUICKGELU)) return TRACE_ERR_ARG;
     if ((p.lda % 8) || (p.ldw % 8) || (p.ldc % 8)) return TRACE_ERR_ARG;

@@ -275,54 +275,22 @@ __global__ __launch_bounds__(NTHR) void gemm_ldr_kernel(GemmArgs p) {
         }
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
         __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(p.C + (size_t)m * p.ldc + on0 + ch * 8));
-        if constexpr (EPI == EPI_RESIDUAL && !FP8) {
-            // LayerNorm fold, producer side: the 32 lanes that hold a row's 256 columns of this tile add up the stored (bf16-rounded) values
-            // and their squares; lane 0 of the row writes the pair — 1 / (N / 256) of the statistics the next GEMM's epilogue needs
-            // (ln_stats_finalize_kernel adds the column tiles' shares)
-            if (p.stats_part) {
-                const uint32_t u[4] = {v.x, v.y, v.z, v.w};
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a = bflo(u[e]), b = bfhi(u[e]);
-                    s1 += a + b;
-                    s2 = fmaf(a, a, fmaf(b, b, s2));
-                }
-                // 32-lane sums on the DPP path (plain VALU): four steps inside each 16-lane row, then row 0 -> row 1 / row 2 -> row 3.  (The first
-                // version used __shfl_xor = ds_bpermute, 160 LDS round trips per thread and tile: +35 us per ViT residual GEMM.)
-#define LDR_DPP_ADD(V, CTRL, ROWMASK) V += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), CTRL, ROWMASK, 0xf, true))
-                LDR_DPP_ADD(s1, 0xB1, 0xf); LDR_DPP_ADD(s2, 0xB1, 0xf);        // quad_perm [1,0,3,2]
-                LDR_DPP_ADD(s1, 0x4E, 0xf); LDR_DPP_ADD(s2, 0x4E, 0xf);        // quad_perm [2,3,0,1]
-                LDR_DPP_ADD(s1, 0x141, 0xf); LDR_DPP_ADD(s2, 0x141, 0xf);      // row_half_mirror
-                LDR_DPP_ADD(s1, 0x140, 0xf); LDR_DPP_ADD(s2, 0x140, 0xf);      // row_mirror: every lane of a 16-lane row holds the row's sum
-                LDR_DPP_ADD(s1, 0x142, 0xa); LDR_DPP_ADD(s2, 0x142, 0xa);      // row_bcast15 into rows 1, 3: lanes 16..31 / 48..63 hold their half's sum
-#undef LDR_DPP_ADD
-                if (ch == 16) {
-                    float* dst = p.stats_part + ((size_t)(n0 / BN) * p.M + m) * 2;
-                    if (p.opt & 2) *reinterpret_cast<float2*>(dst) = make_float2(s1, s2);       // round-3 form (A/B)
-                    else st_agent_f2(dst, s1, s2);                                              // written through: common.h
-                }
-            }
-        }
     }
 }
 
 template <int EPI, bool FP8>
 void launch_one(const GemmArgs& p, int nblk, size_t lds, hipStream_t s) {
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ldr_kernel<EPI, FP8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        done = true;
-    }
+    static LdsGrant grant;
+    (void)grant_dynamic_lds(grant, reinterpret_cast<const void*>(gemm_ldr_kernel<EPI, FP8>), (int)lds);       // a refusal shows as the launch error the caller checks
     hipLaunchKernelGGL((gemm_ldr_kernel<EPI, FP8>), dim3(nblk), dim3(NTHR), lds, s, p);
 }
 
 }  // namespace
 
-int g_gemm_ldr_opt = 0;            // A/B: bit 0 = no residual touches (trace_op_set_gemm_variant(400 + opt))
+int g_gemm_ldr_opt = 0;            // A/B: bit 0 = no residual touches, bit 1 = no A-panel touches (trace_op_set_gemm_variant(400 + opt))
 int launch_gemm_ldr(const GemmArgs& p0, int epi, hipStream_t s) {
     GemmArgs p = p0;
-    p.opt = g_gemm_ldr_opt | (g_ln_stats_plain ? 2 : 0);
+    p.opt = g_gemm_ldr_opt;
     if (p.M < 1 || p.N % BN || p.K % BK) return TRACE_ERR_ARG;
     constexpr size_t LOOPB = 2 * STAGE, OBYTES = (size_t)TOUCH_OFF + 4 * 256;      // staged tile + the fp8 scale rows + the touch scratch
     const size_t lds = LOOPB > OBYTES ? LOOPB : OBYTES;

@@ -36,15 +36,7 @@ constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
 constexpr int CTL_OFF = 2 * STAGE;                // int s_next[2] | 2 x 512-byte bias rows | touch scratch
 constexpr int BIAS_OFF = CTL_OFF + 64;
 constexpr int TOUCH_OFF = BIAS_OFF + 2 * 512;    // 4 x 256 bytes: where the loader waves' L2 touches land (never read)
-constexpr int C1_OFF = TOUCH_OFF + 4 * 256;      // LN fold (OPT bit 4 = 16): 2 x 1 KB rows of the tile's c1 column sums (fp32: it multiplies the row mean and has to
-                                                 // cancel what the K loop accumulated for it), beside the bias rows (= c2, bf16)
-constexpr int STAT_OFF = C1_OFF + 2 * 1024;      // LN fold: 2 x 256 rows x (rstd, -mean * rstd) fp32 of the tile's row panel
-constexpr int LDS_BYTES = STAT_OFF + 2 * 2048;
-// LN FOLD (round 3): C = LayerNorm(A) . W^T + b without the LayerNorm pass.  With W' = W diag(gamma) (bf16, made at load), c1[n] = sum_k W'[n][k]
-// and c2[n] = sum_k beta[k] W[n][k] + b[n]:   C[m][n] = rstd_m (A . W'^T)[m][n] - rstd_m mean_m c1[n] + c2[n] — the K loop runs on the raw
-// residual stream, the epilogue applies one fused multiply-add pair per element from the row's (rstd, -mean rstd) — which the producing GEMM's
-// epilogue + a finalize kernel left in GemmArgs::stats — and the column's (c1, c2) — GemmArgs::c1 / GemmArgs::bias.  The loader waves park the
-// 256 row pairs and the two column rows of every tile in LDS next to the bias row, the MFMA waves read them after the K loop.
+constexpr int LDS_BYTES = TOUCH_OFF + 4 * 256;
 constexpr int CTR_STRIDE = 32;                    // ints between the per-XCD ticket counters (one 128-byte line each)
 
 __device__ __forceinline__ int swz(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
@@ -167,60 +159,24 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // rows I0 .. I0+NI-1 (16-row m-tiles) of the wave's sub-tile: activation in registers, lane transposition, stores.  C and R are addressed
 // through buffer descriptors (scalar base + ONE 32-bit byte offset register per access) whose extent is the M valid rows: rows of the
 // last row panel that hang over M are dropped (stores) / read as zero (loads) by the bounds check, no predicates and no second code path.
-template <int EPI, int I0, int NI, bool LNF = false>
-__device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp)[TN], __amdgpu_buffer_rsrc_t crs, int coff, int cstep, bool hi8,
-                                              const char* lnf_c1, const char* lnf_c2, const char* lnf_stat) {
+template <int EPI, int I0, int NI>
+__device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp)[TN], __amdgpu_buffer_rsrc_t crs, int coff, int cstep, bool hi8) {
     constexpr bool GLU = (EPI == EPI_SWIGLU);
     constexpr int NH = GLU ? 1 : 2;               // 32-column output groups per m-tile
-    // LN fold: the lane's offsets into the tile's LDS rows, rebuilt here from an id the optimiser cannot see through (as loop invariants of the
-    // tile loop they would be two more registers held across the K loop)
-    const char* sc1 = lnf_c1;
-    const char* sc2 = lnf_c1;
-    const char* sstat = lnf_stat;
-    if (LNF) {
-        int lane_l;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l));
-        sc1 = lnf_c1 + (lane_l >> 4) * 16;         // columns g*4 .. +3 of every n-tile: fp32 c1 ...
-        sc2 = lnf_c2 + (lane_l >> 4) * 8;          // ... and bf16 c2 (the bias row)
-        sstat = lnf_stat + (lane_l & 15) * 8;      // row r of every m-tile
-    }
-    // LN fold: c1 (fp32) and c2 (bf16) of the lane's 4 columns are re-read from the tile's LDS rows for every (m-tile, n-tile), with a scheduling
-    // fence per n-tile.  Held in registers like the bias they are 8-16 more of them beside 128 accumulators (those builds spilled 40-84 bytes
-    // per lane); unfenced, the compiler hoists all the reads of an m-tile together (spills again); read one n-tile ahead (4 more registers) the
-    // build spills 16 bytes per tile and measured SLOWER than this form (profiles/r03_vit_stream170_lnfold*_kernel_stats.csv: fc1 784 vs 777 us); so did a
-    // fence per PAIR of n-tiles (two reads in flight, the same 16-byte spill: fc1 774 vs 766, qkv 563 vs 549 us).
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         uint32_t pk[2 * NH][2];
         if (!GLU) {
             // the packed bias is re-unpacked for every m-tile (opaque to CSE): unpacked once, it is 16 registers beside 128 accumulators
-            if (!LNF) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bp[j].x), "+v"(bp[j].y));
-            }
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bp[j].x), "+v"(bp[j].y));
             typedef float f32x2_t __attribute__((ext_vector_type(2)));
-            float rs = 1.f, tt = 0.f;
-            if (LNF) {                             // the row's (rstd, -mean * rstd), parked by the loader waves
-                const float2 st = *reinterpret_cast<const float2*>(sstat + (I0 + i) * 16 * 8);
-                rs = st.x; tt = st.y;
-            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 // two elements per VALU instruction where the ISA has packed fp32 (add / mul); exp2 and rcp stay one per element
-                f32x2_t x01, x23;
-                if (LNF) {
-                    const float4 cq = *reinterpret_cast<const float4*>(sc1 + j * 64);
-                    const uint2 bq = *reinterpret_cast<const uint2*>(sc2 + j * 32);
-                    const f32x2_t c01 = {cq.x, cq.y}, c23 = {cq.z, cq.w};
-                    const f32x2_t b01 = {bflo(bq.x), bfhi(bq.x)}, b23 = {bflo(bq.y), bfhi(bq.y)};
-                    // (plain fmas with the two row scalars: as packed operands they are four more registers, and this build is at the limit)
-                    x01 = f32x2_t{fmaf(acc[I0 + i][j][0], rs, fmaf(c01[0], tt, b01[0])), fmaf(acc[I0 + i][j][1], rs, fmaf(c01[1], tt, b01[1]))};
-                    x23 = f32x2_t{fmaf(acc[I0 + i][j][2], rs, fmaf(c23[0], tt, b23[0])), fmaf(acc[I0 + i][j][3], rs, fmaf(c23[1], tt, b23[1]))};
-                } else {
-                    const f32x2_t b01 = {bflo(bp[j].x), bfhi(bp[j].x)}, b23 = {bflo(bp[j].y), bfhi(bp[j].y)};
-                    x01 = f32x2_t{acc[I0 + i][j][0], acc[I0 + i][j][1]} + b01;
-                    x23 = f32x2_t{acc[I0 + i][j][2], acc[I0 + i][j][3]} + b23;
-                }
+                const f32x2_t b01 = {bflo(bp[j].x), bfhi(bp[j].x)}, b23 = {bflo(bp[j].y), bfhi(bp[j].y)};
+                f32x2_t x01 = f32x2_t{acc[I0 + i][j][0], acc[I0 + i][j][1]} + b01;
+                f32x2_t x23 = f32x2_t{acc[I0 + i][j][2], acc[I0 + i][j][3]} + b23;
                 if (EPI == EPI_QUICKGELU) {
                     const f32x2_t t01 = x01 * -2.4554669595930157f, t23 = x23 * -2.4554669595930157f;
                     const f32x2_t d01 = f32x2_t{__builtin_amdgcn_exp2f(t01[0]), __builtin_amdgcn_exp2f(t01[1])} + 1.f;
@@ -230,7 +186,6 @@ __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[TM][TN], uint2 (&bp
                 }
                 pk[j][0] = pack2bf(x01[0], x01[1]);
                 pk[j][1] = pack2bf(x23[0], x23[1]);
-                if (LNF) PERS_FENCE();             // the next n-tile's LDS reads stay behind this one's math (hoisted together they spill)
             }
         } else {
 #pragma unroll
@@ -357,9 +312,6 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
     const char* src[16];
     int li = sc.slot, n = 0, q = 0, ticket = 0;
     uint2 bias2 = make_uint2(0u, 0u);
-    constexpr bool LNF = (OPT & 16) != 0 && !GLU && EPI != EPI_RESIDUAL;     // LN fold: park the tile's row statistics and c1 row as well
-    float4 c1v = make_float4(0.f, 0.f, 0.f, 0.f);
-    float2 st2 = make_float2(1.f, 0.f);
     // L2 touches (OPT bit 3 switches them off for A/B runs).  With two LDS stages only ONE K-tile is ever in flight, so when an operand streams
     // from HBM (ViT fc2: an 803 MB A) a K-tile costs the load's latency, not its MFMA time — and even from the Infinity Cache the pieces land
     // late often enough to show.  One byte of every A line of K-tile kt + LEAD, requested LEAD - 1 hand-overs before its LDS-DMA pieces, turns
@@ -397,11 +349,6 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
                          : reinterpret_cast<const char*>(p.W) + ((size_t)(n0_ + row) * p.ldw + kc * 8) * 2;                            \
         }                                                                                                                              \
         if (!GLU && lw == 3 && p.bias) bias2 = *reinterpret_cast<const uint2*>(p.bias + n0_ + lane * 4);  /* else stays zero */       \
-        if (LNF) {                                                                                                                     \
-            const float* sp_ = p.stats + 2 * (size_t)min(m0_ + lw * 64 + lane, p.M - 1);                                                \
-            st2 = (p.opt & 32) ? *reinterpret_cast<const float2*>(sp_) : ld_agent_f2(sp_);  /* coherent across the XCDs' L2s: common.h */    \
-            if (lw == 2) c1v = *reinterpret_cast<const float4*>(p.c1 + n0_ + lane * 4);                                                \
-        }                                                                                                                              \
         if (toucher)                                                                                                                   \
             tsrc = reinterpret_cast<const char*>(p.A) + (size_t)min(m0_ + (tn_ & 3) * 64 + lane, p.M - 1) * p.lda * 2;                 \
     }
@@ -437,20 +384,12 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
             PERS_WAIT_PIECES();
             if (kt == 0 && !GLU && lw == 3)                         // this tile's bias row (zeros without a bias), read by the MFMA waves after the K loop
                 *reinterpret_cast<uint2*>(smem + BIAS_OFF + (n & 1) * 512 + lane * 8) = bias2;
-            if (LNF && kt == 0) {
-                *reinterpret_cast<float2*>(smem + STAT_OFF + (n & 1) * 2048 + (lw * 64 + lane) * 8) = st2;
-                if (lw == 2) *reinterpret_cast<float4*>(smem + C1_OFF + (n & 1) * 1024 + lane * 16) = c1v;
-            }
             if (kt == 1 && tid == NMT) {                            // the tile after this one: everyone reads it after this tile's last hand-over
                 s_next[(n + 1) & 1] = dynamic ? nwg + ticket : li + nwg;
                 // the launch's last ticket on this XCD re-arms the counter — with an agent-scope atomic, like the tickets themselves: every draw of the
                 // launch precedes it in the counter's modification order (the last draw returned cnt - 1), and it reaches memory the way the next
-                // launch's draws will.  Until round 3 this was a plain store: that one sits in whichever XCD's L2 the holder ran on until a
-                // write-back, while the draws are performed memory-side (dynamic == 3 keeps that form for the A/B stress run of DESIGN 5a).
-                if (dynamic && ticket == cnt - 1) {
-                    if (dynamic == 3) ctr[xcd * CTR_STRIDE] = 0;
-                    else (void)atomicExch(ctr + xcd * CTR_STRIDE, 0);
-                }
+                // launch's draws will
+                if (dynamic && ticket == cnt - 1) (void)atomicExch(ctr + xcd * CTR_STRIDE, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                           // K-tile q handed over; the stage of q-1 is free
@@ -558,16 +497,11 @@ __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, i
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
         const int g_e = lane_e >> 4;
         uint2 bp[TN];                                               // this lane's 4 x 4 bias values, packed (unpacked where they are used)
-        constexpr bool LNF = (OPT & 16) != 0 && !GLU && EPI != EPI_RESIDUAL;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             bp[j] = make_uint2(0u, 0u);
-            if (!GLU && !LNF) bp[j] = *reinterpret_cast<const uint2*>(smem + BIAS_OFF + (n & 1) * 512 + (wn * (BN / WN) + j * 16 + g_e * 4) * 2);
+            if (!GLU) bp[j] = *reinterpret_cast<const uint2*>(smem + BIAS_OFF + (n & 1) * 512 + (wn * (BN / WN) + j * 16 + g_e * 4) * 2);
         }
-        // LN fold: the lane's c1 group (4 values per n-tile, 32 bytes apart) and row pair (16 rows apart per m-tile) in the tile's LDS rows
-        const char* sc1 = smem + C1_OFF + (n & 1) * 1024 + (wn * (BN / WN)) * 4;                 // wave-uniform parts only: the lane's part is added where it is used
-        const char* sc2 = smem + BIAS_OFF + (n & 1) * 512 + (wn * (BN / WN)) * 2;
-        const char* sstat = smem + STAT_OFF + (n & 1) * 2048 + (wm * (BM / WM)) * 8;
         if (has_next) {                                             // K-tile 0 of the next tile: the loaders go on to its K-tile 1 during the epilogue
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -585,9 +519,9 @@ __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, i
             if (has_next) PERS_FRAGS(q);
             residual_store(out, rr, crs, coff, 32 * p.ldc);
         } else {
-            epilogue_rows<EPI, 0, TM / 2, LNF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sc2, sstat);
+            epilogue_rows<EPI, 0, TM / 2>(acc, bp, crs, coff, 32 * p.ldc, hi8);
             if (has_next) PERS_FRAGS(q);                            // 24 registers the first half of the epilogue has freed
-            epilogue_rows<EPI, TM / 2, TM / 2, LNF>(acc, bp, crs, coff, 32 * p.ldc, hi8, sc1, sc2, sstat);
+            epilogue_rows<EPI, TM / 2, TM / 2>(acc, bp, crs, coff, 32 * p.ldc, hi8);
         }
         if (!has_next) break;
         li = li_next;
@@ -633,20 +567,13 @@ CtrState* counters_for(hipStream_t s, int* ncu_out) {
 
 template <int EPI, int OPT>
 void launch_opt(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers_kernel<EPI, OPT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        done = true;
-    }
+    static LdsGrant grant;
+    (void)grant_dynamic_lds(grant, reinterpret_cast<const void*>(gemm_pers_kernel<EPI, OPT>), LDS_BYTES);       // a refusal shows as the launch error the caller checks
     hipLaunchKernelGGL((gemm_pers_kernel<EPI, OPT>), dim3(nblk), dim3(NTHR), LDS_BYTES, s, p, ctr, dynamic);
 }
 int g_opt = 0;
 template <int EPI>
 void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
-    if (p.stats) {                                  // LN fold (EPI_NONE / EPI_QUICKGELU: launch_gemm_pers checks)
-        if constexpr (EPI == EPI_NONE || EPI == EPI_QUICKGELU) launch_opt<EPI, 16>(p, nblk, dynamic, ctr, s);
-        return;
-    }
     switch (g_opt) {
         case 2: launch_opt<EPI, 2>(p, nblk, dynamic, ctr, s); break;
         case 4: launch_opt<EPI, 4>(p, nblk, dynamic, ctr, s); break;
@@ -659,8 +586,7 @@ void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
 
 int g_gemm_pers_opt = 0;           // A/B builds of the K loop (trace_op_set_gemm_variant(300 + opt))
 int g_gemm_pers_static = 0;        // 1: tiles dealt round-robin instead of by ticket (A/B runs)
-int g_gemm_pers_walk = 0;          // every route, the LayerNorm-fold launches included (trace_op_set_gemm_variant(500 + w)): 0 = tickets, atomic re-arm;
-                                   // 1 = static deal; 2 = tickets with round 3's plain-store re-arm (the stress tool's positive control)
+int g_gemm_pers_walk = 0;          // every route (trace_op_set_gemm_variant(500 + w)): 0 = tickets, atomic re-arm; 1 = static deal
 
 int g_gemm_pers_grid_cap = 0;      // tuning knob (trace_op_set_gemm_variant(1000 + n)); streams carry their own cap: gemm_pers_set_cap.  > 0: at most this many workgroups per launch (a stream confined to part of the CUs by a CU mask: the
                                    // persistent grid must not exceed the CUs it can run on, or the surplus workgroups wait for a second round)
@@ -672,8 +598,10 @@ int gemm_pers_init(hipStream_t s) { return counters_for(s, nullptr) ? TRACE_OK :
 // CU mask must not be handed more workgroups than it can run at once, or the surplus waits for a second round.  Lives with the stream's counters
 // (until round 3 this was one process-wide number that outlived the streams it was set for).
 int gemm_pers_set_cap(hipStream_t s, int cap) {
+    if (cap < 0) return TRACE_ERR_ARG;
     CtrState* st = counters_for(s, nullptr);
-    if (!st || cap < 0) return TRACE_ERR_HIP;
+    if (!st) return TRACE_ERR_HIP;
+    std::lock_guard<std::mutex> lk(g_ctr_mu);       // launch_gemm_pers reads it under the same lock (the pipeline's other thread may be launching)
     st->cap = cap;
     return TRACE_OK;
 }
@@ -697,21 +625,22 @@ void gemm_pers_release(int dev) {
 // TRACE_ERR_STATE: no ticket counters for this stream and none can be made now (capturing): the caller falls back to gemm_ldr
 int launch_gemm_pers(const GemmArgs& p0, int epi, hipStream_t s) {
     GemmArgs p = p0;
-    p.opt = g_ln_stats_plain ? 32 : 0;              // bit 5: round-3 plain loads of the fold's row statistics (A/B)
+    p.opt = 0;
     if (p.M < 1 || p.N % BN || p.K % BK || p.K < 2 * BK || p.fp8) return TRACE_ERR_ARG;
-    if (p.stats && (!p.c1 || !p.bias || (epi != EPI_NONE && epi != EPI_QUICKGELU))) return TRACE_ERR_ARG;      // LN fold: c1, c2 (= bias) and the row statistics
     if ((long)p.M * p.ldc >= (1L << 30) || (epi == EPI_RESIDUAL && (long)p.M * p.ldr >= (1L << 30))) return TRACE_ERR_ARG;   // 32-bit byte offsets
     int ncu = 0;
     CtrState* st = counters_for(s, &ncu);
     if (!st) return TRACE_ERR_STATE;
     int* ctr = st->ctr;
-    const int cap = st->cap > 0 ? st->cap : g_gemm_pers_grid_cap;      // the stream's own cap (CU-masked streams), else the process-wide tuning knob
+    int stream_cap;
+    { std::lock_guard<std::mutex> lk(g_ctr_mu); stream_cap = st->cap; }
+    const int cap = stream_cap > 0 ? stream_cap : g_gemm_pers_grid_cap;      // the stream's own cap (CU-masked streams), else the process-wide tuning knob
     if (cap > 0 && cap < ncu) ncu = cap < 8 ? 8 : cap;                 // every XCD keeps a workgroup: tiles are dealt per XCD
     const int total = ((p.M + BM - 1) / BM) * (p.N / BN);
     // g_gemm_pers_static == 2: one workgroup per tile (the dispatcher places them as CUs free up, nothing persists): this kernel's K loop and
     // register epilogue without the tile walk (A/B runs)
     const int nblk = g_gemm_pers_static == 2 ? total : (total < ncu ? total : ncu);
-    const int dynamic = (g_gemm_pers_static || g_gemm_pers_walk == 1) ? 0 : (g_gemm_pers_walk == 2 ? 3 : 1);
+    const int dynamic = (g_gemm_pers_static || g_gemm_pers_walk == 1) ? 0 : 1;
     g_opt = g_gemm_pers_opt;
     switch (epi) {
         case EPI_NONE: launch_one<EPI_NONE>(p, nblk, dynamic, ctr, s); break;

@@ -3,7 +3,33 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "common.h"
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: one process may hold contexts on several GPUs, so the grant is
+// tracked per device (a bit per device id), not once per process; safe from both launch threads of the pipeline (a double grant is idempotent).
+struct LdsGrant { std::atomic<uint32_t> devs{0}; };
+inline bool grant_dynamic_lds(LdsGrant& g, const void* fn, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return false;
+    const uint32_t bit = 1u << dev;
+    if (g.devs.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    g.devs.fetch_or(bit, std::memory_order_release);
+    return true;
+}
+
+// the same for kernels whose dynamic-LDS request varies per launch: the largest size granted so far, per device
+struct LdsGrantSized { std::atomic<size_t> bytes[32]; LdsGrantSized() { for (auto& b : bytes) b.store(0); } };
+inline bool grant_dynamic_lds(LdsGrantSized& g, const void* fn, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return false;
+    if (bytes <= g.bytes[dev].load(std::memory_order_acquire)) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    size_t cur = g.bytes[dev].load(std::memory_order_relaxed);
+    while (cur < bytes && !g.bytes[dev].compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+    return true;
+}
 
 constexpr int SK_ROWS = 256;     // largest decode batch = row stride of the fp32 k-chunk partial buffers [ks][SK_ROWS][N]
 constexpr int SKINNY_ROWS = 64;  // rows one skinny (activations-parked-in-LDS) GEMV takes; larger batches run the split-K MFMA GEMM (gemm.hip)
@@ -29,10 +55,6 @@ struct GemmArgs {
     // locality, as for the GEMV).  Bit 2: a 4-stage K-tile ring (three tiles in flight) instead of the double buffer.  (Bit 1 was a non-temporal
     // hint on the weight DMA: 11.58 vs 11.15 ms per 128-sequence step, profiles/r03_decode_gemm_ab_b128.txt — removed.)
     int w_tiled;
-    // LayerNorm fold (ViT, gemm_pers.hip / gemm_ldr.hip): consumer side — stats[m] = (rstd, -mean * rstd) of row m of A, c1[n] = sum_k W[n][k] (fp32),
-    // bias = c2: C = rstd (A . W^T) + (-mean rstd) c1 + c2 for W pre-multiplied by the LayerNorm weight; producer side (EPI_RESIDUAL, gemm_ldr) —
-    // stats_part[tn][m] = (sum, sum of squares) of the 256 columns of output row m that column tile tn holds
-    const float* stats; const float* c1; float* stats_part;
 };
 int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s);
 int gemm_partial_ks(int N, int K);                                // K-chunks launch_gemm_bf16(EPI_PARTIAL) should be given for an [<= 128, K] x [N, K]^T product
@@ -52,30 +74,15 @@ int launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t*
 int launch_rmsnorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w, int rows, int D, float eps,
                    hipStream_t s);
 
-// ---- LayerNorm fold (ViT): C = LN(A) W^T + b as one GEMM on the raw rows (GemmArgs::stats / c1 / stats_part; gemm_pers.hip, gemm_ldr.hip) ----
-// part [NT][M][2] (sum, sum of squares per 256-column tile, from the residual GEMM's epilogue) -> stats [M][2] = (rstd, -mean * rstd)
-extern int g_ln_stats_plain;                                       // norm.hip: 1 = plain (round-3) stores / loads of the fold's statistics instead of agent-scope atomics
-int launch_ln_stats_finalize(const float* part, int NT, int M, int D, float eps, float* stats, hipStream_t s);
-int launch_ln_row_stats(const bf16_t* x, int ldx, int M, int D, float eps, float* stats, hipStream_t s);      // the same from the rows themselves
-// Wf = bf16(W * gamma), c1 = row sums of Wf, c2 = W . beta + b   (at load)
-int launch_ln_fold_weights(const bf16_t* W, int ldw, const bf16_t* gamma, const bf16_t* beta, const bf16_t* b, bf16_t* Wf, float* c1, bf16_t* c2,
-                           int N, int K, hipStream_t s);
-// true: launch_gemm_bf16 would run this bias / activation GEMM on the persistent kernel (which has the fold epilogue) / this residual GEMM on
-// the loader-wave kernel (whose epilogue can emit the row statistics)
-bool gemm_routes_to_pers(int M, int N, int K);
-bool gemm_routes_to_ldr(int M, int N, int K);
-
 // ---- ViT front end (vit.hip) ----
 // frames [T,3,S,S] (bf16 or fp32) -> im2col patches A [T*G*G, Kpad] bf16 (k = c*P*P + py*P + px, zero padded)
 // ---- patch_embed.hip (round 4): the ViT front end as one kernel, reading the frame tensor directly ----
 bool patch_embed_supported(int S, int P, int D);                   // P in {14, 16}, D in {128, 256, 512, 1024}; other geometries keep the three-pass path below
 size_t patch_embed_packed_elems(int P, int D);                     // elements of the repacked conv weight
 int launch_patch_pack(const bf16_t* W, int ldw, bf16_t* wp, int D, int P, hipStream_t s);          // at load: [D][ldw] (k = c P P + ky P + j) -> fragment order, j padded to 16
-int launch_cls_row(const bf16_t* cls, const bf16_t* pos, const bf16_t* lw, const bf16_t* lb, bf16_t* out, float* st, int D, float eps, float eps_fold,
-                   hipStream_t s);                                 // at load: the CLS row every frame gets + its LayerNorm-fold statistics
+int launch_cls_row(const bf16_t* cls, const bf16_t* pos, const bf16_t* lw, const bf16_t* lb, bf16_t* out, int D, float eps, hipStream_t s);   // at load: the CLS row every frame gets
 int launch_patch_embed(const void* frames, int frames_fp32, const bf16_t* wp, const bf16_t* pos, const bf16_t* lw, const bf16_t* lb,
-                       const bf16_t* cls_row, const float* cls_stats, bf16_t* X, float* stats, int T, int S, int P, int D, float eps, float eps_fold,
-                       hipStream_t s);                             // frames -> X = pre_layrnorm(cat(CLS, conv) + pos) [T (G G + 1), D] (+ row statistics)
+                       const bf16_t* cls_row, bf16_t* X, int T, int S, int P, int D, float eps, hipStream_t s);   // frames -> X = pre_layrnorm(cat(CLS, conv) + pos) [T (G G + 1), D]
 int launch_im2col(const void* frames, int frames_fp32, bf16_t* A, int T, int S, int P, int Kpad, hipStream_t s);
 // X[t, 0] = cls + pos[0];  X[t, 1+p] = PE[t*GG + p] + pos[1+p]      (PE = patch-embed GEMM output)
 //   then X = LayerNorm(X) (pre_layrnorm), fused

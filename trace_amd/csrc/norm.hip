@@ -157,87 +157,6 @@ __global__ __launch_bounds__(256) void norm1024_kernel(const bf16_t* __restrict_
 }
 }  // namespace
 
-// ---- LayerNorm fold (ViT): statistics and weight preparation ------------------------------------------------------------------------
-// part [NT][M][2] = per-column-tile (sum, sum of squares) left by the residual GEMM's epilogue -> stats [M][2] = (rstd, -mean * rstd)
-__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, int NT, int M, int D, float eps, float* __restrict__ stats, int plain) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int t = 0; t < NT; ++t) {                 // fixed order
-        const float* src = part + ((size_t)t * M + m) * 2;
-        const float2 q = plain ? *reinterpret_cast<const float2*>(src) : ld_agent_f2(src);
-        s1 += q.x; s2 += q.y;
-    }
-    const float mean = s1 / (float)D;
-    const float var = fmaxf(s2 / (float)D - mean * mean, 0.f);
-    const float rstd = rsqrtf(var + eps);
-    if (plain) *reinterpret_cast<float2*>(stats + (size_t)m * 2) = make_float2(rstd, -mean * rstd);
-    else st_agent_f2(stats + (size_t)m * 2, rstd, -mean * rstd);
-}
-// the same statistics straight from rows x [M][D] (the first layer's input, which no GEMM epilogue produced): one wave per row
-__global__ __launch_bounds__(256) void ln_row_stats_kernel(const bf16_t* __restrict__ x, int ldx, int M, int D, float eps, float* __restrict__ stats, int plain) {
-    const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int c = lane; c < (D >> 3); c += 64) {
-        const uint4 u4 = *reinterpret_cast<const uint4*>(x + (size_t)m * ldx + c * 8);
-        const uint32_t u[4] = {u4.x, u4.y, u4.z, u4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float a = bflo(u[e]), b = bfhi(u[e]);
-            s1 += a + b;
-            s2 = fmaf(a, a, fmaf(b, b, s2));
-        }
-    }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == 0) {
-        const float mean = s1 / (float)D;
-        const float rstd = rsqrtf(fmaxf(s2 / (float)D - mean * mean, 0.f) + eps);
-        if (plain) *reinterpret_cast<float2*>(stats + (size_t)m * 2) = make_float2(rstd, -mean * rstd);
-        else st_agent_f2(stats + (size_t)m * 2, rstd, -mean * rstd);
-    }
-}
-// W [N][K], LayerNorm weight / bias gamma, beta [K], linear bias b [N] ->  Wf = bf16(W * gamma) [N][K],  c1[n] = sum_k Wf[n][k] in fp32 (of the
-// ROUNDED products: it has to cancel what the GEMM accumulates for a constant row),  c2[n] = bf16(sum_k beta[k] W[n][k] + b[n]).  One workgroup per row.
-__global__ __launch_bounds__(256) void ln_fold_weights_kernel(const bf16_t* __restrict__ W, int ldw, const bf16_t* __restrict__ gamma,
-                                                              const bf16_t* __restrict__ beta, const bf16_t* __restrict__ b, bf16_t* __restrict__ Wf,
-                                                              float* __restrict__ c1, bf16_t* __restrict__ c2, int K) {
-    __shared__ float r1[4], r2[4];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    float s1 = 0.f, s2 = 0.f;
-    for (int k = tid; k < K; k += 256) {
-        const float w = bf2f(W[(size_t)n * ldw + k]);
-        const bf16_t wf = f2bf(w * bf2f(gamma[k]));
-        Wf[(size_t)n * ldw + k] = wf;
-        s1 += bf2f(wf);
-        s2 = fmaf(bf2f(beta[k]), w, s2);
-    }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if ((tid & 63) == 0) { r1[tid >> 6] = s1; r2[tid >> 6] = s2; }
-    __syncthreads();
-    if (tid == 0) {
-        c1[n] = r1[0] + r1[1] + r1[2] + r1[3];
-        c2[n] = f2bf(r2[0] + r2[1] + r2[2] + r2[3] + (b ? bf2f(b[n]) : 0.f));
-    }
-}
-int g_ln_stats_plain = 0;      // 1: the LayerNorm-fold statistics move with plain stores / loads as in round 3 (the stress tool's positive control: trace_op_set_gemm_variant(510 + x))
-int launch_ln_stats_finalize(const float* part, int NT, int M, int D, float eps, float* stats, hipStream_t s) {
-    if (NT < 1 || M < 1 || D < 1) return TRACE_ERR_ARG;
-    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, part, NT, M, D, eps, stats, g_ln_stats_plain);
-    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
-}
-int launch_ln_row_stats(const bf16_t* x, int ldx, int M, int D, float eps, float* stats, hipStream_t s) {
-    if (M < 1 || D % 8 || (ldx % 8)) return TRACE_ERR_ARG;
-    hipLaunchKernelGGL(ln_row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, M, D, eps, stats, g_ln_stats_plain);
-    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
-}
-int launch_ln_fold_weights(const bf16_t* W, int ldw, const bf16_t* gamma, const bf16_t* beta, const bf16_t* b, bf16_t* Wf, float* c1, bf16_t* c2,
-                           int N, int K, hipStream_t s) {
-    if (N < 1 || K < 1) return TRACE_ERR_ARG;
-    hipLaunchKernelGGL(ln_fold_weights_kernel, dim3(N), dim3(256), 0, s, W, ldw, gamma, beta, b, Wf, c1, c2, K);
-    return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
-}
-
 int launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w, const bf16_t* b, int rows, int D,
                      float eps, hipStream_t s, int silu) {
     if (D % 8 || D > MAXCH * 512 || (ldx % 8) || (ldy % 8) || rows <= 0) return TRACE_ERR_ARG;

@@ -1,5 +1,5 @@
 // CLIP ViT front end as ONE kernel: the stride-P patch convolution as an MFMA GEMM that reads the frame tensor directly — no im2col
-// matrix — with the CLS / position-embedding assembly, `pre_layrnorm` and the first layer's LayerNorm-fold row statistics in its epilogue.
+// matrix — with the CLS / position-embedding assembly and `pre_layrnorm` in its epilogue.
 // Reference: HF CLIPVisionEmbeddings (Conv2d 3 -> D, k = s = P, no bias; cat CLS; + position_embedding) and CLIPVisionTransformer.pre_layrnorm
 // (transformers modeling_clip.py:148-154,208-217,641-642), reached from trace/model/multimodal_encoder/clip_encoder.py:50.
 //
@@ -15,8 +15,7 @@
 //     double-buffered, one barrier per k-step; the weight fragments stream from L2 with a one-step register prefetch.
 //   * epilogue, the round-3 arithmetic with the same rounding points: pe = bf16(acc); e = bf16(pe + pos[j]); two-pass LayerNorm in fp32 over the
 //     D channels of a row (row sums: lane -> 4 lanes of a row by DPP-free xor shuffles -> 8 waves through LDS, fixed order); y = bf16(LN(e));
-//     then (sum y, sum y^2) of the ROUNDED row -> (rstd, -mean rstd) for the first layer's folded LayerNorm; rows staged per wave in LDS and
-//     stored as 256-byte row segments.  The CLS row (identical for every frame) is made once at load and copied by the frame's first workgroup.
+//     rows staged per wave in LDS and stored as 256-byte row segments.  The CLS row (identical for every frame) is made once at load and copied by the frame's first workgroup.
 #include "common.h"
 #include "kernels.h"
 
@@ -46,8 +45,7 @@ __device__ __forceinline__ uint4 load8(const TIN* base, size_t off) {
 template <typename TIN, int NTW>
 __global__ __launch_bounds__(512) void patch_embed_kernel(const TIN* __restrict__ frames, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ pos,
                                                           const bf16_t* __restrict__ lw, const bf16_t* __restrict__ lb, const bf16_t* __restrict__ cls_row,
-                                                          const float* __restrict__ cls_stats, bf16_t* __restrict__ X, float* __restrict__ stats,
-                                                          int S, int P, int G, int D, float eps, float eps_fold) {
+                                                          bf16_t* __restrict__ X, int S, int P, int G, int D, float eps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* xs = reinterpret_cast<uint4*>(smem);                                   // [2][PE_MT * 64] X fragments of a k-step
     float* red = reinterpret_cast<float*>(smem + 2 * PE_MT * 1024);               // [PE_WAVES][64] row partials
@@ -167,11 +165,8 @@ __global__ __launch_bounds__(512) void patch_embed_kernel(const TIN* __restrict_
             for (int e = 0; e < 4; ++e) { const float d = acc[i][j][e] - mean[i]; q[i] = fmaf(d, d, q[i]); }
     }
     row_sum(q);
-    // y = bf16((e - mean) * rstd * gamma + beta), staged in LDS; (sum y, sum y^2) of the rounded row for the first layer's LayerNorm fold
+    // y = bf16((e - mean) * rstd * gamma + beta), staged in LDS
     unsigned char* st = stage + (size_t)wid * 64 * PE_PITCH;
-    float t1[PE_MT], t2[PE_MT];
-#pragma unroll
-    for (int i = 0; i < PE_MT; ++i) { t1[i] = 0.f; t2[i] = 0.f; }
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         const uint2 gw = *reinterpret_cast<const uint2*>(lw + nbase + j * 16), gb = *reinterpret_cast<const uint2*>(lb + nbase + j * 16);
@@ -184,24 +179,6 @@ __global__ __launch_bounds__(512) void patch_embed_kernel(const TIN* __restrict_
             for (int e = 0; e < 4; ++e) y[e] = (acc[i][j][e] - mean[i]) * rstd * w4[e] + b4[e];
             const uint2 o = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
             *reinterpret_cast<uint2*>(st + (i * 16 + r) * PE_PITCH + (j * 16 + 4 * g) * 2) = o;
-            const float z[4] = {bflo(o.x), bfhi(o.x), bflo(o.y), bfhi(o.y)};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { t1[i] += z[e]; t2[i] = fmaf(z[e], z[e], t2[i]); }
-        }
-    }
-    if (stats) {                                            // workgroup-uniform
-        row_sum(t1);
-        row_sum(t2);
-        if (wid == 0 && g == 0) {
-#pragma unroll
-            for (int i = 0; i < PE_MT; ++i) {
-                const int patch = m0 + i * 16 + r;
-                if (patch < GG) {
-                    const float mu = t1[i] / (float)D;
-                    const float rs = rsqrtf(fmaxf(t2[i] / (float)D - mu * mu, 0.f) + eps_fold);
-                    st_agent_f2(stats + 2 * ((size_t)t * NT + 1 + patch), rs, -mu * rs);
-                }
-            }
         }
     }
     __syncthreads();                                        // the staged rows of every wave are complete (and `red` reads are done)
@@ -217,11 +194,10 @@ __global__ __launch_bounds__(512) void patch_embed_kernel(const TIN* __restrict_
             *reinterpret_cast<uint4*>(X + ((size_t)t * NT + 1 + patch) * D + wid * NTW * 16 + piece * 8) = v;
         }
     }
-    // the frame's CLS row (made once at load: LN(bf16(cls + pos[0])) and its fold statistics)
+    // the frame's CLS row (made once at load: LN(bf16(cls + pos[0])))
     if (m0 == 0) {
         for (int c = tid; c < (D >> 3); c += 512)
             *reinterpret_cast<uint4*>(X + (size_t)t * NT * D + c * 8) = *reinterpret_cast<const uint4*>(cls_row + c * 8);
-        if (stats && tid == 0) st_agent_f2(stats + 2 * (size_t)t * NT, cls_stats[0], cls_stats[1]);
     }
 }
 
@@ -251,10 +227,9 @@ __global__ __launch_bounds__(256) void patch_pack_kernel(const bf16_t* __restric
     }
 }
 
-// cls_row = bf16(LN(bf16(cls + pos[0]))) (two-pass, fp32) and its (rstd, -mean rstd) under eps_fold.  One workgroup of 256 threads, D <= 1024.
+// cls_row = bf16(LN(bf16(cls + pos[0]))) (two-pass, fp32).  One workgroup of 256 threads, D <= 1024.
 __global__ __launch_bounds__(256) void cls_row_kernel(const bf16_t* __restrict__ cls, const bf16_t* __restrict__ pos, const bf16_t* __restrict__ lw,
-                                                      const bf16_t* __restrict__ lb, bf16_t* __restrict__ out, float* __restrict__ st, int D, float eps,
-                                                      float eps_fold) {
+                                                      const bf16_t* __restrict__ lb, bf16_t* __restrict__ out, int D, float eps) {
     __shared__ float s_red[4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     auto block_sum = [&](float v) {
@@ -277,39 +252,22 @@ __global__ __launch_bounds__(256) void cls_row_kernel(const bf16_t* __restrict__
 #pragma unroll
     for (int i = 0; i < 4; ++i) if (tid + i * 256 < D) { const float d = e[i] - mean; q += d * d; }
     const float rstd = rsqrtf(block_sum(q) / (float)D + eps);
-    float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = tid + i * 256;
-        if (c < D) {
-            const bf16_t y = f2bf((e[i] - mean) * rstd * bf2f(lw[c]) + bf2f(lb[c]));
-            out[c] = y;
-            t1 += bf2f(y);
-            t2 = fmaf(bf2f(y), bf2f(y), t2);
-        }
-    }
-    t1 = block_sum(t1);
-    t2 = block_sum(t2);
-    if (tid == 0) {
-        const float mu = t1 / (float)D;
-        const float rs = rsqrtf(fmaxf(t2 / (float)D - mu * mu, 0.f) + eps_fold);
-        st[0] = rs; st[1] = -mu * rs;
+        if (c < D) out[c] = f2bf((e[i] - mean) * rstd * bf2f(lw[c]) + bf2f(lb[c]));
     }
 }
 
 template <typename TIN, int NTW>
-int launch_pe(const void* frames, const bf16_t* wp, const bf16_t* pos, const bf16_t* lw, const bf16_t* lb, const bf16_t* cls_row, const float* cls_stats,
-              bf16_t* X, float* stats, int T, int S, int P, int G, int D, float eps, float eps_fold, hipStream_t s) {
+int launch_pe(const void* frames, const bf16_t* wp, const bf16_t* pos, const bf16_t* lw, const bf16_t* lb, const bf16_t* cls_row,
+              bf16_t* X, int T, int S, int P, int G, int D, float eps, hipStream_t s) {
     constexpr int LDS = 2 * PE_MT * 1024 + PE_WAVES * 64 * 4 + PE_WAVES * 64 * PE_PITCH;
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(patch_embed_kernel<TIN, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return TRACE_ERR_HIP;
-        done = true;
-    }
+    static LdsGrant grant;
+    if (!grant_dynamic_lds(grant, reinterpret_cast<const void*>(patch_embed_kernel<TIN, NTW>), LDS)) return TRACE_ERR_HIP;
     const int grid = T * ((G * G + 63) / 64);
-    hipLaunchKernelGGL((patch_embed_kernel<TIN, NTW>), dim3(grid), dim3(512), LDS, s, (const TIN*)frames, wp, pos, lw, lb, cls_row, cls_stats, X, stats, S, P,
-                       G, D, eps, eps_fold);
+    hipLaunchKernelGGL((patch_embed_kernel<TIN, NTW>), dim3(grid), dim3(512), LDS, s, (const TIN*)frames, wp, pos, lw, lb, cls_row, X, S, P,
+                       G, D, eps);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 
@@ -325,23 +283,20 @@ int launch_patch_pack(const bf16_t* W, int ldw, bf16_t* wp, int D, int P, hipStr
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 
-int launch_cls_row(const bf16_t* cls, const bf16_t* pos, const bf16_t* lw, const bf16_t* lb, bf16_t* out, float* st, int D, float eps, float eps_fold,
-                   hipStream_t s) {
+int launch_cls_row(const bf16_t* cls, const bf16_t* pos, const bf16_t* lw, const bf16_t* lb, bf16_t* out, int D, float eps, hipStream_t s) {
     if (D < 8 || D > 1024) return TRACE_ERR_ARG;
-    hipLaunchKernelGGL(cls_row_kernel, dim3(1), dim3(256), 0, s, cls, pos, lw, lb, out, st, D, eps, eps_fold);
+    hipLaunchKernelGGL(cls_row_kernel, dim3(1), dim3(256), 0, s, cls, pos, lw, lb, out, D, eps);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 
-// frames [T, 3, S, S] (16-bit elements, or fp32 when frames_fp32) -> X [T, G G + 1, D] = pre_layrnorm(cat(CLS, conv(frames)) + pos); stats (optional)
-// [T (G G + 1)][2] = (rstd, -mean rstd) of every row of X under eps_fold (the first layer's folded LayerNorm; == eps for CLIP)
+// frames [T, 3, S, S] (16-bit elements, or fp32 when frames_fp32) -> X [T, G G + 1, D] = pre_layrnorm(cat(CLS, conv(frames)) + pos)
 int launch_patch_embed(const void* frames, int frames_fp32, const bf16_t* wp, const bf16_t* pos, const bf16_t* lw, const bf16_t* lb,
-                       const bf16_t* cls_row, const float* cls_stats, bf16_t* X, float* stats, int T, int S, int P, int D, float eps, float eps_fold,
-                       hipStream_t s) {
+                       const bf16_t* cls_row, bf16_t* X, int T, int S, int P, int D, float eps, hipStream_t s) {
     if (T < 1 || !patch_embed_supported(S, P, D)) return TRACE_ERR_ARG;
     const int G = S / P;
 #define PE_GO(NTW_)                                                                                                                                  \
-    return frames_fp32 ? launch_pe<float, NTW_>(frames, wp, pos, lw, lb, cls_row, cls_stats, X, stats, T, S, P, G, D, eps, eps_fold, s)              \
-                       : launch_pe<bf16_t, NTW_>(frames, wp, pos, lw, lb, cls_row, cls_stats, X, stats, T, S, P, G, D, eps, eps_fold, s)
+    return frames_fp32 ? launch_pe<float, NTW_>(frames, wp, pos, lw, lb, cls_row, X, T, S, P, G, D, eps, s)                                          \
+                       : launch_pe<bf16_t, NTW_>(frames, wp, pos, lw, lb, cls_row, X, T, S, P, G, D, eps, s)
     switch (D / 128) {
         case 1: PE_GO(1);
         case 2: PE_GO(2);

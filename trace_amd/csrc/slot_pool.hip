@@ -238,11 +238,8 @@ int launch_slot_pool(const bf16_t* feats, long frame_stride, int row_stride, con
     const int RP = (n + NPART - 1) / NPART;
     const size_t lds = (size_t)RP * NS * 4 + (size_t)((RP + 1) & ~1) * 8 + 64 + (size_t)NS * D * 4;
     if (lds > 160 * 1024) return TRACE_ERR_ARG;
-    static size_t set_for = 0;
-    if (lds > set_for) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(slot_pool_part_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        set_for = lds;
-    }
+    static LdsGrantSized grant;
+    if (!grant_dynamic_lds(grant, reinterpret_cast<const void*>(slot_pool_part_kernel), lds)) return TRACE_ERR_HIP;
     float* pm = ws;
     float* pl = pm + (size_t)T * NPART * NS;
     float* pres = pl + (size_t)T * NPART * NS;

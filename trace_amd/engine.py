@@ -529,27 +529,6 @@ class ops:
         return Cc
 
     @staticmethod
-    def gemm_lnfold(X, W, gamma, beta, bias, eps, epilogue=EPI_NONE):
-        """act(LayerNorm(X) . W^T + bias) as one GEMM on the raw rows (the ViT's LayerNorm fold)"""
-        lib = _lib.load(ops.element)
-        M, K = X.shape
-        N = W.shape[0]
-        Cc = torch.empty((M, N), dtype=ops.dtype(), device=X.device)
-        _lib.check(lib.trace_op_gemm_lnfold(_ptr(X), _ptr(W), _ptr(gamma), _ptr(beta), _ptr(bias), _ptr(Cc), M, N, K, eps, epilogue, _stream()))
-        return Cc
-
-    @staticmethod
-    def gemm_residual_stats(A, W, bias, R, eps):
-        """(A . W^T + bias + R, row statistics [M, 2] = (rstd, -mean * rstd) of that result) — the fold's producer epilogue + finalize kernel"""
-        lib = _lib.load(ops.element)
-        M, K = A.shape
-        N = W.shape[0]
-        Cc = torch.empty((M, N), dtype=ops.dtype(), device=A.device)
-        st = torch.empty((M, 2), dtype=torch.float32, device=A.device)
-        _lib.check(lib.trace_op_gemm_residual_stats(_ptr(A), _ptr(W), _ptr(bias), _ptr(R), _ptr(Cc), _ptr(st), M, N, K, eps, _stream()))
-        return Cc, st
-
-    @staticmethod
     def layernorm(x, w, b, eps):
         lib = _lib.load(ops.element)
         y = torch.empty_like(x)

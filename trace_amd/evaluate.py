@@ -101,8 +101,8 @@ def evaluate_videos(model, tokenizer, processor, items: Sequence[dict], prompt: 
     eng = model.engine
     # videos decoded together: the decode batch limit (128; 64 on the fp8 path).  When the engine holds two such banks of KV slots (max_batch >= 2 bs)
     # the chunks go through the two-stage pipeline: chunk k decodes on one stream while chunk k+1 is preprocessed, encoded and prefilled on another
-    # (the default since round 4; `pipeline=False`: chunk by chunk.  Bit-identical to the chunk-by-chunk loop in every test.  Round 3 kept it opt-in
-    # because a rare wrong ViT row panel showed up under it; that needs the ViT's LayerNorm fold, which is off by default now — DESIGN 5a)
+    # (the default since round 4; `pipeline=False`: chunk by chunk.  Bit-identical to the chunk-by-chunk loop in every test.  The rare wrong ViT row
+    # panel of round 3 needed the ViT's LayerNorm fold, which was never root-caused and left the product in round 5 — DESIGN.md)
     bs = max(1, min(batch_size or eng.decode_batch_max, eng.decode_batch_max, eng.max_batch))
     pipelined = pipeline and eng.max_batch >= 2 * bs
     nf = num_frames or getattr(model.config, "num_frames", 128)

@@ -1418,6 +1418,7 @@ extern int g_skinny_debug;
 extern int g_gemm_pers_opt;
 extern int g_gemm_ldr_opt;
 extern int g_gemm_pers_walk;
+extern int g_gemm_resid_pers;
 extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 1000 && variant <= 1000 + 1024) { g_gemm_pers_grid_cap = variant - 1000; return TRACE_OK; }   // persistent GEMM: at most n workgroups (0 = #CUs)
     if (variant >= 100 && variant < 104) { g_attn_debug = variant - 100; return TRACE_OK; }
@@ -1431,7 +1432,8 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
     if (variant >= 500 && variant <= 501) { g_gemm_pers_walk = variant - 500; return TRACE_OK; }   // the persistent GEMM's tile walk on every route (gemm_pers.hip)
-    if (variant >= 400 && variant < 404) { g_gemm_ldr_opt = variant - 400; return TRACE_OK; }   // microbench: attention phase cut-offs
+    if (variant >= 520 && variant <= 521) { g_gemm_resid_pers = variant - 520; return TRACE_OK; }   // residual GEMMs on the persistent kernel too (auto routing)
+    if (variant >= 400 && variant < 404) { g_gemm_ldr_opt = variant - 400; return TRACE_OK; }   // gemm_ldr A/B: bit 0 = no residual touches, bit 1 = no A-panel touches
     if (variant < 0 || variant > 7) return fail(TRACE_ERR_ARG, "variant must be 0..7");
     g_gemm_variant = variant;
     return TRACE_OK;

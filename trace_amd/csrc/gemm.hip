@@ -371,6 +371,7 @@ int launch_glds(const GemmArgs& p, int epi, hipStream_t s) {
 int g_gemm_variant = 0;   // 0 = auto, 2 = 128^2 tiles, 3 = this file's 256^2 kernel, 4 = the loader-wave 256^2 kernel, 5 / 6 = the persistent one
                           // (gemm_pers.hip; 6 = static tile deal) — tests / microbench
 extern int g_gemm_pers_static;
+int g_gemm_resid_pers = 0;   // 1: residual shapes also run on the persistent kernel in auto mode (trace_op_set_gemm_variant(520 + x); A/B runs)
 
 // split-K partial-row GEMM for decode batches above SKINNY_ROWS: M <= 128 rows (one row panel), 128x128 tiles, ks chunks of K
 template <int EPI, bool WT, int NSTAGE>
@@ -435,7 +436,7 @@ int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
             return launch_gemm_pers(p, epi, s);
         }
         if (p.N % 256 == 0 && (g_gemm_variant == 4 || (g_gemm_variant == 0 && v == 3))) {
-            if (g_gemm_variant == 0 && pers_ok && epi != EPI_RESIDUAL) {
+            if (g_gemm_variant == 0 && pers_ok && (epi != EPI_RESIDUAL || g_gemm_resid_pers)) {
                 g_gemm_pers_static = 0;
                 const int rc = launch_gemm_pers(p, epi, s);
                 // no ticket counters for this stream and none can be made inside a capture: the one-workgroup-per-tile kernel gives the same bits

@@ -211,14 +211,54 @@ def test_attention_vit_rowmajor_v_equals_transposed_v():
     """Round 3: the LDS-DMA ViT attention reads V row-major (ds_read_b64_tr_b16) instead of a transposed, permuted copy: the same values
     in the same MFMA k-slots, so the two paths agree bit for bit (trace_op_set_gemm_variant(116) = the transposed-V path)."""
     q, k, v = rnd(3, 577, 16, 64, seed=4), rnd(3, 577, 16, 64, seed=5), rnd(3, 577, 16, 64, seed=6)
-    a = ops.attention(q, k, v, False, 0.125)
     try:
+        ops.set_gemm_variant(190)                  # the 4 x 32-row kernel (577 tokens go to the 192-row kernel since round 5)
+        a = ops.attention(q, k, v, False, 0.125)
         ops.set_gemm_variant(116)
         b = ops.attention(q, k, v, False, 0.125)
     finally:
         ops.set_gemm_variant(110)
+        ops.set_gemm_variant(191)
     assert torch.equal(a, b)
     check("attn vit 577 keys", a, _attn_ref(q, k, v, False, 0.125), 2e-2, 2e-2)
+
+
+@pytest.mark.parametrize("Bn,n,heads", [(3, 577, 16), (2, 193, 3), (1, 384, 5), (1, 769, 2), (5, 196, 1), (7, 577, 1)])
+@pytest.mark.parametrize("ring", [191, 192])
+def test_attention_vit_192_row_kernel(Bn, n, heads, ring):
+    """Round 5: the 192-row ViT attention (16x16x32 MFMA, three query tiles per wave, row sums on the matrix pipe, the rows 192 does not divide on
+    a VALU path) against torch and against the 4 x 32-row kernel: whole workgroups only (384), one leftover row (193, 577, 769), four (196), no
+    key tail (384) and a key tail (the others), head counts that leave the last quad of (frame, head) pairs partly empty; both ring depths."""
+    q, k, v = rnd(Bn, n, heads, 64, seed=11), rnd(Bn, n, heads, 64, seed=12), rnd(Bn, n, heads, 64, seed=13)
+    ref = _attn_ref(q, k, v, False, 0.125)
+    try:
+        ops.set_gemm_variant(ring)
+        got = ops.attention(q, k, v, False, 0.125)
+        again = ops.attention(q, k, v, False, 0.125)
+        ops.set_gemm_variant(190)
+        old = ops.attention(q, k, v, False, 0.125)
+    finally:
+        ops.set_gemm_variant(191)
+    assert torch.equal(got, again)
+    check("attn vit 192-row", got, ref, 2e-2, 2e-2)
+    check("attn vit 192-row vs 32-row kernel", got, old, 2e-2, 2e-2)
+
+
+def test_attention_vit_192_row_kernel_moves_its_reference():
+    """Keys that beat everything before them by far more than the lazy-rescale threshold (2^8), in the first tile, in the middle, in the last
+    tile and as the tail key, for rows of different waves and query tiles — and a row whose scores only fall: the slow path must rescale exactly
+    the rows that need it, once."""
+    Bn, n, heads = 2, 577, 2
+    q, k, v = rnd(Bn, n, heads, 64, seed=21), rnd(Bn, n, heads, 64, seed=22), rnd(Bn, n, heads, 64, seed=23)
+    for key, row, gain in ((3, 5, 5.0), (70, 50, 6.0), (150, 200, 4.0), (300, 17, 8.0), (500, 383, 5.0), (575, 100, 7.0), (576, 576, 6.0), (576, 20, 9.0), (64, 191, 6.0)):
+        k[:, key] = q[:, row] * gain
+    k[:, 0] = q[:, 300] * 8.0                       # row 300: its largest score is the very first key
+    try:
+        ops.set_gemm_variant(191)
+        got = ops.attention(q, k, v, False, 0.125)
+    finally:
+        ops.set_gemm_variant(191)
+    check("attn vit 192-row spikes", got, _attn_ref(q, k, v, False, 0.125), 3e-2, 2e-2)
 
 
 def test_attention_vit_spiked_scores():

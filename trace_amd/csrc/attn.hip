@@ -529,6 +529,377 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+// =====================================================================================================================
+// ViT attention, round 5: 192 query rows per workgroup on the 16x16x32 MFMA ("big" kernel).
+// What the 4 x 32-row kernel above leaves on the table at 577 tokens (rocprofv3, 170 frames x 16 heads: 381 us = 0.24 of the MFMA peak):
+//   * 577 = 18 x 32 + 1: the 19th query tile computes 32 rows for ONE, and 19 tiles fill 5 workgroups of 4 waves: 20 wave slots for 18.03 tiles
+//     of work (10 %);
+//   * every workgroup streams its head's whole K / V (148 KB) from L2 for 128 query rows — 2.0 GB per launch, and the staging alone costs
+//     ~250 us of a launch (knock-out runs, profiles/r02_attn_vit_probe.txt);
+//   * every K / V fragment read from LDS feeds ONE MFMA; the VALU is the busier pipe (62 % vs 33 % of the SIMD cycles, r02_attn_vit_pmc.txt).
+// Here a wave owns 48 query rows = three 16-row tiles of the 16x16x32 MFMA, a workgroup 4 x 48 = 192 rows, and 576 = 3 x 192: three whole
+// workgroups per (frame, head), no padded rows, K / V streamed 3 times instead of 5 (1.2 GB), every LDS fragment read feeds three MFMAs, and
+// two waves per SIMD (192 registers) with three independent softmax streams each.  Layout, per 64-key tile (both matmuls "swapped", as above):
+//   S^T[kv 16][q 16] = K . Q^T   A = K fragment (lane (r, g): key r, d = ks 32 + 8 g ..: one swizzled ds_read_b128), B = Q fragment (registers);
+//                                the accumulator starts at -m (the softmax reference), so the result IS the exp2 argument; lane (q, g) holds
+//                                the scores of query q against keys 4 g .. 4 g + 3 of the 16-key tile;
+//   O^T[d 16][q 16] += V^T . P   B = P: the k-slots (g, 0..3 | 4..7) of lane (q, g) are its own scores of key tiles 2 kp and 2 kp + 1 — P never
+//                                leaves the lane; A = V^T fragment with the matching key order: two ds_read_b64_tr_b16 of the row-major V image
+//                                (a 16-lane group fetches keys 4 g .. + 3 x 16 d and lane r receives column r).  The V image has 64-byte rows
+//                                [d-half][key][32 d] whose two 32-byte halves are swapped for odd (key >> 2) — on the DMA's SOURCE address — so
+//                                that the 32 lanes served together (g = 0, 1: 8 keys x 32 bytes) touch every bank once;
+//   l[q]            += 1 . P     the row sums ride on the matrix pipe too: A = a constant fragment of ones (no LDS read, 6 of 54 MFMAs per tile)
+//                                instead of 48 VALU adds per lane and tile — the sums are then the sums of the ROUNDED p, i.e. exactly the
+//                                weights O was accumulated with.
+// The softmax reference moves lazily (THR = 8: p <= 256), decided per query row but only inside a wave-uniform slow path (the common tile costs a
+// local max + one compare per query tile).  The query rows that 192 does not divide (row 576 of the ViT) go to one extra workgroup per four
+// (frame, head) pairs, one wave per pair, on the VALU (a 577-key GEMV: ~2 us per wave, hidden among the MFMA workgroups that read the same K / V).
+constexpr int BSTAGE = 16384;
+constexpr int BIG_ROWS = 192, BIG_QW = 48, BIG_MAXKV = 1024, BIG_MAXLEFT = 4;
+constexpr float BIG_THR = 8.f;
+
+__device__ __forceinline__ void mfma16_from(f32x4_t& d, const bf16x8_t& a, const bf16x8_t& b, const f32x4_t& c) {
+    // D != C: the builtin ties the result to its accumulator operand (a copy of the -m vector per score tile); early-clobber: D overlaps no source
+    // (the s_nop covers the VALU-write -> MFMA-read wait states hipcc does not pad inside asm, as in attn_vit_dma_kernel)
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_" TRACE_EL " %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+}
+
+// v_max3_f32 as it is: fmaxf() makes the compiler quiet possible signalling NaNs first (one v_max_f32 x, x, x per MFMA result: 60 instructions per
+// key tile for 48 comparisons); a NaN score is a NaN output either way
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// the maximum of the 16 scores a lane holds for one query tile: ONE asm block (between separate asm statements hipcc pads an s_nop each)
+__device__ __forceinline__ float max16_raw(const f32x4_t& a, const f32x4_t& b, const f32x4_t& c, const f32x4_t& d) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3\n\t"
+        "v_max3_f32 %0, %0, %4, %5\n\t"
+        "v_max3_f32 %0, %0, %6, %7\n\t"
+        "v_max3_f32 %0, %0, %8, %9\n\t"
+        "v_max3_f32 %0, %0, %10, %11\n\t"
+        "v_max3_f32 %0, %0, %12, %13\n\t"
+        "v_max3_f32 %0, %0, %14, %15\n\t"
+        "v_max_f32 %0, %0, %16"
+        : "=&v"(r)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]),
+          "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]));
+    return r;
+}
+// LDS transpose reads as inline asm.  Through the builtin, hipcc's wait-count pass cannot tell the read from the LDS-DMA writes in flight and puts an
+// s_waitcnt vmcnt(0) in front of the first one of every tile — i.e. the wave waits for ALL the tiles it has prefetched before it may read the
+// one that landed long ago (the 4 x 32-row kernel above pays exactly that; found in its ISA in round 5).  As asm the reads are opaque to that pass;
+// their results are handed to the MFMAs through tr_wait(), an s_waitcnt lgkmcnt(0) that carries the registers as tied operands, so no use (and no
+// copy) of a result can be scheduled before the wait.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+__device__ __forceinline__ void tr_read2(u32x2_t& lo, u32x2_t& hi, uint32_t lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(lo), "=&v"(hi) : "v"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void tr_wait(u32x2_t (&v)[4][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[2][0]), "+v"(v[2][1]), "+v"(v[3][0]), "+v"(v[3][1])
+                 :: "memory");
+}
+
+template <int NST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_vit_big_kernel(AttnArgs a) {
+    constexpr int HD = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int nqb = a.nq_rows / BIG_ROWS, nleft = a.nq_rows - nqb * BIG_ROWS;
+    const int per = 4 * nqb + (nleft > 0 ? 1 : 0);              // workgroups per quad of (frame, head) pairs: 4 x nqb MFMA workgroups (+ one for the leftover rows)
+    const int BH = a.batch * a.kv_heads;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int quad = lid / per, rq = lid - quad * per;
+    const float sc = a.scale * 1.4426950408889634f;
+
+    if (rq == 4 * nqb) {
+        // ---------------- leftover query rows of four (frame, head) pairs: one wave per pair, VALU only, no workgroup barrier ----------------
+        const int bh = quad * 4 + wid;
+        if (bh >= BH) return;
+        const int b = bh / a.kv_heads, kvh = bh - b * a.kv_heads;
+        const bf16_t* kbase = a.K + (size_t)b * a.k_bs + (size_t)kvh * a.k_hs;
+        const bf16_t* vbase = a.Vrow + (size_t)b * a.vr_bs + (size_t)kvh * a.vr_hs;
+        float* pl = reinterpret_cast<float*>(smem + wid * (BIG_MAXKV * 4));
+        const int nit = (a.nkv_rows + 63) >> 6;
+        for (int rr = 0; rr < nleft; ++rr) {
+            const int row = nqb * BIG_ROWS + rr;
+            const bf16_t* qp = a.Q + (size_t)b * a.q_bs + (size_t)kvh * a.q_hs + (size_t)row * a.q_rs;
+            uint4 qv[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) qv[c] = *reinterpret_cast<const uint4*>(qp + c * 8);
+            float mx = -3.0e38f;
+            for (int it = 0; it < nit; ++it) {                  // scores of keys it * 64 + lane (exp2 domain)
+                const int key = it * 64 + lane;
+                float dot = 0.f;
+                if (key < a.nkv_rows) {
+                    const bf16_t* kp = kbase + (size_t)key * a.k_rs;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const uint4 kk = *reinterpret_cast<const uint4*>(kp + c * 8);
+                        dot = dot2_el(qv[c].x, kk.x, dot); dot = dot2_el(qv[c].y, kk.y, dot);
+                        dot = dot2_el(qv[c].z, kk.z, dot); dot = dot2_el(qv[c].w, kk.w, dot);
+                    }
+                    dot *= sc;
+                    mx = fmaxf(mx, dot);
+                    pl[key] = dot;
+                }
+            }
+            mx = wave_max(mx);
+            float ls = 0.f;
+            for (int it = 0; it < nit; ++it) {
+                const int key = it * 64 + lane;
+                if (key < a.nkv_rows) {
+                    const float p = __builtin_amdgcn_exp2f(pl[key] - mx);      // (each lane re-reads what it wrote)
+                    pl[key] = p;
+                    ls += p;
+                }
+            }
+            ls = wave_sum(ls);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's LDS writes precede its reads below (one in-order LDS queue per wave)
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;   // lane = d: O[d] = sum_key p[key] V[key][d]
+            const bf16_t* vp = vbase + lane;
+            int key = 0;
+            for (; key + 4 <= a.nkv_rows; key += 4) {
+                const float4 p4 = *reinterpret_cast<const float4*>(pl + key);       // same address in every lane: an LDS broadcast
+                acc0 = fmaf(p4.x, bf2f(vp[(size_t)(key + 0) * a.vr_rs]), acc0);
+                acc1 = fmaf(p4.y, bf2f(vp[(size_t)(key + 1) * a.vr_rs]), acc1);
+                acc2 = fmaf(p4.z, bf2f(vp[(size_t)(key + 2) * a.vr_rs]), acc2);
+                acc3 = fmaf(p4.w, bf2f(vp[(size_t)(key + 3) * a.vr_rs]), acc3);
+            }
+            for (; key < a.nkv_rows; ++key) acc0 = fmaf(pl[key], bf2f(vp[(size_t)key * a.vr_rs]), acc0);
+            const float o = ((acc0 + acc1) + (acc2 + acc3)) / ls;
+            a.O[(size_t)b * a.o_bs + (size_t)kvh * a.o_hs + (size_t)row * a.o_rs + lane] = f2bf(o);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the next row overwrites pl)
+        }
+        return;
+    }
+
+    // ---------------- MFMA workgroup: query rows [qb * 192, + 192) of one (frame, head) ----------------
+    const int bh = quad * 4 + rq / nqb, qb = rq - (rq / nqb) * nqb;
+    if (bh >= BH) return;                                        // (workgroup-uniform)
+    const int b = bh / a.kv_heads, kvh = bh - b * a.kv_heads;
+    const int q0 = qb * BIG_ROWS + wid * BIG_QW;
+    const int rem = a.nkv_rows % BKV, nkv_main = a.nkv_rows - rem, nt = nkv_main / BKV;
+    const bf16_t* kbase = a.K + (size_t)b * a.k_bs + (size_t)kvh * a.k_hs;
+    const bf16_t* vbase = a.Vrow + (size_t)b * a.vr_bs + (size_t)kvh * a.vr_hs;
+
+    // ---- LDS-DMA: per tile 8 K pieces (8 rows x 128 B, XOR-swizzled on the source) + 8 V pieces (16 keys x 64 B of one d-half, halves swapped
+    //      for odd key quads); wave w issues pieces 2 w, 2 w + 1 of each
+    const bf16_t* ksrc[2];
+    const bf16_t* vsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pi = 2 * wid + j;
+        const int kr = pi * 8 + (lane >> 3);
+        ksrc[j] = kbase + (size_t)kr * a.k_rs + (((lane & 7) ^ ((kr >> 1) & 7)) << 3);
+        const int vkey = (pi & 3) * 16 + (lane >> 2);
+        vsrc[j] = vbase + (size_t)vkey * a.vr_rs + (pi >> 2) * 32 + (((lane & 3) ^ (((vkey >> 2) & 1) << 1)) << 3);
+    }
+    const long kstep = (long)BKV * a.k_rs, vstep = (long)BKV * a.vr_rs;
+    auto issue = [&](int t, int stage) {
+        char* st = smem + stage * BSTAGE + (2 * wid) * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            glds16(ksrc[j] + (size_t)t * kstep, st + j * 1024);
+            glds16(vsrc[j] + (size_t)t * vstep, st + 8192 + j * 1024);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nt) issue(t, t);
+
+    // ---- Q fragments, scaled once: q' = bf16(q * scale * log2 e)
+    bf16x8_t qf[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const bf16_t* qp = a.Q + (size_t)b * a.q_bs + (size_t)kvh * a.q_hs + (size_t)(q0 + i * 16 + r16) * a.q_rs + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 q4 = *reinterpret_cast<const uint4*>(qp + ks * 32);
+            union { bf16x8_t v; uint32_t u[4]; } o;
+            o.u[0] = pack2bf(bflo(q4.x) * sc, bfhi(q4.x) * sc);
+            o.u[1] = pack2bf(bflo(q4.y) * sc, bfhi(q4.y) * sc);
+            o.u[2] = pack2bf(bflo(q4.z) * sc, bfhi(q4.z) * sc);
+            o.u[3] = pack2bf(bflo(q4.w) * sc, bfhi(q4.w) * sc);
+            qf[i][ks] = o.v;
+        }
+    }
+    f32x4_t oacc[4][3], lacc[3], cinit[3];
+    float m[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        m[i] = 0.f;
+        lacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    bool first = true;
+
+    // ---- trailing keys (nkv % 64 of them) on the VALU: they initialise the softmax state
+    for (int jt = 0; jt < rem; ++jt) {
+        const int kv = nkv_main + jt;
+        const bf16_t* kp = kbase + (size_t)kv * a.k_rs + g * 8;
+        uint32_t ku[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 kk = *reinterpret_cast<const uint4*>(kp + ks * 32);
+            ku[ks][0] = kk.x; ku[ks][1] = kk.y; ku[ks][2] = kk.z; ku[ks][3] = kk.w;
+        }
+        const bf16_t* vp = vbase + (size_t)kv * a.vr_rs + 4 * g;
+        uint2 vv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vv[dt] = *reinterpret_cast<const uint2*>(vp + dt * 16);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float dot = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                union { bf16x8_t v; uint32_t u[4]; } qq;
+                qq.v = qf[i][ks];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dot = fmaf(bflo(qq.u[e]), bflo(ku[ks][e]), dot);
+                    dot = fmaf(bfhi(qq.u[e]), bfhi(ku[ks][e]), dot);
+                }
+            }
+            dot += __shfl_xor(dot, 16, 64);                      // the four lanes (q, g = 0..3) hold 16 d each
+            dot += __shfl_xor(dot, 32, 64);
+            const float mnew = first ? dot : fmaxf(m[i], dot);
+            const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(m[i] - mnew);
+            const float p = __builtin_amdgcn_exp2f(dot - mnew);
+            m[i] = mnew;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lacc[i][e] = fmaf(lacc[i][e], alpha, p);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                oacc[dt][i][0] = fmaf(p, bflo(vv[dt].x), oacc[dt][i][0] * alpha);
+                oacc[dt][i][1] = fmaf(p, bfhi(vv[dt].x), oacc[dt][i][1] * alpha);
+                oacc[dt][i][2] = fmaf(p, bflo(vv[dt].y), oacc[dt][i][2] * alpha);
+                oacc[dt][i][3] = fmaf(p, bfhi(vv[dt].y), oacc[dt][i][3] * alpha);
+            }
+        }
+        first = false;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float ci = first ? 0.f : -m[i];
+        cinit[i] = f32x4_t{ci, ci, ci, ci};
+    }
+    union { bf16x8_t v; uint32_t u[4]; } ones;
+    ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = TRACE_EL_ONE2;
+
+    // lane offsets: K fragment rows r16 of a 16-key block (k-step 0; k-step 1 is ^ 64), V transpose reads of d-tiles with (dt & 1) = 0 / 1
+    const int koff = kswz<HD>(r16, g);                          // (rows j * 16 + r16: (row >> 1) & 7 does not depend on j)
+    const int vrow = (4 * g + (r16 >> 2)) * 64 + (r16 & 3) * 8;
+    const int vtr0 = vrow + (g & 1) * 32, vtr1 = vrow + ((g & 1) ^ 1) * 32;
+    // LDS byte address of stage 0's V image (the asm reads take the 32-bit LDS address, not a generic pointer)
+    const uint32_t vlds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem) + 8192u;
+
+    int stage = 0, stage_n = NST - 1;
+    for (int t = 0; t < nt; ++t) {
+        // tile t landed: this wave's pieces by its own counted vmcnt (4 pieces per tile; the younger tiles may stay in flight), everybody's by the
+        // barrier; the barrier also says every wave is done reading tile t - 1, whose stage the DMA issued next overwrites
+        const int ahead = min(NST - 2, nt - 1 - t);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NST - 1 < nt && a.dbg != 1) issue(t + NST - 1, stage_n);
+        if (a.dbg != 2) {
+            const char* kb = smem + stage * BSTAGE;
+            // ---- S^T = K . Q^T - m
+            f32x4_t S[4][3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8_t kf0 = *reinterpret_cast<const bf16x8_t*>(kb + j * 2048 + koff);
+                const bf16x8_t kf1 = *reinterpret_cast<const bf16x8_t*>(kb + j * 2048 + (koff ^ 64));
+#pragma unroll
+                for (int i = 0; i < 3; ++i) mfma16_from(S[j][i], kf0, qf[i][0], cinit[i]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) S[j][i] = mfma16(kf1, qf[i][1], S[j][i]);
+            }
+            // ---- does any row need its reference moved?  (local maxima only; the exact row maximum is taken inside the slow path)
+            float mt[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                mt[i] = max16_raw(S[0][i], S[1][i], S[2][i], S[3][i]);
+            }
+            if (__any(first || max3_raw(mt[0], mt[1], mt[2]) > BIG_THR)) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    float mx = fmaxf(mt[i], __shfl_xor(mt[i], 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    const bool need = first || mx > BIG_THR;     // the same in the four lanes of a query row
+                    const float d = need ? mx : 0.f;
+                    const float f = first ? 0.f : __builtin_amdgcn_exp2f(-d);       // (first tile: O = l = 0, and 2^-d may overflow)
+                    m[i] += d;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) lacc[i][e] *= f;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) oacc[dt][i][e] *= f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) S[j][i][e] -= d;
+                    const float ci = -m[i];
+                    cinit[i] = f32x4_t{ci, ci, ci, ci};
+                }
+                first = false;
+            }
+            // ---- p = 2^S, O^T += V^T . P, l += 1 . P
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                // the 8 V fragments of this key-tile pair first: their LDS latency runs under the exponentials
+                u32x2_t vq[4][2];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    tr_read2(vq[dt][0], vq[dt][1], vlds + stage * BSTAGE + (dt >> 1) * 4096 + (2 * kp) * 1024 + ((dt & 1) ? vtr1 : vtr0));
+                union { bf16x8_t v; uint32_t u[4]; } pf[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const f32x4_t& s0 = S[2 * kp][i];
+                    const f32x4_t& s1 = S[2 * kp + 1][i];
+                    pf[i].u[0] = pack2bf(__builtin_amdgcn_exp2f(s0[0]), __builtin_amdgcn_exp2f(s0[1]));
+                    pf[i].u[1] = pack2bf(__builtin_amdgcn_exp2f(s0[2]), __builtin_amdgcn_exp2f(s0[3]));
+                    pf[i].u[2] = pack2bf(__builtin_amdgcn_exp2f(s1[0]), __builtin_amdgcn_exp2f(s1[1]));
+                    pf[i].u[3] = pack2bf(__builtin_amdgcn_exp2f(s1[2]), __builtin_amdgcn_exp2f(s1[3]));
+                }
+                tr_wait(vq);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    union { bf16x8_t v; u32x2_t q[2]; } u;
+                    u.q[0] = vq[dt][0]; u.q[1] = vq[dt][1];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) oacc[dt][i] = mfma16(u.v, pf[i].v, oacc[dt][i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) lacc[i] = mfma16(ones.v, pf[i].v, lacc[i]);
+            }
+        }
+        stage = stage + 1 == NST ? 0 : stage + 1;
+        stage_n = stage_n + 1 == NST ? 0 : stage_n + 1;
+    }
+
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float inv = 1.f / lacc[i][0];
+        bf16_t* op = a.O + (size_t)b * a.o_bs + (size_t)kvh * a.o_hs + (size_t)(q0 + i * 16 + r16) * a.o_rs + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 o;
+            o.x = pack2bf(oacc[dt][i][0] * inv, oacc[dt][i][1] * inv);
+            o.y = pack2bf(oacc[dt][i][2] * inv, oacc[dt][i][3] * inv);
+            *reinterpret_cast<uint2*>(op + dt * 16) = o;
+        }
+    }
+}
+
 // V [rows, HD] (row stride src_rs) -> V^T [HD, rows_pad] (row stride dst_rs), zero-filled for rows >= n.
 // One block per 64-row tile: 16-byte loads -> LDS -> 16-byte stores along the token axis.
 // perm = 1: within every 16 keys the destination order is [0-3, 8-11, 4-7, 12-15] (attn_vit_dma_kernel's PV operand layout).
@@ -595,6 +966,13 @@ bool attn_vit_wants_perm(int nkv_rows, bool has_vrow) {
     return (g_attn_pf_debug < 5 || g_attn_pf_debug == 6) && nkv_rows >= 2 * BKV && (rem == 0 || (has_vrow && rem <= TAILV));
 }
 
+int g_attn_vit_big = 1;    // the round-5 192-row kernel for shapes it takes (trace_op_set_gemm_variant(190 + x): 0 = the 4 x 32-row kernel, 1 = 4-stage ring, 2 = 3-stage ring)
+// v_perm == 2 (row-major V), >= 192 query rows of which 192 leaves at most BIG_MAXLEFT over, whole key tiles + a short tail, keys fit the leftover path's LDS rows
+static bool attn_vit_big_ok(const AttnArgs& a) {
+    return g_attn_vit_big && a.v_perm == 2 && !a.causal && a.nq_rows >= BIG_ROWS && a.nq_rows % BIG_ROWS <= BIG_MAXLEFT && a.nkv_rows >= BKV &&
+           a.nkv_rows % BKV <= TAILV && a.nkv_rows <= BIG_MAXKV && !(a.q_rs % 8) && !(a.q_hs % 8) && !(a.q_bs % 8) && !(a.k_rs % 8) && !(a.k_hs % 8) &&
+           !(a.k_bs % 8) && !(a.o_rs % 4) && !(a.o_hs % 4) && !(a.o_bs % 4);
+}
 int launch_attn_vit(const AttnArgs& a_, hipStream_t s) {
     AttnArgs a = a_;
     a.dbg = g_attn_pf_debug;
@@ -602,6 +980,20 @@ int launch_attn_vit(const AttnArgs& a_, hipStream_t s) {
     if (a.v_perm) {
         if (a.causal || !attn_vit_wants_perm(a.nkv_rows, a.Vrow != nullptr)) return TRACE_ERR_ARG;
         if (a.v_perm == 2 && (!a.Vrow || (a.vr_rs % 8) || (a.vr_hs % 8) || (a.vr_bs % 8))) return TRACE_ERR_ARG;
+        if (attn_vit_big_ok(a)) {
+            const int nqb = a.nq_rows / BIG_ROWS, per = 4 * nqb + (a.nq_rows % BIG_ROWS ? 1 : 0);
+            const long nblk = (long)(((long)a.batch * a.kv_heads + 3) / 4) * per;
+            if (nblk > 0x7fffffffL) return TRACE_ERR_ARG;
+            static LdsGrant grant3, grant4;
+            if (g_attn_vit_big == 2) {
+                if (!grant_dynamic_lds(grant3, reinterpret_cast<const void*>(attn_vit_big_kernel<3>), 3 * BSTAGE)) return TRACE_ERR_HIP;
+                hipLaunchKernelGGL(attn_vit_big_kernel<3>, dim3((unsigned)nblk), dim3(256), 3 * BSTAGE, s, a);
+            } else {
+                if (!grant_dynamic_lds(grant4, reinterpret_cast<const void*>(attn_vit_big_kernel<4>), 4 * BSTAGE)) return TRACE_ERR_HIP;
+                hipLaunchKernelGGL(attn_vit_big_kernel<4>, dim3((unsigned)nblk), dim3(256), 4 * BSTAGE, s, a);
+            }
+            return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+        }
         static LdsGrant grant_t, grant_r;
         if (!grant_dynamic_lds(grant_t, reinterpret_cast<const void*>(attn_vit_dma_kernel<false>), DSTAGES * DSTAGE) ||
             !grant_dynamic_lds(grant_r, reinterpret_cast<const void*>(attn_vit_dma_kernel<true>), DSTAGES * DSTAGE)) return TRACE_ERR_HIP;

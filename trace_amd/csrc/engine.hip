@@ -1419,6 +1419,7 @@ extern int g_gemm_pers_opt;
 extern int g_gemm_ldr_opt;
 extern int g_gemm_pers_walk;
 extern int g_gemm_resid_pers;
+extern int g_attn_vit_big;
 extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 1000 && variant <= 1000 + 1024) { g_gemm_pers_grid_cap = variant - 1000; return TRACE_OK; }   // persistent GEMM: at most n workgroups (0 = #CUs)
     if (variant >= 100 && variant < 104) { g_attn_debug = variant - 100; return TRACE_OK; }
@@ -1428,6 +1429,7 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 160 && variant <= 161) { g_vit_patch_fused = variant - 160; return TRACE_OK; }
     if (variant >= 170 && variant <= 174) { g_decode_fuse_norm_rows = variant - 170; return TRACE_OK; }
     if (variant >= 180 && variant <= 181) { g_decode_fuse_swiglu = variant - 180; return TRACE_OK; }
+    if (variant >= 190 && variant <= 192) { g_attn_vit_big = variant - 190; return TRACE_OK; }   // ViT attention: 0 = the 4 x 32-row kernel, 1 = the 192-row kernel (4-stage ring), 2 = (3-stage ring)
     if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : 32; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }

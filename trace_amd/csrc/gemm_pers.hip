@@ -477,7 +477,6 @@ __device__ __forceinline__ void loader_role_rs(const GemmArgs& p, const Sched& s
             src[j] = isA ? ((uint32_t)min(m0_ + row, p.M - 1) * (uint32_t)p.lda + kc * 8) * 2u                                         \
                          : ((uint32_t)(n0_ + row) * (uint32_t)p.ldw + kc * 8) * 2u;                                                    \
         }                                                                                                                              \
-        if (!GLU && lw == 3 && p.bias) bias2 = *reinterpret_cast<const uint2*>(p.bias + n0_ + lane * 4);  /* else stays zero */       \
     }
 #define RS_LOAD(KO)                                                                                                                    \
     { const char* gk_ = gbase + (size_t)(KO);                                                                                          \
@@ -486,15 +485,16 @@ __device__ __forceinline__ void loader_role_rs(const GemmArgs& p, const Sched& s
     { char* dst_ = wbase + (STG) * STAGE;                                                                                              \
       _Pragma("unroll") for (int j = 0; j < 16; ++j) *reinterpret_cast<u32x4*>(dst_ + j * 1024) = R[j]; }
     RS_SETUP(h_li);
-    if (RTOUCH) { int tm_, tn_; tile_coords(base + h_li, ntm, ntn, tm_, tn_); hm0 = tm_ * BM; hn0 = tn_ * BN; }
+    { int tm_, tn_; tile_coords(base + h_li, ntm, ntn, tm_, tn_); hm0 = tm_ * BM; hn0 = tn_ * BN; }
     RS_LOAD(0);
     RS_WRITE(0);                                                    // K-tile 0 of the first tile -> stage 0 (waits for its loads)
     l_kt = 1;
     RS_LOAD(128);                                                   // K-tile 1 -> registers
     while (true) {
         // ---- hand-over of stream position q = (tile h_li, K-tile kt): its ds_writes were issued one iteration ago (or above)
-        if (kt == 0 && !GLU && lw == 3)                             // this tile's bias row (the load cursor is in the same tile: nk >= 4)
-            *reinterpret_cast<uint2*>(smem + BIAS_OFF + (n & 1) * 512 + lane * 8) = bias2;
+        // this tile's bias row (zeros without a bias), read by the MFMA waves after the K loop: requested behind hand-over 0, parked before hand-over 2
+        // (kept in a register from the tile's set-up on, it made hipcc wait for ALL the loads in flight at the tile boundary)
+        if (kt == 2 && !GLU && lw == 3) *reinterpret_cast<uint2*>(smem + BIAS_OFF + (n & 1) * 512 + lane * 8) = bias2;
         if (kt == 1 && tid == NMT) {                                // the tile after this one (read from hand-over 1 on: by this wave's load cursor at nk - 2)
             s_next[(n + 1) & 1] = dynamic ? nwg + ticket : h_li + nwg;
             if (dynamic && ticket == cnt - 1) (void)atomicExch(ctr + xcd * CTR_STRIDE, 0);       // the launch's last ticket re-arms the counter (loader_role)
@@ -503,6 +503,7 @@ __device__ __forceinline__ void loader_role_rs(const GemmArgs& p, const Sched& s
         __builtin_amdgcn_s_barrier();                               // position q handed over; the stage of q - 1 is free
         asm volatile("" ::: "memory");
         if (kt == 0 && dynamic && tid == NMT) ticket = atomicAdd(ctr + xcd * CTR_STRIDE, 1);
+        if (kt == 0 && !GLU && lw == 3 && p.bias) bias2 = *reinterpret_cast<const uint2*>(p.bias + hn0 + lane * 4);
         if (l_live) {
             RS_WRITE((q + 1) & 1);                                  // position q + 1: registers -> the stage just freed
             if (l_kt + 1 < nk) {
@@ -520,6 +521,10 @@ __device__ __forceinline__ void loader_role_rs(const GemmArgs& p, const Sched& s
                 }
             }
         }
+        // (the next tile's index is read BEFORE the touches: hipcc guards an LDS read behind an LDS-DMA with vmcnt(0), i.e. with a wait for this
+        // iteration's loads as well)
+        int nx_h = 0;
+        if (kt == nk - 1) nx_h = __builtin_amdgcn_readfirstlane(s_next[(n + 1) & 1]);
         if (RTOUCH && kt == nk - 1) {
             // residual touches of the tile whose last K-tile has just been handed over (loader_role / gemm_ldr.hip), BEHIND this iteration's loads
             const int L = lw * 64 + lane;
@@ -533,10 +538,9 @@ __device__ __forceinline__ void loader_role_rs(const GemmArgs& p, const Sched& s
         }
         ++q;
         if (++kt == nk) {
-            const int nx = __builtin_amdgcn_readfirstlane(s_next[(n + 1) & 1]);
-            if (nx >= cnt) break;
-            h_li = nx; kt = 0; ++n;
-            if (RTOUCH) { int tm_, tn_; tile_coords(base + h_li, ntm, ntn, tm_, tn_); hm0 = tm_ * BM; hn0 = tn_ * BN; }
+            if (nx_h >= cnt) break;
+            h_li = nx_h; kt = 0; ++n;
+            { int tm_, tn_; tile_coords(base + h_li, ntm, ntn, tm_, tn_); hm0 = tm_ * BM; hn0 = tn_ * BN; }
         }
     }
 #undef RS_SETUP

@@ -564,28 +564,28 @@ __device__ __forceinline__ void mfma16_from(f32x4_t& d, const bf16x8_t& a, const
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_" TRACE_EL " %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
 }
 
-// v_max3_f32 as it is: fmaxf() makes the compiler quiet possible signalling NaNs first (one v_max_f32 x, x, x per MFMA result: 60 instructions per
-// key tile for 48 comparisons); a NaN score is a NaN output either way
-__device__ __forceinline__ float max3_raw(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+// "Does any of the 16 scores a lane holds exceed the threshold?" on the scores' BIT PATTERNS with integer max3: fmaxf() makes the compiler quiet
+// possible signalling NaNs first (one v_max_f32 x, x, x per MFMA result: 60 instructions per key tile for 48 comparisons), and a v_max3_f32 in inline asm
+// is invisible to hipcc's hazard recognizer — it was scheduled straight behind the MFMA that writes its operand, inside that MFMA's result latency, read
+// stale registers now and then, and two runs of the first hardware test differed in a few bits.  As signed integers, IEEE floats above a positive
+// threshold compare like the floats (negative scores are negative integers, NaNs land above everything -> the slow path), which is all the fast path
+// needs; the slow path takes its exact maxima with fmaxf.
+__device__ __forceinline__ int imax3(int a, int b, int c) { return max(max(a, b), c); }
+__device__ __forceinline__ int bits_max16(const f32x4_t& a, const f32x4_t& b, const f32x4_t& c, const f32x4_t& d) {
+    int r = imax3(__float_as_int(a[0]), __float_as_int(a[1]), __float_as_int(a[2]));
+    r = imax3(r, __float_as_int(a[3]), __float_as_int(b[0]));
+    r = imax3(r, __float_as_int(b[1]), __float_as_int(b[2]));
+    r = imax3(r, __float_as_int(b[3]), __float_as_int(c[0]));
+    r = imax3(r, __float_as_int(c[1]), __float_as_int(c[2]));
+    r = imax3(r, __float_as_int(c[3]), __float_as_int(d[0]));
+    r = imax3(r, __float_as_int(d[1]), __float_as_int(d[2]));
+    return max(r, __float_as_int(d[3]));
 }
-// the maximum of the 16 scores a lane holds for one query tile: ONE asm block (between separate asm statements hipcc pads an s_nop each)
-__device__ __forceinline__ float max16_raw(const f32x4_t& a, const f32x4_t& b, const f32x4_t& c, const f32x4_t& d) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3\n\t"
-        "v_max3_f32 %0, %0, %4, %5\n\t"
-        "v_max3_f32 %0, %0, %6, %7\n\t"
-        "v_max3_f32 %0, %0, %8, %9\n\t"
-        "v_max3_f32 %0, %0, %10, %11\n\t"
-        "v_max3_f32 %0, %0, %12, %13\n\t"
-        "v_max3_f32 %0, %0, %14, %15\n\t"
-        "v_max_f32 %0, %0, %16"
-        : "=&v"(r)
-        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]),
-          "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]));
-    return r;
+__device__ __forceinline__ float fmax16(const f32x4_t& a, const f32x4_t& b, const f32x4_t& c, const f32x4_t& d) {
+    float r = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+    r = fmaxf(r, fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+    r = fmaxf(r, fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])));
+    return fmaxf(r, fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3])));
 }
 // LDS transpose reads as inline asm.  Through the builtin, hipcc's wait-count pass cannot tell the read from the LDS-DMA writes in flight and puts an
 // s_waitcnt vmcnt(0) in front of the first one of every tile — i.e. the wave waits for ALL the tiles it has prefetched before it may read the
@@ -822,16 +822,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int i = 0; i < 3; ++i) S[j][i] = mfma16(kf1, qf[i][1], S[j][i]);
             }
-            // ---- does any row need its reference moved?  (local maxima only; the exact row maximum is taken inside the slow path)
-            float mt[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                mt[i] = max16_raw(S[0][i], S[1][i], S[2][i], S[3][i]);
-            }
-            if (__any(first || max3_raw(mt[0], mt[1], mt[2]) > BIG_THR)) {
+            // ---- does any row need its reference moved?  (integer compare of the bit patterns; the exact row maxima are taken inside the slow path)
+            const int over = imax3(bits_max16(S[0][0], S[1][0], S[2][0], S[3][0]), bits_max16(S[0][1], S[1][1], S[2][1], S[3][1]),
+                                   bits_max16(S[0][2], S[1][2], S[2][2], S[3][2]));
+            if (__any(first || over > __float_as_int(BIG_THR))) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    float mx = fmaxf(mt[i], __shfl_xor(mt[i], 16, 64));
+                    const float mloc = fmax16(S[0][i], S[1][i], S[2][i], S[3][i]);
+                    float mx = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
                     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                     const bool need = first || mx > BIG_THR;     // the same in the four lanes of a query row
                     const float d = need ? mx : 0.f;

@@ -683,15 +683,15 @@ static int stc_block(trace_ctx* c, const StcBlock& k, const bf16_t* x, bf16_t* o
     LCHK(launch_bias_act(c->stc_g2, k.fc2b, N, H, ACT_SIGMOID, s));
     LCHK(launch_scale_rows(z, c->stc_g2, N, HW, H, s));
     TRY(gemm(z, H, k.w3, H, y, H, nullptr, nullptr, 0, rows, H, H, EPI_NONE, s));
-    LCHK(launch_layernorm(y, H, y, H, k.n3w, k.n3b, rows, H, 1e-6f, s, 0));
     const bf16_t* shortcut = x;
     if (k.wd) {
         TRY(gemm(x, k.cin, k.wd, k.cin, sc, H, nullptr, nullptr, 0, rows, H, k.cin, EPI_NONE, s));
         LCHK(launch_layernorm(sc, H, sc, H, k.ndw, k.ndb, rows, H, 1e-6f, s, 0));
         shortcut = sc;
     }
-    LCHK(launch_add_act(y, shortcut, (long)rows * H, ACT_SILU, s));          // y = SiLU(y + shortcut); x is dead after this
-    if (out != y) HIPCHK(hipMemcpyAsync(out, y, (size_t)rows * H * 2, hipMemcpyDeviceToDevice, s));
+    // out = SiLU(LN(conv3 out) + shortcut) in ONE pass, written where the next block reads it (round 5: was LayerNorm, add + SiLU and a copy —
+    // three passes over [rows, H]; same rounding points).  x is dead from here on (out may be x: row-wise in place).
+    LCHK(launch_layernorm(y, H, out, H, k.n3w, k.n3b, rows, H, 1e-6f, s, 1, shortcut, H));
     return TRACE_OK;
 }
 

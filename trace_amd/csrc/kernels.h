@@ -70,7 +70,8 @@ enum { ACT_NONE = 0, ACT_SILU = 1, ACT_SIGMOID = 2, ACT_GELU = 3 };
 // ---- norms (norm.hip) ----
 // y = LN(x) * w + b over the last dim D (D % 8 == 0, D <= 8192); rows independent; x,y bf16, stats fp32.
 int launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w, const bf16_t* b,
-                     int rows, int D, float eps, hipStream_t s, int silu = 0);   // silu = 1: y = SiLU(LN(x))
+                     int rows, int D, float eps, hipStream_t s, int silu = 0,   // silu = 1: y = SiLU(LN(x))
+                     const bf16_t* res = nullptr, int ldres = 0);                // res: y = act(bf16(LN(x)) + res) (the RegNet block's tail; y may alias res)
 int launch_rmsnorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w, int rows, int D, float eps,
                    hipStream_t s);
 

@@ -10,7 +10,7 @@ constexpr int MAXCH = 8;   // 8 chunks x 64 lanes x 8 elements = 4096
 template <bool RMS>
 __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
                                                    const bf16_t* __restrict__ w, const bf16_t* __restrict__ b, int rows,
-                                                   int D, float eps, int silu) {
+                                                   int D, float eps, int silu, const bf16_t* __restrict__ res = nullptr, int ldres = 0) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -72,7 +72,12 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
                 const float bb[8] = {bflo(ub.x), bfhi(ub.x), bflo(ub.y), bfhi(ub.y), bflo(ub.z), bfhi(ub.z), bflo(ub.w), bfhi(ub.w)};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * ww[e] + bb[e];
-                if (silu) {             // LayerNorm2d + SiLU of timm's ConvNormAct (STC connector): LN output rounded like a separate op
+                if (res) {              // the RegNet block's tail in one pass (STC connector): act(LN(x) + shortcut), LN output rounded like a separate op
+                    const uint4 ur = *reinterpret_cast<const uint4*>(res + (size_t)row * ldres + c * 8);
+                    const float rr[8] = {bflo(ur.x), bfhi(ur.x), bflo(ur.y), bfhi(ur.y), bflo(ur.z), bfhi(ur.z), bflo(ur.w), bfhi(ur.w)};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float t = bf2f(f2bf(o[e])) + rr[e]; o[e] = silu ? t / (1.f + __expf(-t)) : t; }
+                } else if (silu) {      // LayerNorm2d + SiLU of timm's ConvNormAct (STC connector): LN output rounded like a separate op
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { const float t = bf2f(f2bf(o[e])); o[e] = t / (1.f + __expf(-t)); }
                 }
@@ -158,19 +163,23 @@ __global__ __launch_bounds__(256) void norm1024_kernel(const bf16_t* __restrict_
 }  // namespace
 
 int launch_layernorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w, const bf16_t* b, int rows, int D,
-                     float eps, hipStream_t s, int silu) {
-    if (D % 8 || D > MAXCH * 512 || (ldx % 8) || (ldy % 8) || rows <= 0) return TRACE_ERR_ARG;
+                     float eps, hipStream_t s, int silu, const bf16_t* res, int ldres) {
+    if (D % 8 || D > MAXCH * 512 || (ldx % 8) || (ldy % 8) || rows <= 0 || (res && (ldres % 8))) return TRACE_ERR_ARG;
+    if (res) {
+        hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, w, b, rows, D, eps, silu, res, ldres);
+        return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
+    }
     if (D == 1024 && rows >= 4096) {
         hipLaunchKernelGGL((norm1024_kernel<false, 4>), dim3((rows + 15) / 16), dim3(256), 0, s, x, ldx, y, ldy, w, b, rows, eps, silu);
         return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
     }
-    hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, w, b, rows, D, eps, silu);
+    hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, w, b, rows, D, eps, silu, nullptr, 0);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 
 int launch_rmsnorm(const bf16_t* x, int ldx, bf16_t* y, int ldy, const bf16_t* w, int rows, int D, float eps,
                    hipStream_t s) {
     if (D % 8 || D > MAXCH * 512 || (ldx % 8) || (ldy % 8) || rows <= 0) return TRACE_ERR_ARG;
-    hipLaunchKernelGGL(norm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, w, nullptr, rows, D, eps, 0);
+    hipLaunchKernelGGL(norm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, w, nullptr, rows, D, eps, 0, nullptr, 0);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }

@@ -2,7 +2,6 @@
 #   (1) kernel tests: register-staged GEMM loaders (332), the 192-row ViT attention (191 / 192), the rest of test_gpu_kernels
 #   (2) interleaved A/Bs: GEMM family on the ViT / prefill shapes; ViT attention; decode touch-prefetch at batch 128 and batch 1
 set -x
-python -c "from trace_amd import _lib; _lib.load(); _lib.load('f16')" || exit 9
 O=gpurun_out/r5c1
 mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_kernels.py -q -x --tb=short -p no:cacheprovider > $O/kernels.log 2>&1; echo "kernel tests rc=$?"; tail -15 $O/kernels.log

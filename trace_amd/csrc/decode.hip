@@ -19,8 +19,6 @@
 #include "common.h"
 #include "kernels.h"
 
-int g_decode_prefetch_mb = 32;     // MB touched under each latency-bound kernel of a decode step (0 = off; A/B: trace_op_set_gemm_variant(600 + MB))
-
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
@@ -58,6 +56,7 @@ __device__ __forceinline__ void prefetch_workgroup(const Prefetch& pf, int xblk,
         if (pf.p[r] && pf.bytes[r]) touch_range(pf.p[r], pf.bytes[r], xblk * nw + wid, nxblk * nw, sc, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may be in flight when the workgroup's LDS is released
 }
+int g_decode_prefetch_mb = 32;     // MB touched under each latency-bound kernel of a decode step (0 = off; A/B: trace_op_set_gemm_variant(600 + MB))
 
 // ---------------------------------------------------------------------------------------------------------
 // skinny_lds: decode GEMV with the ACTIVATIONS STATIONARY IN LDS.

@@ -29,36 +29,6 @@ __device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
 union Frag { uint4 u; bf16x8_t v; };
 
 // ---------------------------------------------------------------------------------------------------------
-// Touch-prefetch under the latency-bound kernels of a decode step (round 5).  add_rmsnorm (6.5 us), qkv_finish (9 us) and the batch-1 attention
-// (13 us) move a few MB through dependent round trips while the HBM channels idle — and the kernel that follows each of them streams tens to
-// hundreds of MB from a cold start.  Those kernels are launched with EXTRA workgroups that do nothing but request one dword of every 128-byte
-// line of a range the NEXT kernel reads first (by LDS-DMA into a scratch: an L2 / Infinity-Cache fill with no register destination — gemm_pers.hip's
-// touch), so the bytes cross the memory bus while it would otherwise be quiet and the next kernel finds them in the 256 MB Infinity Cache.
-// Loads only: no result depends on them.
-struct Prefetch {
-    const char* p[2];      // up to two ranges (e.g. the o-proj weights and the head of the gate|up weights)
-    unsigned int bytes[2];
-};
-__device__ __forceinline__ void touch_range(const char* base, unsigned int bytes, int worker, int nworkers, char* lds_scratch, int lane) {
-    const unsigned int nlines = bytes >> 7;
-    for (unsigned int l0 = (unsigned int)worker * 64u; l0 < nlines; l0 += (unsigned int)nworkers * 64u) {
-        const unsigned int l = min(l0 + (unsigned int)lane, nlines - 1u);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)l * 128u),
-                                         (__attribute__((address_space(3))) void*)lds_scratch, 4, 0, 0);
-    }
-}
-// the body of a prefetch-only workgroup: `xblk` of `nxblk` extra workgroups, `nw` waves each
-__device__ __forceinline__ void prefetch_workgroup(const Prefetch& pf, int xblk, int nxblk, int nw, char* lds_scratch) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    char* sc = lds_scratch + wid * 256;
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-        if (pf.p[r] && pf.bytes[r]) touch_range(pf.p[r], pf.bytes[r], xblk * nw + wid, nxblk * nw, sc, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may be in flight when the workgroup's LDS is released
-}
-int g_decode_prefetch_mb = 32;     // MB touched under each latency-bound kernel of a decode step (0 = off; A/B: trace_op_set_gemm_variant(600 + MB))
-
-// ---------------------------------------------------------------------------------------------------------
 // skinny_lds: decode GEMV with the ACTIVATIONS STATIONARY IN LDS.
 // History: the first version gave every workgroup 16 weight rows and all of K, and read X (B x K bf16, L2-resident)
 // straight into MFMA fragments.  At B = 32 that L2 stream is as large as the weight stream itself and cost 30-60 %
@@ -455,14 +425,9 @@ __global__ __launch_bounds__(256) void tile_pack_kernel(const bf16_t* __restrict
 __global__ __launch_bounds__(1024) void add_rmsnorm_kernel(const float* __restrict__ part, int KS, const bf16_t* __restrict__ R, int ldr,
                                                            bf16_t* __restrict__ xout, int ldx, const bf16_t* __restrict__ w,
                                                            bf16_t* __restrict__ y, int ldy, int N, float eps,
-                                                           uint8_t* __restrict__ y8, float* __restrict__ sy, int B, Prefetch pf) {
+                                                           uint8_t* __restrict__ y8, float* __restrict__ sy) {
     __shared__ float s_red[16];
     __shared__ float s_amax[16];
-    __shared__ __attribute__((aligned(16))) char s_touch[16 * 256];
-    if ((int)blockIdx.x >= B) {                        // prefetch-only workgroups (the next GEMM's first weights), see touch_range
-        prefetch_workgroup(pf, blockIdx.x - B, gridDim.x - B, 16, s_touch);
-        return;
-    }
     const int b = blockIdx.x, tid = threadIdx.x;
     const int c = tid;                                 // N <= 4096: one 4-element chunk per thread
     const bool on = c < (N >> 2);
@@ -555,7 +520,7 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
                                                              unsigned int* __restrict__ tickets, bf16_t* __restrict__ O, int ldo,
                                                              int nq, int nkv, int nsplit, float scale, int fuse_rope,
                                                              const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                                             const float* __restrict__ qpart, int qks, int dbg, Prefetch pf) {
+                                                             const float* __restrict__ qpart, int qks, int dbg) {
     constexpr int HD = 128, GQ = 4;
     __shared__ __attribute__((aligned(16))) float s_acc[4][GQ][HD];
     __shared__ float s_m[4][GQ], s_l[4][GQ];
@@ -563,14 +528,6 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i = lane & 15, g = lane >> 4;          // i: A-row / head column; g: k-group
-    if ((int)blockIdx.x >= nsplit) {
-        // prefetch-only workgroups (small batches: the attention is a handful of dependent round trips while HBM idles; the GEMVs that follow
-        // stream the o-proj and gate|up weights from a cold start), see touch_range.  They take no ticket and touch no partial.
-        const int nx = gridDim.x - nsplit;
-        prefetch_workgroup(pf, ((blockIdx.z * gridDim.y) + blockIdx.y) * nx + (blockIdx.x - nsplit), nx * gridDim.y * gridDim.z, 4,
-                           reinterpret_cast<char*>(&s_acc[0][0][0]));
-        return;
-    }
     const int sp = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
     const int p_new = pos[b];
     const int ctx = p_new + 1;
@@ -1139,27 +1096,10 @@ int launch_tile_pack(const bf16_t* src, int ldw, bf16_t* dst, int N, int K, hipS
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 
-// the extra prefetch-only workgroups a launch gets: enough waves to have the range requested within a few microseconds, never more than the CUs left over
-static Prefetch make_prefetch(const void* next0, size_t bytes0, const void* next1, size_t bytes1) {
-    Prefetch pf{};
-    const size_t cap = (size_t)g_decode_prefetch_mb << 20;
-    size_t left = cap;
-    const void* ptrs[2] = {next0, next1};
-    const size_t bys[2] = {bytes0, bytes1};
-    for (int r = 0; r < 2; ++r) {
-        const size_t n = ptrs[r] ? std::min(bys[r], left) : 0;
-        pf.p[r] = n ? (const char*)ptrs[r] : nullptr;
-        pf.bytes[r] = (unsigned int)(n & ~(size_t)127);
-        left -= n;
-    }
-    return pf;
-}
 int launch_add_rmsnorm(const float* part, int KS, const bf16_t* R, int ldr, bf16_t* xout, int ldx, const bf16_t* w, bf16_t* y,
-                       int ldy, int B, int N, float eps, hipStream_t s, uint8_t* y8, float* sy, const void* next_w, size_t next_bytes) {
+                       int ldy, int B, int N, float eps, hipStream_t s, uint8_t* y8, float* sy) {
     if (B < 1 || B > SK_ROWS || KS < 1 || N % 4 || N > 4096 || (ldr % 4) || (ldx % 4) || (ldy % 4)) return TRACE_ERR_ARG;
-    const Prefetch pf = make_prefetch(next_w, next_bytes, nullptr, 0);
-    const int extra = pf.bytes[0] ? std::max(16, std::min(192, 256 - B)) : 0;     // 16-wave workgroups beside the B real ones
-    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(B + extra), dim3(1024), 0, s, part, KS, R, ldr, xout, ldx, w, y, ldy, N, eps, y8, sy, B, pf);
+    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(B), dim3(1024), 0, s, part, KS, R, ldr, xout, ldx, w, y, ldy, N, eps, y8, sy);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 
@@ -1170,26 +1110,8 @@ __global__ __launch_bounds__(256) void qkv_finish_kernel(const float* __restrict
                                                          bf16_t* __restrict__ kcache, bf16_t* __restrict__ vtcache, long slot_stride,
                                                          long kv_head_stride, int ctx_stride, const int32_t* __restrict__ slots,
                                                          const int32_t* __restrict__ pos, int B, int nq, int nkv,
-                                                         const float* __restrict__ cos_t, const float* __restrict__ sin_t, int nreal, int pf_seqs) {
+                                                         const float* __restrict__ cos_t, const float* __restrict__ sin_t) {
     constexpr int HD = 128, HALF = 64;
-    __shared__ __attribute__((aligned(16))) char s_touch[4 * 256];
-    if ((int)blockIdx.x >= nreal) {
-        // prefetch-only workgroups: the K rows of the first pf_seqs sequences — what the attention launched next reads first (its workgroups are
-        // ordered by sequence) — one (sequence, kv head) unit per wave group, rows 0 .. pos of [slot][kvh][pos][128]
-        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-        const int worker = (blockIdx.x - nreal) * 4 + wid, nworkers = (gridDim.x - nreal) * 4;
-        const int units = pf_seqs * nkv;
-        if (units > 0 && nworkers >= units) {
-            const int unit = worker % units, sub = worker / units, nsub = nworkers / units;
-            if (sub < nsub) {
-                const int sb = unit / nkv, kh = unit - sb * nkv;
-                const char* base = reinterpret_cast<const char*>(kcache + (size_t)slots[sb] * slot_stride + (size_t)kh * kv_head_stride);
-                touch_range(base, (unsigned int)(pos[sb] + 1) * (HD * 2), sub, nsub, s_touch + wid * 256, lane);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
     const int nh = nq + 2 * nkv;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= B * nh * 8) return;
@@ -1239,15 +1161,8 @@ int launch_qkv_finish(const float* part, int ks, int ldq, bf16_t* qout, bf16_t* 
                       hipStream_t s) {
     if (B < 1 || ks < 1 || (ldq % 8)) return TRACE_ERR_ARG;
     const int total = B * (nq + 2 * nkv) * 8;
-    const int nreal = (total + 255) / 256;
-    // the K rows of the first sequences (a sequence's K rows of a layer: (pos + 1) x nkv x 256 bytes): about g_decode_prefetch_mb MB of them
-    int pf_seqs = 0, extra = 0;
-    if (g_decode_prefetch_mb > 0 && B >= 32) {
-        pf_seqs = std::min(B, std::max(1, g_decode_prefetch_mb / 4));     // ~4 MB per sequence at ctx ~2000
-        extra = pf_seqs * nkv;                                            // 4 waves per (sequence, kv head) unit
-    }
-    hipLaunchKernelGGL(qkv_finish_kernel, dim3(nreal + extra), dim3(256), 0, s, part, ks, ldq, qout, kcache, vtcache, slot_stride,
-                       kv_head_stride, ctx_stride, slots, pos, B, nq, nkv, cos_t, sin_t, nreal, pf_seqs);
+    hipLaunchKernelGGL(qkv_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, ks, ldq, qout, kcache, vtcache, slot_stride,
+                       kv_head_stride, ctx_stride, slots, pos, B, nq, nkv, cos_t, sin_t);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 
@@ -1255,14 +1170,11 @@ int g_attn_debug = 0;   // microbenchmark-only phase cut-offs (0 = full kernel)
 int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vtcache, long slot_stride, long kv_head_stride,
                        int ctx_stride, const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,
                        int nq, int nkv, int hd, int nsplit, float scale, int fuse_rope, const float* cos_t, const float* sin_t,
-                       const float* qpart, int qks, hipStream_t s, const void* next0, size_t bytes0, const void* next1, size_t bytes1) {
+                       const float* qpart, int qks, hipStream_t s) {
     if (hd != 128 || nq != 4 * nkv || nsplit < 1 || B < 1 || !tickets || ctx_stride % 32) return TRACE_ERR_ARG;
-    const Prefetch pf = make_prefetch(next0, bytes0, next1, bytes1);
-    // extra x-blocks per (kv head, sequence): small batches only (a wide batch's attention is HBM-bound itself); ~512 prefetch waves in all
-    const int extra = (pf.bytes[0] && B <= 4) ? std::max(1, 128 / (nkv * B)) : 0;
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit + extra, nkv, B), dim3(256), 0, s, qkv, ldq, kcache, vtcache, slot_stride,
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv, B), dim3(256), 0, s, qkv, ldq, kcache, vtcache, slot_stride,
                        kv_head_stride, ctx_stride, slots, pos, ws, tickets, O, ldo, nq, nkv, nsplit, scale, fuse_rope, cos_t, sin_t,
-                       qpart, qks, g_attn_debug, pf);
+                       qpart, qks, g_attn_debug);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 

@@ -1075,17 +1075,14 @@ static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
                                 nullptr, nullptr, nullptr, 0, s));
         if (e1) hipEventRecord(e1, s);
         TRY(pgemm(c->dO, H, W.wo, W.wo_d, H, H, H, ks_o));
-        // (extra workgroups of the two add_rmsnorm launches touch the head of the weights the next GEMM streams: decode.hip touch_range)
-        LCHK(launch_add_rmsnorm(c->sk_ws, ks_o, c->dX, H, c->dX, H, W.rms2, c->dH, H, B, H, c->c.rms_eps, s, nullptr, nullptr,
-                                (wt & 1) ? (const void*)W.wgu_d : (const void*)W.wgu, (size_t)2 * I * H * 2));
+        LCHK(launch_add_rmsnorm(c->sk_ws, ks_o, c->dX, H, c->dX, H, W.rms2, c->dH, H, B, H, c->c.rms_eps, s));
         if (wt & 1) {
             GemmArgs g{c->dH, H, W.wgu_d, H, c->dACT, I, nullptr, nullptr, 0, B, 2 * I, H, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, wt};
             if (launch_gemm_bf16(g, EPI_SWIGLU, s) != TRACE_OK) return fail(TRACE_ERR_HIP, "gate|up GEMM launch failed");
         } else TRY(gemm(c->dH, H, W.wgu, H, c->dACT, I, nullptr, nullptr, 0, B, 2 * I, H, EPI_SWIGLU, s));
         TRY(pgemm(c->dACT, I, W.wd, W.wd_d, I, H, I, ks_d));
         const bf16_t* nw = l + 1 < c->NL ? c->llm[l + 1].rms1 : c->final_norm;
-        const void* nxt = l + 1 < c->NL ? ((wt & 1) ? (const void*)c->llm[l + 1].wqkv_d : (const void*)c->llm[l + 1].wqkv) : nullptr;
-        LCHK(launch_add_rmsnorm(c->sk_ws, ks_d, c->dX, H, c->dX, H, nw, c->dH, H, B, H, c->c.rms_eps, s, nullptr, nullptr, nxt, (size_t)QKV * H * 2));
+        LCHK(launch_add_rmsnorm(c->sk_ws, ks_d, c->dX, H, c->dX, H, nw, c->dH, H, B, H, c->c.rms_eps, s));
     }
     return head_and_select(c, c->dH, 1, logits_out, s);
 }
@@ -1115,8 +1112,7 @@ static int decode_step_fused(trace_ctx* c, float* logits_out, hipStream_t s) {
         std::swap(xa, xb);
         LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots, c->d_pos, c->dO,
                                 H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, decode_nsplit(B), 1.0f / sqrtf((float)HD), 1,
-                                c->rope_cos, c->rope_sin, c->sk_ws2, ks_q, s,
-                                W.wo_d, (size_t)H * H * 2, W.wgu_d, (size_t)2 * I * H * 2));      // prefetch-only workgroups: the o-proj weights, then the head of gate|up
+                                c->rope_cos, c->rope_sin, c->sk_ws2, ks_q, s));
         LCHK(launch_skinny_gemm(c->dO, H, W.wo_d, H, nullptr, H, nullptr, 0, B, H, H, EPI_PARTIAL, 1, SKWS(c), s));
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (l == 0 && c->profile == 2 && (c->bracket_mask & 2) && s != c->cap_stream && c->kev_used + 2 <= (int)c->kev.size()) {
@@ -1424,7 +1420,6 @@ extern int g_gemm_ldr_opt;
 extern int g_gemm_pers_walk;
 extern int g_gemm_resid_pers;
 extern int g_attn_vit_big;
-extern int g_decode_prefetch_mb;
 extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 1000 && variant <= 1000 + 1024) { g_gemm_pers_grid_cap = variant - 1000; return TRACE_OK; }   // persistent GEMM: at most n workgroups (0 = #CUs)
     if (variant >= 100 && variant < 104) { g_attn_debug = variant - 100; return TRACE_OK; }
@@ -1439,7 +1434,6 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
     if (variant >= 500 && variant <= 501) { g_gemm_pers_walk = variant - 500; return TRACE_OK; }   // the persistent GEMM's tile walk on every route (gemm_pers.hip)
-    if (variant >= 600 && variant <= 600 + 256) { g_decode_prefetch_mb = variant - 600; return TRACE_OK; }   // decode touch-prefetch: MB per latency-bound kernel (0 = off)
     if (variant >= 520 && variant <= 521) { g_gemm_resid_pers = variant - 520; return TRACE_OK; }   // residual GEMMs on the persistent kernel too (auto routing)
     if (variant >= 400 && variant < 404) { g_gemm_ldr_opt = variant - 400; return TRACE_OK; }   // gemm_ldr A/B: bit 0 = no residual touches, bit 1 = no A-panel touches
     if (variant < 0 || variant > 7) return fail(TRACE_ERR_ARG, "variant must be 0..7");

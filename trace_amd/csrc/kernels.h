@@ -161,11 +161,8 @@ int launch_tile_pack(const bf16_t* src, int ldw, bf16_t* dst, int N, int K, hipS
 int launch_swiglu_combine(const float* part, int KS, int N2, bf16_t* out, int ldo, int B, hipStream_t s);
 // x = bf16(sum_ks part[ks][b]) + R[b] -> xout (may alias R); y = RMSNorm(x) * w.  N <= 4096.
 // y8 / sy (optional): y also as e4m3 [B][N] + per-row scale, as launch_quant_rows_fp8(y) would give (fp8 weight path)
-// next_w / next_bytes (optional): what the kernel launched next reads first — extra workgroups of this launch touch it into the Infinity Cache
-// (decode.hip touch_range; g_decode_prefetch_mb caps it)
 int launch_add_rmsnorm(const float* part, int KS, const bf16_t* R, int ldr, bf16_t* xout, int ldx, const bf16_t* w, bf16_t* y,
-                       int ldy, int B, int N, float eps, hipStream_t s, uint8_t* y8 = nullptr, float* sy = nullptr, const void* next_w = nullptr,
-                       size_t next_bytes = 0);
+                       int ldy, int B, int N, float eps, hipStream_t s, uint8_t* y8 = nullptr, float* sy = nullptr);
 // single-query GQA attention over the cache (context = pos[b] + 1 rows, split nsplit ways, <= 128 rows per split).
 // fuse_rope = 1: `qkv` rows are the raw [q | k | v] projections of the new token: q and the new k are rotated here
 // (RoPE at pos[b]) and k/v appended to the cache at row pos[b].  fuse_rope = 0: `qkv` holds ready q rows (ld ldq)
@@ -177,8 +174,7 @@ int launch_qkv_finish(const float* part, int ks, int ldq, bf16_t* qout, bf16_t* 
 int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vtcache, long slot_stride, long kv_head_stride,
                        int ctx_stride, const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,
                        int nq, int nkv, int hd, int nsplit, float scale, int fuse_rope, const float* cos_t, const float* sin_t,
-                       const float* qpart, int qks, hipStream_t s,    // qpart: fp32 partial rows [qks][SK_ROWS][ldq] instead of bf16 qkv
-                       const void* next0 = nullptr, size_t bytes0 = 0, const void* next1 = nullptr, size_t bytes1 = 0);   // batches <= 4: ranges the next kernels read first (touch_range)
+                       const float* qpart, int qks, hipStream_t s);   // qpart: fp32 partial rows [qks][SK_ROWS][ldq] instead of bf16 qkv
 // heads: logits over [text V+1 | time Tv | score Sv] rows of Wh [NV_pad, H]; only tiles intersecting an active
 // head's range are computed.  part: [B, ntiles] (max,idx).  logits_out optional [B, NV] fp32 (masked -inf).
 int launch_head_logits(const bf16_t* X, int ldx, const bf16_t* Wh, int H, const int32_t* heads, int V, int Tv, int Sv,

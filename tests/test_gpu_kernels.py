@@ -118,41 +118,6 @@ def test_gemm_persistent_equals_loader_wave_kernel(M, N, K):
         ops.set_gemm_variant(0)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (9000, 2048, 512), (70000, 1024, 256), (66000, 512, 320), (3934, 4096, 1024)])
-def test_gemm_persistent_register_staged_loaders(M, N, K):
-    """Round 5: the persistent GEMM with register-staged loader waves (trace_op_set_gemm_variant(332): K-tile q + 2 is pulled into the loader waves'
-    registers while K-tile q + 1 sits in LDS — a load has a K-tile period of slack instead of none) against gemm_ldr.hip, bit for bit: every
-    epilogue, ragged M, fewer tiles than CUs, many tiles per workgroup (the load cursor enters the next tile two hand-overs ahead of the hand-over
-    cursor), nk = 4 and 5 (the shortest K loops the form takes), the in-place residual, back-to-back launches; K = 128 keeps the LDS-DMA loaders."""
-    A, W, b, R = rnd(M, K), rnd(N, K, scale=0.05), rnd(N, scale=0.5), rnd(M, N)
-    lib = E._lib.load()
-    try:
-        for epi, kw in ((E.EPI_NONE, dict(bias=b)), (E.EPI_QUICKGELU, dict(bias=b)), (E.EPI_RESIDUAL, dict(bias=b, R=R)), (E.EPI_SWIGLU, {})):
-            ops.set_gemm_variant(300)
-            ops.set_gemm_variant(4)
-            ref = ops.gemm(A, W, epilogue=epi, **kw)
-            ops.set_gemm_variant(332)
-            for v in (5, 6):
-                ops.set_gemm_variant(v)
-                for rep in range(3):
-                    got = ops.gemm(A, W, epilogue=epi, **kw)
-                    assert torch.equal(got, ref), (epi, v, rep, (got.float() - ref.float()).abs().max().item())
-        ops.set_gemm_variant(4)
-        ref = ops.gemm(A, W, R=R, epilogue=E.EPI_RESIDUAL)
-        ops.set_gemm_variant(5)
-        Rc = R.clone()
-        E._lib.check(lib.trace_op_gemm(E._ptr(A), K, E._ptr(W), K, E._ptr(Rc), N, None, E._ptr(Rc), N, M, N, K, E.EPI_RESIDUAL, E._stream()))
-        assert torch.equal(Rc, ref)
-        A2, W2 = rnd(M, 128, seed=5), rnd(N, 128, scale=0.05, seed=6)      # nk = 2: falls back to the LDS-DMA loaders
-        ops.set_gemm_variant(4)
-        ref = ops.gemm(A2, W2, bias=b)
-        ops.set_gemm_variant(5)
-        assert torch.equal(ops.gemm(A2, W2, bias=b), ref)
-    finally:
-        ops.set_gemm_variant(300)
-        ops.set_gemm_variant(0)
-
-
 def test_gemm_persistent_two_streams():
     """Two persistent launches in flight on different streams: each stream has its own ticket counters."""
     M, N, K = 40000, 1024, 256

@@ -20,6 +20,12 @@
 //   * one loader wave also touches the A lines of K-tile kt + 3 into L2 (loader_role): with one K-tile in flight, load latency
 //     would otherwise be the K-tile time on operands that stream from HBM.
 // Same K order, same fp32 -> bf16 roundings as gemm_ldr.hip / gemm.hip: results are bit-identical (tests/test_gpu_kernels.py).
+// Round 5, measured and NOT kept (profiles/r05_gemm_regstage_ab.txt): loader waves that pull K-tile q + 2 into their REGISTERS (global_load_dwordx4) and
+// write it to LDS (ds_write_b128) when hand-over q + 1 has freed the stage — a K-tile period of load slack instead of none.  Bit-identical on hardware
+// at the first attempt and 4-20 % SLOWER on every shape (fc1 775 vs 691 us, qkv 583 vs 489, fc2 729 vs 631, prefill gate|up 777 vs 659): with the
+// operand panels in L2 the K loop is not waiting for load latency (switching the L2 touches off changes the K = 1024 shapes by < 2 %), it is short of LDS
+// bandwidth — 192 KB of fragment reads + 64 KB of tile writes per K-tile against 2048 MFMA cycles — and 16 ds_write_b128 per loader wave and K-tile
+// on top of that cost more than the slack buys.
 #include <mutex>
 #include <unordered_map>
 #include "common.h"
@@ -435,120 +441,6 @@ __device__ __forceinline__ void loader_role(const GemmArgs& p, const Sched& sc, 
 
 }
 
-// ---------------- loader wave, REGISTER-STAGED form (OPT bit 5 = 32; round 5) ----------------
-// loader_role above keeps exactly ONE K-tile in flight: the LDS-DMA pieces of K-tile q + 1 can only be issued when hand-over q has freed their
-// stage, and they must have LANDED by hand-over q + 1 — issue time (64 pieces through the CU's address path, ~31 cycles each = ~2000 cycles)
-// plus the last piece's latency against the K-tile's 2048 MFMA cycles: the K loop runs at load latency, not at MFMA speed (the matrix pipe is
-// busy ~70 % of a K = 1024 tile's K loop; the L2 touches above exist to shorten that latency).  There is no LDS for a third stage — but the
-// loader waves have ~130 idle registers each.  Here a loader wave pulls its 16 pieces of K-tile q + 2 into REGISTERS (global_load_dwordx4)
-// as soon as hand-over q is through, and writes them to LDS (ds_write_b128, lane-linear = the image the LDS-DMA builds, swizzle on the
-// source address as before) right after hand-over q + 1 has freed their stage: a load has a whole K-tile period of slack beyond its issue time
-// instead of none, and what must fit between two hand-overs is a burst of 16 LDS writes per loader wave (data already on chip).
-// The MFMA waves, the LDS layout, the barrier protocol (one per hand-over) and every result bit are unchanged.  No A-panel touches (the loads
-// themselves run two K-tiles ahead); the residual touches stay, issued behind the loads of the tile's last hand-over — the next wait for
-// loaded registers then also waits for them, at the one hand-over per tile that has an epilogue of slack.  Needs nk >= 4 (the load cursor
-// enters the next tile two hand-overs before the hand-over cursor, and the next tile's index is published at hand-over 1).
-template <int EPI>
-__device__ __forceinline__ void loader_role_rs(const GemmArgs& p, const Sched& sc, char* smem, int* ctr, int dynamic, int lw, int tid, int lane) {
-    constexpr bool GLU = (EPI == EPI_SWIGLU);
-    constexpr bool RTOUCH = EPI == EPI_RESIDUAL;
-    int* s_next = reinterpret_cast<int*>(smem + CTL_OFF);
-    const int ntm = sc.ntm, ntn = sc.ntn, nk = sc.nk, xcd = sc.xcd, cnt = sc.cnt, base = sc.base, nwg = sc.nwg;
-    const bool isA = lw < 2;
-    const int half = (lw & 1) * 128;
-    char* const wbase = smem + (isA ? 0 : A_BYTES) + half * 128 + lane * 16;       // this lane's slot in piece 0 of its region, stage 0
-    // operand rows as 32-bit byte offsets from a wave-uniform base (scalar base + one offset register per piece; the launcher checks the range)
-    const char* const gbase = isA ? reinterpret_cast<const char*>(p.A) : reinterpret_cast<const char*>(p.W);
-    uint32_t src[16];
-    u32x4 R[16];
-    uint2 bias2 = make_uint2(0u, 0u);
-    int h_li = sc.slot, kt = 0, n = 0, q = 0, ticket = 0;          // hand-over cursor: tile h_li (the n-th of this workgroup), K-tile kt; stream position q
-    int l_kt = 0;                                                  // load cursor's K-tile (its tile's pointers are in src)
-    bool l_live = true;                                            // the load cursor has not run off the last tile
-    int hm0 = 0, hn0 = 0;                                          // the hand-over tile's origin (residual touches)
-#define RS_SETUP(LI)                                                                                                                   \
-    {                                                                                                                                  \
-        int tm_, tn_;                                                                                                                  \
-        tile_coords(base + (LI), ntm, ntn, tm_, tn_);                                                                                  \
-        const int m0_ = tm_ * BM, n0_ = tn_ * BN;                                                                                      \
-        _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                                               \
-            const int row = half + j * 8 + (lane >> 3);                                                                                \
-            const int kc = (lane & 7) ^ ((row >> 1) & 7);                                                                              \
-            src[j] = isA ? ((uint32_t)min(m0_ + row, p.M - 1) * (uint32_t)p.lda + kc * 8) * 2u                                         \
-                         : ((uint32_t)(n0_ + row) * (uint32_t)p.ldw + kc * 8) * 2u;                                                    \
-        }                                                                                                                              \
-    }
-#define RS_LOAD(KO)                                                                                                                    \
-    { const char* gk_ = gbase + (size_t)(KO);                                                                                          \
-      _Pragma("unroll") for (int j = 0; j < 16; ++j) R[j] = *reinterpret_cast<const u32x4*>(gk_ + (size_t)src[j]); }
-#define RS_WRITE(STG)                                                                                                                  \
-    { char* dst_ = wbase + (STG) * STAGE;                                                                                              \
-      _Pragma("unroll") for (int j = 0; j < 16; ++j) *reinterpret_cast<u32x4*>(dst_ + j * 1024) = R[j]; }
-    RS_SETUP(h_li);
-    { int tm_, tn_; tile_coords(base + h_li, ntm, ntn, tm_, tn_); hm0 = tm_ * BM; hn0 = tn_ * BN; }
-    RS_LOAD(0);
-    RS_WRITE(0);                                                    // K-tile 0 of the first tile -> stage 0 (waits for its loads)
-    l_kt = 1;
-    RS_LOAD(128);                                                   // K-tile 1 -> registers
-    while (true) {
-        // ---- hand-over of stream position q = (tile h_li, K-tile kt): its ds_writes were issued one iteration ago (or above)
-        // this tile's bias row (zeros without a bias), read by the MFMA waves after the K loop: requested behind hand-over 0, parked before hand-over 2
-        // (kept in a register from the tile's set-up on, it made hipcc wait for ALL the loads in flight at the tile boundary)
-        if (kt == 2 && !GLU && lw == 3) *reinterpret_cast<uint2*>(smem + BIAS_OFF + (n & 1) * 512 + lane * 8) = bias2;
-        if (kt == 1 && tid == NMT) {                                // the tile after this one (read from hand-over 1 on: by this wave's load cursor at nk - 2)
-            s_next[(n + 1) & 1] = dynamic ? nwg + ticket : h_li + nwg;
-            if (dynamic && ticket == cnt - 1) (void)atomicExch(ctr + xcd * CTR_STRIDE, 0);       // the launch's last ticket re-arms the counter (loader_role)
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the K-tile's LDS writes (and the two above) have been performed
-        __builtin_amdgcn_s_barrier();                               // position q handed over; the stage of q - 1 is free
-        asm volatile("" ::: "memory");
-        if (kt == 0 && dynamic && tid == NMT) ticket = atomicAdd(ctr + xcd * CTR_STRIDE, 1);
-        if (kt == 0 && !GLU && lw == 3 && p.bias) bias2 = *reinterpret_cast<const uint2*>(p.bias + hn0 + lane * 4);
-        if (l_live) {
-            RS_WRITE((q + 1) & 1);                                  // position q + 1: registers -> the stage just freed
-            if (l_kt + 1 < nk) {
-                ++l_kt;
-                RS_LOAD(l_kt * 128);                                // position q + 2
-            } else {
-                // the load cursor leaves the tile at hand-over nk - 2 >= 2: the next tile's index was published before hand-over 1
-                const int nx = __builtin_amdgcn_readfirstlane(s_next[(n + 1) & 1]);
-                if (nx < cnt) {
-                    l_kt = 0;
-                    RS_SETUP(nx);
-                    RS_LOAD(0);
-                } else {
-                    l_live = false;
-                }
-            }
-        }
-        // (the next tile's index is read BEFORE the touches: hipcc guards an LDS read behind an LDS-DMA with vmcnt(0), i.e. with a wait for this
-        // iteration's loads as well)
-        int nx_h = 0;
-        if (kt == nk - 1) nx_h = __builtin_amdgcn_readfirstlane(s_next[(n + 1) & 1]);
-        if (RTOUCH && kt == nk - 1) {
-            // residual touches of the tile whose last K-tile has just been handed over (loader_role / gemm_ldr.hip), BEHIND this iteration's loads
-            const int L = lw * 64 + lane;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int idx = L + t * 256, row = idx >> 2, seg = idx & 3;
-                const bf16_t* ra = p.R + (size_t)min(hm0 + row, p.M - 1) * p.ldr + hn0 + seg * 64;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ra,
-                                                 (__attribute__((address_space(3))) void*)(smem + TOUCH_OFF + lw * 256), 4, 0, 0);
-            }
-        }
-        ++q;
-        if (++kt == nk) {
-            if (nx_h >= cnt) break;
-            h_li = nx_h; kt = 0; ++n;
-            { int tm_, tn_; tile_coords(base + h_li, ntm, ntn, tm_, tn_); hm0 = tm_ * BM; hn0 = tn_ * BN; }
-        }
-    }
-#undef RS_SETUP
-#undef RS_LOAD
-#undef RS_WRITE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no touch of this wave may still be in flight when the workgroup's LDS is released
-}
-
 template <int EPI, int OPT>
 __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, int dynamic) {
     constexpr bool GLU = (EPI == EPI_SWIGLU);
@@ -558,8 +450,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pers_kernel(GemmArgs p, int* ctr, i
     const Sched sc = make_sched(p);
     const int ntn = sc.ntn, ntm = sc.ntm, nk = sc.nk, slot = sc.slot, cnt = sc.cnt, base = sc.base;
     if (wid >= WM * WN) {
-        if constexpr ((OPT & 32) != 0) loader_role_rs<EPI>(p, sc, smem, ctr, dynamic, wid - WM * WN, tid, lane);
-        else loader_role<EPI, OPT>(p, sc, smem, ctr, dynamic, wid - WM * WN, tid, lane);
+        loader_role<EPI, OPT>(p, sc, smem, ctr, dynamic, wid - WM * WN, tid, lane);
         return;
     }
 
@@ -690,10 +581,6 @@ int g_opt = 0;
 template <int EPI>
 void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
     switch (g_opt) {
-        case 32:                                   // register-staged loaders (need nk >= 4 and 32-bit operand byte offsets; other shapes keep the LDS-DMA loaders)
-            if (p.K >= 4 * BK && (size_t)p.M * p.lda * 2 < (1ull << 32) && (size_t)p.N * p.ldw * 2 < (1ull << 32)) launch_opt<EPI, 32>(p, nblk, dynamic, ctr, s);
-            else launch_opt<EPI, 0>(p, nblk, dynamic, ctr, s);
-            break;
         case 2: launch_opt<EPI, 2>(p, nblk, dynamic, ctr, s); break;
         case 4: launch_opt<EPI, 4>(p, nblk, dynamic, ctr, s); break;
         case 8: launch_opt<EPI, 8>(p, nblk, dynamic, ctr, s); break;

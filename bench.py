@@ -111,6 +111,8 @@ CONFIGS = {
                name="C4: Charades-STA moment retrieval shape, TRACE-7B bf16"),
     "c5": dict(frames=256, max_new=16, n_text=251, video_pos=200, schedule="dvc", videos_per_step=32, fp8=True,
                name="C5: VideoMME long video (256 frames, past MAX_FRAMES), TRACE-7B, fp8 (e4m3 W8A8) decoder projections"),
+    "stc": dict(frames=16, max_new=0, n_text=0, video_pos=0, schedule="none", videos_per_step=1,
+                name="STC connector (legacy trace.infer path) at its real shape: 16 frames x 24x24 patches, 1024 -> 4096 channels -> 9 x 13 x 13 tokens"),
 }
 
 
@@ -227,6 +229,57 @@ def run_c1(args) -> None:
     shutil.rmtree(tmp, ignore_errors=True)
 
 
+def stc_flops(T: int, G: int, cin: int, H: int) -> dict:
+    """algorithmic FLOPs of one STCConnector.forward (projector/builder.py:208-249) by part: the 1x1 convolutions of the two RegStages (timm Bottleneck:
+    conv1, conv3 and, in a stage's first block when the width changes, the shortcut conv), the Conv3d sampler as a GEMM, the readout MLP; the depthwise
+    3x3 convolutions and the squeeze-excite GEMVs are counted too (VALU / GEMV work, not MFMA)."""
+    rows1, To, Go = T * G * G, T // 2 + 1, G // 2 + 1
+    rows2 = To * Go * Go
+    s1 = 2.0 * rows1 * H * cin * 2 + 2.0 * rows1 * H * H + 3 * 2 * 2.0 * rows1 * H * H      # block 0: conv1 + shortcut (cin -> H), conv3; blocks 1-3: conv1, conv3
+    s2 = 4 * 2 * 2.0 * rows2 * H * H
+    return {"s1_convs": s1, "sampler": 2.0 * rows2 * H * 8 * H, "s2_convs": s2, "readout": 2 * 2.0 * rows2 * H * H,
+            "depthwise": 2.0 * 9 * H * (4 * rows1 + 4 * rows2), "squeeze_excite": 8 * 2 * 2.0 * max(T, To) * H * (H // 4), "rows1": rows1, "rows2": rows2}
+
+
+def run_stc(args) -> None:
+    """`--config stc`: the STC connector at the shape the reference builds it with (mm_hidden 1024 -> hidden 4096, 24 x 24 patch grid, 16
+    frames -> (16 / 2 + 1) x 13 x 13 = 1521 tokens), on patch features resident in HBM: ms per call, TFLOP/s and the fraction of the bf16 MFMA peak over the
+    connector's GEMM work.  Weights are synthetic (device RNG); the RegStage block is the restated one (timm is not importable offline: DESIGN section 2)."""
+    import dataclasses
+    from trace_amd.engine import TraceEngine
+    if not torch.cuda.is_available():
+        raise SystemExit("--config stc needs an MI355X (the HIP path has no CPU fallback)")
+    T = args.frames
+    cfg = dataclasses.replace(tcfg.trace_7b(T), mm_projector_type="stc_connector", num_hidden_layers=1, vision_num_layers=2)    # the LLM and the tower are not run here
+    eng = TraceEngine(cfg, device=0, max_batch=1, max_ctx=2048, max_frames=T, max_new_tokens=8)
+    eng.load_weights(synth.iter_weights(cfg, device="cuda"))
+    feats = (torch.randn(T, cfg.vision_patches, cfg.vision_hidden_size, device="cuda") * 1.0).to(torch.bfloat16)
+    for _ in range(max(1, args.warmup)):
+        out = eng.stc_connector(feats, T)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.steps):
+        out = eng.stc_connector(feats, T)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.steps
+    fl = stc_flops(T, cfg.vision_grid, cfg.mm_hidden_size, cfg.hidden_size)
+    gemm_fl = fl["s1_convs"] + fl["sampler"] + fl["s2_convs"] + fl["readout"]
+    tf = gemm_fl / (ms * 1e-3) / 1e12
+    print(json.dumps({
+        "metric": "STC connector, ms per 16-frame clip (auxiliary line: SURVEY row a11)", "value": ms, "unit": "ms/call", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": CONFIGS["stc"]["name"], "frames": T, "tokens_out": int(out.shape[0]), "rows_stage1": fl["rows1"], "rows_stage2": fl["rows2"],
+                   "weights": "random-init (device RNG); RegStage block restated (timm unavailable offline)"},
+        "roofline": {"bound": "mfma", "kernel": "the connector's GEMMs together (1x1 convolutions of both RegStages, Conv3d sampler as an im2col GEMM, readout MLP) over the WHOLE call, elementwise passes included in the time",
+                     "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None,
+                     "algorithmic_gflop_per_call": gemm_fl / 1e9,
+                     "gflop_by_part": {k: v / 1e9 for k, v in fl.items() if k not in ("rows1", "rows2")}},
+        "finite": bool(torch.isfinite(out).all())}), flush=True)
+    eng.close()
+
+
 def self_launch(args) -> None:
     """`python bench.py --gpus N` with no launcher around it: start one rank per GPU ourselves (the driver's own N > 1 invocation,
     `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, sets WORLD_SIZE and never gets here)."""
@@ -287,9 +340,9 @@ def main():
                          "— the step is GPU-bound — and allow the per-launch HIP-event roofline probe in the timed region)")
     ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=True,
                     help="(the default since round 4) two-stage pipeline over the timed steps — batch k decodes on one stream while batch k+1 runs its ViT + prefill "
-                         "on another (TraceEngine.generate_stream): +2-3 %% videos/s.  Round 3 kept it off: over ~100 pipelined steps one video's ViT features came "
-                         "out different a few times — the persistent GEMM's ticket counter was re-armed with a plain store; it is an agent-scope atomic now "
-                         "(profiles/r04_pipeline_stress.txt: the old form differs, the new one does not)")
+                         "on another (TraceEngine.generate_stream): +2-3 %% videos/s.  Round 3 kept it off: over ~100 pipelined steps one video's ViT features "
+                         "did not repeat step 0 a few times; rounds 3-4 traced that to the configuration with the ViT's LayerNorm fold on (8 of 866 steps with it, 0 of 392 "
+                         "without: profiles/r04_pipeline_stress_*.txt); the fold was never root-caused and left the product in round 5")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="timed steps strictly one after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
@@ -312,6 +365,10 @@ def main():
         if args.gpus != 1:
             raise SystemExit("--config c1 is the single-clip plumbing case: one process, at most one GPU")
         return run_c1(args)
+    if args.config == "stc":
+        if args.gpus != 1:
+            raise SystemExit("--config stc times one connector call shape on one GPU")
+        return run_stc(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)                                       # never returns
 

@@ -571,21 +571,11 @@ __device__ __forceinline__ void mfma16_from(f32x4_t& d, const bf16x8_t& a, const
 // threshold compare like the floats (negative scores are negative integers, NaNs land above everything -> the slow path), which is all the fast path
 // needs; the slow path takes its exact maxima with fmaxf.
 __device__ __forceinline__ int imax3(int a, int b, int c) { return max(max(a, b), c); }
-__device__ __forceinline__ int bits_max16(const f32x4_t& a, const f32x4_t& b, const f32x4_t& c, const f32x4_t& d) {
+__device__ __forceinline__ int bits_max8(const f32x4_t& a, const f32x4_t& b) {
     int r = imax3(__float_as_int(a[0]), __float_as_int(a[1]), __float_as_int(a[2]));
     r = imax3(r, __float_as_int(a[3]), __float_as_int(b[0]));
     r = imax3(r, __float_as_int(b[1]), __float_as_int(b[2]));
-    r = imax3(r, __float_as_int(b[3]), __float_as_int(c[0]));
-    r = imax3(r, __float_as_int(c[1]), __float_as_int(c[2]));
-    r = imax3(r, __float_as_int(c[3]), __float_as_int(d[0]));
-    r = imax3(r, __float_as_int(d[1]), __float_as_int(d[2]));
-    return max(r, __float_as_int(d[3]));
-}
-__device__ __forceinline__ float fmax16(const f32x4_t& a, const f32x4_t& b, const f32x4_t& c, const f32x4_t& d) {
-    float r = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
-    r = fmaxf(r, fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
-    r = fmaxf(r, fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])));
-    return fmaxf(r, fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3])));
+    return max(r, __float_as_int(b[3]));
 }
 // LDS transpose reads as inline asm.  Through the builtin, hipcc's wait-count pass cannot tell the read from the LDS-DMA writes in flight and puts an
 // s_waitcnt vmcnt(0) in front of the first one of every tile — i.e. the wave waits for ALL the tiles it has prefetched before it may read the
@@ -603,7 +593,7 @@ __device__ __forceinline__ void tr_wait(u32x2_t (&v)[4][2]) {
 }
 
 template <int NST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_vit_big_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_vit_big_kernel(AttnArgs a) {
     constexpr int HD = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -688,23 +678,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- LDS-DMA: per tile 8 K pieces (8 rows x 128 B, XOR-swizzled on the source) + 8 V pieces (16 keys x 64 B of one d-half, halves swapped
     //      for odd key quads); wave w issues pieces 2 w, 2 w + 1 of each
-    const bf16_t* ksrc[2];
-    const bf16_t* vsrc[2];
+    // (sources as 32-bit byte offsets from the wave-uniform head bases: scalar base + one offset register per piece — as 64-bit pointers the four of
+    // them were what the 168-register build spilled and reloaded in every tile)
+    uint32_t ksrc[2], vsrc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int pi = 2 * wid + j;
         const int kr = pi * 8 + (lane >> 3);
-        ksrc[j] = kbase + (size_t)kr * a.k_rs + (((lane & 7) ^ ((kr >> 1) & 7)) << 3);
+        ksrc[j] = ((uint32_t)kr * (uint32_t)a.k_rs + (uint32_t)(((lane & 7) ^ ((kr >> 1) & 7)) << 3)) * 2u;
         const int vkey = (pi & 3) * 16 + (lane >> 2);
-        vsrc[j] = vbase + (size_t)vkey * a.vr_rs + (pi >> 2) * 32 + (((lane & 3) ^ (((vkey >> 2) & 1) << 1)) << 3);
+        vsrc[j] = ((uint32_t)vkey * (uint32_t)a.vr_rs + (uint32_t)((pi >> 2) * 32 + (((lane & 3) ^ (((vkey >> 2) & 1) << 1)) << 3))) * 2u;
     }
-    const long kstep = (long)BKV * a.k_rs, vstep = (long)BKV * a.vr_rs;
+    const size_t kstep = (size_t)BKV * a.k_rs * 2, vstep = (size_t)BKV * a.vr_rs * 2;      // bytes per key tile
     auto issue = [&](int t, int stage) {
         char* st = smem + stage * BSTAGE + (2 * wid) * 1024;
+        const char* kt_ = reinterpret_cast<const char*>(kbase) + (size_t)t * kstep;
+        const char* vt_ = reinterpret_cast<const char*>(vbase) + (size_t)t * vstep;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            glds16(ksrc[j] + (size_t)t * kstep, st + j * 1024);
-            glds16(vsrc[j] + (size_t)t * vstep, st + 8192 + j * 1024);
+            glds16(reinterpret_cast<const bf16_t*>(kt_ + (size_t)ksrc[j]), st + j * 1024);
+            glds16(reinterpret_cast<const bf16_t*>(vt_ + (size_t)vsrc[j]), st + 8192 + j * 1024);
         }
     };
 #pragma unroll
@@ -811,58 +804,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (t + NST - 1 < nt && a.dbg != 1) issue(t + NST - 1, stage_n);
         if (a.dbg != 2) {
             const char* kb = smem + stage * BSTAGE;
-            // ---- S^T = K . Q^T - m
-            f32x4_t S[4][3];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bf16x8_t kf0 = *reinterpret_cast<const bf16x8_t*>(kb + j * 2048 + koff);
-                const bf16x8_t kf1 = *reinterpret_cast<const bf16x8_t*>(kb + j * 2048 + (koff ^ 64));
-#pragma unroll
-                for (int i = 0; i < 3; ++i) mfma16_from(S[j][i], kf0, qf[i][0], cinit[i]);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) S[j][i] = mfma16(kf1, qf[i][1], S[j][i]);
-            }
-            // ---- does any row need its reference moved?  (integer compare of the bit patterns; the exact row maxima are taken inside the slow path)
-            const int over = imax3(bits_max16(S[0][0], S[1][0], S[2][0], S[3][0]), bits_max16(S[0][1], S[1][1], S[2][1], S[3][1]),
-                                   bits_max16(S[0][2], S[1][2], S[2][2], S[3][2]));
-            if (__any(first || over > __float_as_int(BIG_THR))) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const float mloc = fmax16(S[0][i], S[1][i], S[2][i], S[3][i]);
-                    float mx = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                    const bool need = first || mx > BIG_THR;     // the same in the four lanes of a query row
-                    const float d = need ? mx : 0.f;
-                    const float f = first ? 0.f : __builtin_amdgcn_exp2f(-d);       // (first tile: O = l = 0, and 2^-d may overflow)
-                    m[i] += d;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) lacc[i][e] *= f;
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) oacc[dt][i][e] *= f;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) S[j][i][e] -= d;
-                    const float ci = -m[i];
-                    cinit[i] = f32x4_t{ci, ci, ci, ci};
-                }
-                first = false;
-            }
-            // ---- p = 2^S, O^T += V^T . P, l += 1 . P
+            // the tile in two halves of 32 keys (kv-tiles 2 kp, 2 kp + 1): only 24 score registers are live at a time — with the whole tile's 48 the kernel
+            // needs 192 registers = two waves per SIMD, and its first hardware run (profiles/r05_attn_big_first_run.txt, r05_pmc_attn.txt) was 23 % SLOWER
+            // than the 4 x 32-row kernel although it issues 13 % fewer instructions: a workgroup lives for 9 key tiles, its prologue / epilogue / dispatch
+            // bubbles only hide under other resident workgroups, and two per CU (issue slots 43 % busy against 73 %) are not enough
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
-                // the 8 V fragments of this key-tile pair first: their LDS latency runs under the exponentials
+                // ---- S^T = K . Q^T - m for 32 keys
+                f32x4_t S[2][3];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * kp + jj;
+                    const bf16x8_t kf0 = *reinterpret_cast<const bf16x8_t*>(kb + j * 2048 + koff);
+                    const bf16x8_t kf1 = *reinterpret_cast<const bf16x8_t*>(kb + j * 2048 + (koff ^ 64));
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) mfma16_from(S[jj][i], kf0, qf[i][0], cinit[i]);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) S[jj][i] = mfma16(kf1, qf[i][1], S[jj][i]);
+                }
+                // the V fragments of these keys: their LDS latency runs under the checks and exponentials below
                 u32x2_t vq[4][2];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
                     tr_read2(vq[dt][0], vq[dt][1], vlds + stage * BSTAGE + (dt >> 1) * 4096 + (2 * kp) * 1024 + ((dt & 1) ? vtr1 : vtr0));
+                // ---- does any row need its reference moved?  (integer compare of the bit patterns; the exact row maxima are taken inside the slow path)
+                const int over = imax3(bits_max8(S[0][0], S[1][0]), bits_max8(S[0][1], S[1][1]), bits_max8(S[0][2], S[1][2]));
+                if (__any(first || over > __float_as_int(BIG_THR))) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float mloc = fmaxf(fmaxf(fmaxf(S[0][i][0], S[0][i][1]), fmaxf(S[0][i][2], S[0][i][3])),
+                                                 fmaxf(fmaxf(S[1][i][0], S[1][i][1]), fmaxf(S[1][i][2], S[1][i][3])));
+                        float mx = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+                        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                        const bool need = first || mx > BIG_THR;     // the same in the four lanes of a query row
+                        const float d = need ? mx : 0.f;
+                        const float f = first ? 0.f : __builtin_amdgcn_exp2f(-d);       // (first keys: O = l = 0, and 2^-d may overflow)
+                        m[i] += d;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) lacc[i][e] *= f;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) oacc[dt][i][e] *= f;
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) S[jj][i][e] -= d;
+                        const float ci = -m[i];
+                        cinit[i] = f32x4_t{ci, ci, ci, ci};
+                    }
+                    first = false;
+                }
+                // ---- p = 2^S, O^T += V^T . P, l += 1 . P
                 union { bf16x8_t v; uint32_t u[4]; } pf[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    const f32x4_t& s0 = S[2 * kp][i];
-                    const f32x4_t& s1 = S[2 * kp + 1][i];
+                    const f32x4_t& s0 = S[0][i];
+                    const f32x4_t& s1 = S[1][i];
                     pf[i].u[0] = pack2bf(__builtin_amdgcn_exp2f(s0[0]), __builtin_amdgcn_exp2f(s0[1]));
                     pf[i].u[1] = pack2bf(__builtin_amdgcn_exp2f(s0[2]), __builtin_amdgcn_exp2f(s0[3]));
                     pf[i].u[2] = pack2bf(__builtin_amdgcn_exp2f(s1[0]), __builtin_amdgcn_exp2f(s1[1]));

@@ -16,12 +16,12 @@ names = {190: "4 x 32-row kernel", 191: "192-row kernel, 4-stage ring", 192: "19
 KO = {110: "full kernel", 111: "no K/V loads after the first tiles", 112: "no tile math (loads + barriers only)"}
 if "--knockout" in sys.argv:          # where the time goes: knock-out runs of both kernels (trace_op_set_gemm_variant(111 / 112))
     q, k, v = rnd(170, 577, 16, 64), rnd(170, 577, 16, 64), rnd(170, 577, 16, 64)
-    for var in (190, 191):
+    for var in (190, 191, 192):
         ops.set_gemm_variant(var)
         for ko, kn in KO.items():
             ops.set_gemm_variant(ko)
             print(f"frames=170 {names[var]}, {kn}: {timed(lambda: ops.attention(q, k, v, False, 0.125)):.1f} us", flush=True)
-    ops.set_gemm_variant(110); ops.set_gemm_variant(191)
+    ops.set_gemm_variant(110); ops.set_gemm_variant(192)
     sys.exit(0)
 for Bn in (170, 32):
     q, k, v = rnd(Bn, 577, 16, 64), rnd(Bn, 577, 16, 64), rnd(Bn, 577, 16, 64)
@@ -31,7 +31,7 @@ for Bn in (170, 32):
             ops.set_gemm_variant(var)
             if r == 0: outs[var] = ops.attention(q, k, v, False, 0.125)
             ts[var].append(timed(lambda: ops.attention(q, k, v, False, 0.125)))
-    ops.set_gemm_variant(191)
+    ops.set_gemm_variant(192)
     fl = 4.0 * Bn * 16 * 577 * 577 * 64
     for var, name in names.items():
         t = statistics.median(ts[var][1:])

@@ -614,28 +614,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const bf16_t* vbase = a.Vrow + (size_t)b * a.vr_bs + (size_t)kvh * a.vr_hs;
         float* pl = reinterpret_cast<float*>(smem + wid * (BIG_MAXKV * 4));
         const int nit = (a.nkv_rows + 63) >> 6;
+        // (First version: lane = d with one 2-byte load per key and lane — 577 dependent load round trips per wave, ~100 us; those workgroups then held
+        // ~30 % of the CU slots of the launch.  Now every load is 16 bytes and eight of them are in flight per lane.)
         for (int rr = 0; rr < nleft; ++rr) {
             const int row = nqb * BIG_ROWS + rr;
             const bf16_t* qp = a.Q + (size_t)b * a.q_bs + (size_t)kvh * a.q_hs + (size_t)row * a.q_rs;
             uint4 qv[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) qv[c] = *reinterpret_cast<const uint4*>(qp + c * 8);
+            // scores of keys it * 64 + lane (exp2 domain): the lane's own 128-byte K row, 8 loads in flight
             float mx = -3.0e38f;
-            for (int it = 0; it < nit; ++it) {                  // scores of keys it * 64 + lane (exp2 domain)
+            for (int it = 0; it < nit; ++it) {
                 const int key = it * 64 + lane;
-                float dot = 0.f;
-                if (key < a.nkv_rows) {
-                    const bf16_t* kp = kbase + (size_t)key * a.k_rs;
+                const bf16_t* kp = kbase + (size_t)min(key, a.nkv_rows - 1) * a.k_rs;
+                uint4 kk[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const uint4 kk = *reinterpret_cast<const uint4*>(kp + c * 8);
-                        dot = dot2_el(qv[c].x, kk.x, dot); dot = dot2_el(qv[c].y, kk.y, dot);
-                        dot = dot2_el(qv[c].z, kk.z, dot); dot = dot2_el(qv[c].w, kk.w, dot);
-                    }
-                    dot *= sc;
-                    mx = fmaxf(mx, dot);
-                    pl[key] = dot;
+                for (int c = 0; c < 8; ++c) kk[c] = *reinterpret_cast<const uint4*>(kp + c * 8);
+                float dot = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    dot = dot2_el(qv[c].x, kk[c].x, dot); dot = dot2_el(qv[c].y, kk[c].y, dot);
+                    dot = dot2_el(qv[c].z, kk[c].z, dot); dot = dot2_el(qv[c].w, kk[c].w, dot);
                 }
+                dot *= sc;
+                if (key < a.nkv_rows) { mx = fmaxf(mx, dot); pl[key] = dot; }
             }
             mx = wave_max(mx);
             float ls = 0.f;
@@ -649,19 +651,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
             ls = wave_sum(ls);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's LDS writes precede its reads below (one in-order LDS queue per wave)
-            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;   // lane = d: O[d] = sum_key p[key] V[key][d]
-            const bf16_t* vp = vbase + lane;
-            int key = 0;
-            for (; key + 4 <= a.nkv_rows; key += 4) {
-                const float4 p4 = *reinterpret_cast<const float4*>(pl + key);       // same address in every lane: an LDS broadcast
-                acc0 = fmaf(p4.x, bf2f(vp[(size_t)(key + 0) * a.vr_rs]), acc0);
-                acc1 = fmaf(p4.y, bf2f(vp[(size_t)(key + 1) * a.vr_rs]), acc1);
-                acc2 = fmaf(p4.z, bf2f(vp[(size_t)(key + 2) * a.vr_rs]), acc2);
-                acc3 = fmaf(p4.w, bf2f(vp[(size_t)(key + 3) * a.vr_rs]), acc3);
+            // O[d] = sum_key p[key] V[key][d]: lane (kg = lane >> 3, c = lane & 7) takes keys kg, kg + 8, ... and d = 8 c .. 8 c + 7 (16-byte loads: a wave
+            // instruction covers 8 whole V rows), eight keys per lane in flight; the eight key groups are summed across lanes at the end (fixed order)
+            const int kg = lane >> 3, c8 = lane & 7;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            const bf16_t* vp = vbase + c8 * 8;
+            for (int k0 = 0; k0 < a.nkv_rows; k0 += 64) {
+                uint4 vv[8];
+                float pp[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int key = k0 + u * 8 + kg;
+                    const int kc = min(key, a.nkv_rows - 1);
+                    vv[u] = *reinterpret_cast<const uint4*>(vp + (size_t)kc * a.vr_rs);
+                    pp[u] = key < a.nkv_rows ? pl[kc] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc[0] = fmaf(pp[u], bflo(vv[u].x), acc[0]); acc[1] = fmaf(pp[u], bfhi(vv[u].x), acc[1]);
+                    acc[2] = fmaf(pp[u], bflo(vv[u].y), acc[2]); acc[3] = fmaf(pp[u], bfhi(vv[u].y), acc[3]);
+                    acc[4] = fmaf(pp[u], bflo(vv[u].z), acc[4]); acc[5] = fmaf(pp[u], bfhi(vv[u].z), acc[5]);
+                    acc[6] = fmaf(pp[u], bflo(vv[u].w), acc[6]); acc[7] = fmaf(pp[u], bfhi(vv[u].w), acc[7]);
+                }
             }
-            for (; key < a.nkv_rows; ++key) acc0 = fmaf(pl[key], bf2f(vp[(size_t)key * a.vr_rs]), acc0);
-            const float o = ((acc0 + acc1) + (acc2 + acc3)) / ls;
-            a.O[(size_t)b * a.o_bs + (size_t)kvh * a.o_hs + (size_t)row * a.o_rs + lane] = f2bf(o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                acc[e] += __shfl_xor(acc[e], 8, 64);
+                acc[e] += __shfl_xor(acc[e], 16, 64);
+                acc[e] += __shfl_xor(acc[e], 32, 64);
+            }
+            if (kg == 0) {
+                const float inv = 1.f / ls;
+                uint4 o;
+                o.x = pack2bf(acc[0] * inv, acc[1] * inv); o.y = pack2bf(acc[2] * inv, acc[3] * inv);
+                o.z = pack2bf(acc[4] * inv, acc[5] * inv); o.w = pack2bf(acc[6] * inv, acc[7] * inv);
+                *reinterpret_cast<uint4*>(a.O + (size_t)b * a.o_bs + (size_t)kvh * a.o_hs + (size_t)row * a.o_rs + c8 * 8) = o;
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the next row overwrites pl)
         }
         return;
@@ -962,12 +989,13 @@ bool attn_vit_wants_perm(int nkv_rows, bool has_vrow) {
     return (g_attn_pf_debug < 5 || g_attn_pf_debug == 6) && nkv_rows >= 2 * BKV && (rem == 0 || (has_vrow && rem <= TAILV));
 }
 
-int g_attn_vit_big = 1;    // the round-5 192-row kernel for shapes it takes (trace_op_set_gemm_variant(190 + x): 0 = the 4 x 32-row kernel, 1 = 4-stage ring, 2 = 3-stage ring)
+int g_attn_vit_big = 2;    // the round-5 192-row kernel for shapes it takes (trace_op_set_gemm_variant(190 + x): 0 = the 4 x 32-row kernel, 1 = 4-stage ring (two workgroups
+                           // per CU), 2 = 3-stage ring (three per CU: the default))
 // v_perm == 2 (row-major V), >= 192 query rows of which 192 leaves at most BIG_MAXLEFT over, whole key tiles + a short tail, keys fit the leftover path's LDS rows
 static bool attn_vit_big_ok(const AttnArgs& a) {
     return g_attn_vit_big && a.v_perm == 2 && !a.causal && a.nq_rows >= BIG_ROWS && a.nq_rows % BIG_ROWS <= BIG_MAXLEFT && a.nkv_rows >= BKV &&
            a.nkv_rows % BKV <= TAILV && a.nkv_rows <= BIG_MAXKV && !(a.q_rs % 8) && !(a.q_hs % 8) && !(a.q_bs % 8) && !(a.k_rs % 8) && !(a.k_hs % 8) &&
-           !(a.k_bs % 8) && !(a.o_rs % 4) && !(a.o_hs % 4) && !(a.o_bs % 4);
+           !(a.k_bs % 8) && !(a.o_rs % 8) && !(a.o_hs % 8) && !(a.o_bs % 8);
 }
 int launch_attn_vit(const AttnArgs& a_, hipStream_t s) {
     AttnArgs a = a_;

@@ -164,6 +164,11 @@ def write_y4m(path: str, frames_rgb: np.ndarray, fps: Tuple[int, int] = (25, 1),
                 f.write(p.tobytes())
 
 
+class NeedsDecoder(ValueError):
+    """The container is well-formed but its video stream is inter-coded (H.264, MPEG-4, VP9, ...): not something these readers decode.
+    open_container() hands such a file to decord, exactly as the reference does for every file (mm_utils.py:421)."""
+
+
 # ---------------------------------------------------------------------------------------------------------------- AVI (MJPG / DIB)
 def _riff_chunks(buf: memoryview, start: int, end: int):
     """(fourcc, payload start, payload size) of every chunk in [start, end); LIST chunks are yielded with their list type appended"""
@@ -176,8 +181,9 @@ def _riff_chunks(buf: memoryview, start: int, end: int):
 
 
 class AviReader:
-    """AVI 1.0 with one video stream of independent frames: Motion-JPEG ('MJPG' and its aliases) or uncompressed 24-bit BGR ('DIB ', BI_RGB,
-    bottom-up).  Inter-coded streams (H.264, MPEG-4, ...) are refused with the reason."""
+    """AVI (1.0 and OpenDML: further 'RIFF....AVIX' segments, 'rec ' groups inside 'movi') with one video stream of independent frames: Motion-JPEG
+    ('MJPG' and its aliases) or uncompressed 24-bit BGR ('DIB ', BI_RGB, bottom-up).  A zero-length video chunk is a dropped frame: it shows the
+    previous picture again and keeps its place on the time line.  Inter-coded streams (H.264, MPEG-4, ...) raise NeedsDecoder."""
 
     def __init__(self, path: str):
         import mmap
@@ -200,7 +206,27 @@ class AviReader:
         self.width = self.height = 0
         self._bits = 24
         usec = 0
-        for cc, p, n in _riff_chunks(buf, 12, len(data)):
+
+        def movi(start: int, end: int) -> None:
+            for c2, p2, n2 in _riff_chunks(buf, start, end):
+                if c2 == b"LIST" and bytes(buf[p2:p2 + 4]) == b"rec ":
+                    movi(p2 + 4, min(p2 + n2, end))                # OpenDML interleave groups
+                elif c2[2:] in (b"dc", b"db"):
+                    if n2 > 0:
+                        self._frames.append((p2, n2))
+                    elif self._frames:
+                        self._frames.append(self._frames[-1])      # dropped frame: the previous picture stays up
+        # the first RIFF chunk ('AVI ') holds the headers and the first 'movi' list; OpenDML files continue in 'RIFF....AVIX' chunks of further 'movi' lists
+        segs, pos = [], 0
+        while pos + 12 <= len(data) and data[pos:pos + 4] == b"RIFF":
+            size = struct.unpack_from("<I", buf, pos + 4)[0]
+            segs.append((bytes(buf[pos + 8:pos + 12]), pos + 12, min(pos + 8 + size, len(data))))
+            pos += 8 + size + (size & 1)
+        for form, s0, s1 in segs[1:]:
+            if form != b"AVIX":
+                segs = segs[:1]
+                break
+        for cc, p, n in (x for form, s0, s1 in segs for x in _riff_chunks(buf, s0, s1)):
             if cc != b"LIST":
                 continue
             kind = bytes(buf[p:p + 4])
@@ -225,9 +251,7 @@ class AviReader:
                                 self._bits = struct.unpack_from("<H", buf, p3 + 14)[0]
                                 self._compression = bytes(buf[p3 + 16:p3 + 20])
             elif kind == b"movi":
-                for c2, p2, n2 in _riff_chunks(buf, p + 4, p + n):
-                    if c2[2:] in (b"dc", b"db") and n2 > 0:
-                        self._frames.append((p2, n2))
+                movi(p + 4, min(p + n, len(data)))
         buf.release()
         if not self._fps and usec:
             self._fps = 1e6 / usec
@@ -235,7 +259,8 @@ class AviReader:
         self._mjpeg = comp in (b"MJPG", b"JPEG", b"AVRN", b"LJPG") or self._handler.upper() in (b"MJPG",)
         self._dib = comp in (b"\0\0\0\0", b"DIB ", b"RGB ", b"RAW ") and self._bits == 24
         if not (self._mjpeg or self._dib):
-            raise ValueError(f"{path}: video stream is coded as {self._compression!r} / {self._handler!r}: only streams of independent frames (Motion-JPEG, "
+            self.close()
+            raise NeedsDecoder(f"{path}: video stream is coded as {self._compression!r} / {self._handler!r}: only streams of independent frames (Motion-JPEG, "
                              "uncompressed 24-bit) are decoded here; transcode inter-coded video (H.264, ...) with `ffmpeg -i in.mp4 out.y4m`, or install decord")
         if not self._frames or self.width < 1 or self.height < 1 or self._fps <= 0:
             raise ValueError(f"{path}: no video frames / bad stream header")
@@ -391,7 +416,7 @@ class Mp4Reader:
         fourcc = bytes(buf[s0 + 12: s0 + 16])
         self.width, self.height = struct.unpack_from(">HH", buf, s0 + 8 + 8 + 24)
         if fourcc not in _MP4_INTRA:
-            raise ValueError(f"{path}: the video track is coded as {fourcc!r}: only tracks of independent still images (Motion-JPEG / Photo-JPEG / PNG samples) "
+            raise NeedsDecoder(f"{path}: the video track is coded as {fourcc!r}: only tracks of independent still images (Motion-JPEG / Photo-JPEG / PNG samples) "
                              "are decoded here; inter-coded video (avc1 = H.264, hvc1, vp09, av01, ...) needs a decoder — `ffmpeg -i in.mp4 out.y4m`, or install decord")
         z0 = stbl[b"stsz"][0]
         uniform, count = struct.unpack_from(">II", buf, z0 + 4)
@@ -506,22 +531,21 @@ def write_mjpeg_mp4(path: str, frames_rgb: np.ndarray, fps: Tuple[int, int] = (2
 
 
 def open_container(path: str):
-    """A reader with decord's VideoReader surface for the containers decodable without a codec library, or None (the caller then needs decord)."""
+    """A reader with decord's VideoReader surface for the containers decodable without a codec library, or None (the caller then goes to decord, as the
+    reference does for every file: mm_utils.py:421).  The readers here are a FAST PATH, never a gate: an .avi / .mp4 / .mov whose stream is inter-coded
+    (NeedsDecoder) or that these parsers cannot make sense of (a truncated or unusual box / chunk structure: ValueError, KeyError, IndexError, struct.error)
+    is handed on; only when decord is absent does the reader's own message surface, as an ImportError that names the codec or the parse problem."""
     low = path.lower()
     if low.endswith(".y4m"):
         return Y4MReader(path)
-    if low.endswith(".avi"):
-        return AviReader(path)
-    if low.endswith((".mp4", ".mov", ".m4v")):
-        # a track of still images is read here; an inter-coded one (the usual case) goes to decord like in the reference — with the codec named if it is absent
+    reader = AviReader if low.endswith(".avi") else Mp4Reader if low.endswith((".mp4", ".mov", ".m4v")) else None
+    if reader is None:
+        return None
+    try:
+        return reader(path)
+    except (ValueError, KeyError, IndexError, struct.error) as e:          # NeedsDecoder is a ValueError
         try:
-            return Mp4Reader(path)
-        except ValueError as e:
-            if "needs a decoder" not in str(e):
-                raise
-            try:
-                import decord  # noqa: F401
-            except ImportError:
-                raise ImportError(str(e)) from e
-            return None
-    return None
+            import decord  # noqa: F401
+        except ImportError:
+            raise ImportError(f"{e}" if isinstance(e, NeedsDecoder) else f"{path}: not readable here ({type(e).__name__}: {e}) and decord is not installed") from e
+        return None

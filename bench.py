@@ -508,10 +508,15 @@ def main():
         k_ms, k_n, k_bytes = prof[2], int(prof[3]), prof[4]
         ach = (k_bytes / (k_ms * 1e-3) / 1e9) if k_ms > 0 else None
         traffic = g_traffic = g_traffic_M = None
+        traffic_src = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
+                # `traffic` is NOT a counter of this run: it is the committed rocprofv3 --pmc pass over the same launch shapes (tools/pmc_kernels.py ->
+                # tools/pmc_traffic.py -> profiles/traffic.json, corrected as MI355X_MICROARCH.md prescribes); the line says which file and when it was taken
+                traffic_src = {"file": "profiles/traffic.json", "measured": tj.get("measured", "round 4"),
+                               "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_kernels.py (same launch shapes as the brackets of this run), FETCH_SIZE x 2 (gfx950)"}
                 traffic, g_traffic, g_traffic_M = tj.get("skinny_gateup_bytes_per_launch"), tj.get("gemm_fc1_bytes_per_launch"), tj.get("gemm_fc1_M", 73856)
                 if int(prof[8]) == 3:      # the wide decode step brackets the decode attention: the committed PMC pass measured it at one batch / context
                     traffic = tj.get("attn_decode_bytes_per_launch") if tj.get("attn_decode_batch") == B else None
@@ -524,8 +529,7 @@ def main():
         if g_traffic is not None and g_traffic_M != g_M:
             g_traffic = None                                    # the committed PMC pass measured another launch shape
         g_tf = (g_gf / g_ms) if g_ms > 0 else None             # GFLOP / ms = TFLOP/s
-        fold_tag = ", LN fold" if prof[9] else ""              # the engine says which instantiations the brackets timed (the fold is opt-in since round 4)
-        stat_tag = " (+ row statistics)" if prof[9] else ""
+        fold_tag = stat_tag = ""                               # (rounds 3-4 tagged the LayerNorm-fold instantiations here; the fold left the product in round 5)
         line = {
             "metric": "videos/sec + decode tok/s, TRACE-7B 128-frame, 1/2/4/8 MI355X",
             "value": vps, "unit": "videos/s", "n_gpus": world, "rccl_ranks": ranks_seen[0], "steps": args.steps, "warmup": args.warmup,
@@ -561,7 +565,7 @@ def main():
             # brackets its largest instance, the ViT fc1 projection, once per video inside the timed region)
             "roofline": {"bound": "mfma", "kernel": f"256x256-tile loader-wave MFMA GEMM family (8 MFMA + 4 loader waves per workgroup): by total time the run's top symbol is gemm_ldr_kernel<EPI_RESIDUAL> (ViT out-proj + fc2, prefill o / down); achieved / frac below are its largest single launch, gemm_pers_kernel<EPI_QUICKGELU{fold_tag}> = ViT fc1 {g_M}x4096x1024 of one {eng.vit_batch_frames if B >= 2 else args.frames}-frame tower call (1 bracketed launch per call); every ViT shape of the family is in `shapes`",
                          "achieved": g_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": (g_tf / 2500.0) if g_tf else None,
-                         "traffic": g_traffic, "algorithmic_gflop_per_launch": g_gf, "algorithmic_bytes_per_launch": g_M * 1024 * 2 + 4096 * 1024 * 2 + g_M * 4096 * 2,
+                         "traffic": g_traffic, "traffic_source": traffic_src if g_traffic is not None else None, "algorithmic_gflop_per_launch": g_gf, "algorithmic_bytes_per_launch": g_M * 1024 * 2 + 4096 * 1024 * 2 + g_M * 4096 * 2,
                          "avg_launch_ms": g_ms, "samples": g_n,
                          "shapes": {name: {"kernel": sym, "MxNxK": f"{g_M}x{N_}x{K_}", "avg_launch_ms": ms_, "tflops": (gf_ / ms_) if ms_ > 0 else None,
                                            "frac": (gf_ / ms_ / 2500.0) if ms_ > 0 else None}
@@ -586,7 +590,8 @@ def main():
                           "skinny_lds_kernel<EPI_PARTIAL,NB,NT=2> (decode gate|up GEMV, 1 bracketed launch per decode step)")}.get(bkind, "none bracketed")
         line["roofline_hbm"] = {"bound": "hbm", "kernel": hbm_kernel,
                                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
-                                "traffic": traffic, "algorithmic_bytes_per_launch": k_bytes, "avg_launch_ms": k_ms, "samples": k_n}
+                                "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
+                                "algorithmic_bytes_per_launch": k_bytes, "avg_launch_ms": k_ms, "samples": k_n}
         if world > 1:
             # timed on rank 0 of the single-GPU run only (the host cores are busy driving N ranks here): the N = 1 line of the same round carries it
             line["cpu_baseline"] = {"value": None, "unit": "videos/s", "cores": None, "kind": "port",

@@ -58,6 +58,35 @@ def test_stc_connector_vs_oracle():
     eng.close()
 
 
+def test_stc_connector_at_real_width_vs_oracle():
+    """Round 5: the connector at the widths the reference builds it with (mm_hidden 1024 -> hidden 4096, 24 x 24 patch grid; builder.py:138-205), two
+    frames (-> 2 x 13 x 13 = 338 tokens): every GEMM of the path at its production K / N — the 1 x 1 convolutions (K = 1024 and 4096), the Conv3d sampler as
+    a K = 32768 GEMM, the readout — the depthwise convolutions and squeeze-excite GEMVs at 4096 channels, and the fused LayerNorm + shortcut + SiLU tail
+    of every block, against the bf16-emulating oracle (the RegStage block itself restated: DESIGN section 2)."""
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=2), mm_projector_type="stc_connector", vision_image_size=336, vision_patch_size=14,
+                              vision_hidden_size=1024, vision_intermediate_size=1024, vision_num_heads=16, vision_num_layers=2, mm_hidden_size=1024)
+    assert cfg.hidden_size == 4096 and cfg.vision_grid == 24
+    sd = synth.state_dict(cfg)
+    eng = TraceEngine(cfg, max_batch=1, max_ctx=512, max_frames=2, max_new_tokens=8)
+    eng.load_weights(sd.items())
+    ora = O.Oracle(cfg, {k: v for k, v in sd.items() if "mm_projector" in k}, emulate_bf16=True)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(2, cfg.vision_patches, cfg.vision_hidden_size, generator=g).to(torch.bfloat16)
+    got = eng.stc_connector(feats.cuda(), 2)
+    again = eng.stc_connector(feats.cuda(), 2)
+    assert torch.equal(got, again)
+    with torch.no_grad():
+        ref = ora.stc_connector(feats.float())
+    assert got.shape == ref.shape == (2 * 13 * 13, 4096)
+    err = (got.float().cpu() - ref).abs()
+    tol = 6e-2 + 6e-2 * ref.abs()
+    frac = (err > tol).float().mean().item()
+    print(f"STC at real width: max err {err.max().item():.4f} (ref max {ref.abs().max().item():.3f}, ref std {ref.std().item():.3f}), outside the budget: {frac:.5f}")
+    assert torch.isfinite(got).all()
+    assert frac < 5e-3, (err.max().item(), ref.abs().max().item(), frac)
+    eng.close()
+
+
 def test_legacy_infer_api(tmp_path):
     """trace.model_init / trace.infer (trace/__init__.py:13-75) with an STC checkpoint: text-head ids only."""
     import numpy as np

@@ -31,7 +31,9 @@ g_alg = FC1_M * 1024 * 2 + 4096 * 1024 * 2 + FC1_M * 4096 * 2
 g_total = gf_kb * 1024 * 2 + gw_kb * 1024
 alg = 28672 * 4096 * 2
 total = fetch_kb * 1024 * 2 + write_kb * 1024
+import datetime
 json.dump({
+    "measured": "round 5, " + datetime.date.today().isoformat(),
     "attn_decode_bytes_per_launch": a_total, "attn_decode_batch": AD_B, "attn_decode_ctx": AD_CTX,
     "attn_decode_detail": {
         "kernel": "attn_decode_kernel, %d sequences x ctx %d x 8 kv heads (the wide decode step's dominant kernel), 4 launches" % (AD_B, AD_CTX),
@@ -40,7 +42,7 @@ json.dump({
     "gemm_fc1_bytes_per_launch": g_total,
     "gemm_fc1_M": FC1_M,
     "gemm_fc1_detail": {
-        "kernel": "gemm_pers_kernel<EPI_QUICKGELU> (ViT fc1 as shipped in round 4: no LayerNorm fold; M=%d N=4096 K=1024), 3 launches" % FC1_M,
+        "kernel": "gemm_pers_kernel<EPI_QUICKGELU> (ViT fc1; M=%d N=4096 K=1024), 3 launches" % FC1_M,
         "FETCH_SIZE_KB_mean": gf_kb, "WRITE_SIZE_KB_mean": gw_kb, "launches": [g1, g2],
         "correction": "FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 (same gfx950 corrections as below; operand panels re-read by "
                       "other column tiles are served by L2 / infinity cache and only partly reach the memory-side counters)",

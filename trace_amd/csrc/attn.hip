@@ -282,7 +282,7 @@ __device__ __forceinline__ void attn_body(AttnArgs a) {
 
 // =====================================================================================================================
 // ViT attention, round 2: head_dim 64, non-causal, one launch = frames x heads x 577 tokens.
-// Knock-out runs of the kernel above (tools/attn_vit_probe.py, 170 frames): tile math alone 387 us, K/V staging alone (global
+// Knock-out runs of the kernel above (round 2's tools/attn_vit_probe.py, 170 frames; today tools/attn_vit_big_probe.py): tile math alone 387 us, K/V staging alone (global
 // loads -> registers -> LDS stores -> barrier) 261 us, together 466-510 us, i.e. 0.2 of the MFMA peak with the matrix pipe 27 % busy:
 // the loop was bound by VALU issue (135 plain + 33 transcendental instructions per 16 MFMAs) and by the staging instructions.
 // This kernel removes most of both:

@@ -115,8 +115,6 @@ struct trace_ctx {
     int kev_used = 0;
     hipEvent_t gev0 = nullptr, gev1 = nullptr;   // pair recorded from inside the captured graph
     double ksum_ms = 0.0; int ksamples = 0;
-    // debugging aid (trace_debug_vit_trace, tools/pipeline_stress.py --trace): per tower call one record [layer][stage][256-row panel] of checksums of
-    // what every stage of every layer left (qkv out, attention out, out-proj out, statistics, fc1 out, fc2 out, statistics)
     hipEvent_t mev0 = nullptr, mev1 = nullptr;   // bracket of one ViT fc1 GEMM launch per trace_vit_forward (profile == 2)
     double msum_ms = 0.0; int msamples = 0; double mflops = 0.0; int mM = 0;
     // the other three GEMM shapes of the layer (qkv, out-proj, fc2), bracketed the same way in layer 0: the 256x256 MFMA GEMM family is the run's

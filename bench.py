@@ -9,8 +9,8 @@
 A "step" = one pass of the hot path over one batch of `--videos-per-step` (default 128; 32 for c5) videos per GPU, inputs already
 resident in HBM: CLIP-ViT-L/14-336 over 128 frames -> SpatialSlotPool -> splice -> Mistral-7B prefill (L = 1967) -> 256 greedy
 decode steps with head switching, then ONE RCCL all-gather of the packed token ids (N > 1).  Prints one JSON line
-(rank 0) with the whole-job videos/sec, the decode tokens/sec, `roofline` = the dominant kernel family of the run (the 256x256 loader-wave
-MFMA GEMM: gemm_ldr_kernel<1> is the top symbol by total time, gemm_pers_kernel<2,16> its largest single launch; all four ViT shapes are
+(rank 0) with the whole-job videos/sec, the decode tokens/sec, `roofline` = the dominant kernel family of the run (the 256x256
+MFMA GEMM: gemm_ldr_kernel<1> is the top symbol by total time, gemm_w4_kernel<2> its largest single launch; all four ViT shapes are
 bracketed with HIP events inside the timed region), `roofline_hbm` = the dominant HBM-bound kernel of the decode phase (the decode
 attention at the default batch), per-rank timings and host placement (N > 1), and the CPU baseline (the oracle timed on a bounded sample
 on this box's host cores; N = 1 only).
@@ -529,6 +529,8 @@ def main():
         if g_traffic is not None and g_traffic_M != g_M:
             g_traffic = None                                    # the committed PMC pass measured another launch shape
         g_tf = (g_gf / g_ms) if g_ms > 0 else None             # GFLOP / ms = TFLOP/s
+        # the persistent kernel the shapes without a residual run on: gemm_w4.hip (4 waves of 128x128) unless TRACE_GEMM_W4=0 sends them back to gemm_pers.hip
+        pers_sym = "gemm_pers_kernel" if os.environ.get("TRACE_GEMM_W4", "1") == "0" else "gemm_w4_kernel"
         fold_tag = stat_tag = ""                               # (rounds 3-4 tagged the LayerNorm-fold instantiations here; the fold left the product in round 5)
         line = {
             "metric": "videos/sec + decode tok/s, TRACE-7B 128-frame, 1/2/4/8 MI355X",
@@ -563,16 +565,16 @@ def main():
             "mfma_util": {"vit": vit_flops / (t_enc * 1e-3) / 2.5e15, "prefill": pre_flops / (t_pre * 1e-3) / 2.5e15},
             # dominant kernel of the run: the 256x256 MFMA GEMM (its four epilogue variants are ~half of GPU time; the probe
             # brackets its largest instance, the ViT fc1 projection, once per video inside the timed region)
-            "roofline": {"bound": "mfma", "kernel": f"256x256-tile loader-wave MFMA GEMM family (8 MFMA + 4 loader waves per workgroup): by total time the run's top symbol is gemm_ldr_kernel<EPI_RESIDUAL> (ViT out-proj + fc2, prefill o / down); achieved / frac below are its largest single launch, gemm_pers_kernel<EPI_QUICKGELU{fold_tag}> = ViT fc1 {g_M}x4096x1024 of one {eng.vit_batch_frames if B >= 2 else args.frames}-frame tower call (1 bracketed launch per call); every ViT shape of the family is in `shapes`",
+            "roofline": {"bound": "mfma", "kernel": f"256x256-tile LDS-DMA MFMA GEMM family (gemm_ldr: 8 MFMA + 4 loader waves, one tile per workgroup; {pers_sym.split('_kernel')[0]}: persistent workgroups): by total time the run's top symbol is gemm_ldr_kernel<EPI_RESIDUAL> (ViT out-proj + fc2, prefill o / down); achieved / frac below are its largest single launch, {pers_sym}<EPI_QUICKGELU{fold_tag}> = ViT fc1 {g_M}x4096x1024 of one {eng.vit_batch_frames if B >= 2 else args.frames}-frame tower call (1 bracketed launch per call); every ViT shape of the family is in `shapes`",
                          "achieved": g_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": (g_tf / 2500.0) if g_tf else None,
                          "traffic": g_traffic, "traffic_source": traffic_src if g_traffic is not None else None, "algorithmic_gflop_per_launch": g_gf, "algorithmic_bytes_per_launch": g_M * 1024 * 2 + 4096 * 1024 * 2 + g_M * 4096 * 2,
                          "avg_launch_ms": g_ms, "samples": g_n,
                          "shapes": {name: {"kernel": sym, "MxNxK": f"{g_M}x{N_}x{K_}", "avg_launch_ms": ms_, "tflops": (gf_ / ms_) if ms_ > 0 else None,
                                            "frac": (gf_ / ms_ / 2500.0) if ms_ > 0 else None}
                                     for name, sym, N_, K_, ms_, gf_ in (
-                                        ("vit_qkv", "gemm_pers_kernel<EPI_NONE" + fold_tag + ">", 3072, 1024, prof[12], prof[15]),
+                                        ("vit_qkv", pers_sym + "<EPI_NONE" + fold_tag + ">", 3072, 1024, prof[12], prof[15]),
                                         ("vit_out_proj", "gemm_ldr_kernel<EPI_RESIDUAL>" + stat_tag, 1024, 1024, prof[13], prof[16]),
-                                        ("vit_fc1", "gemm_pers_kernel<EPI_QUICKGELU" + fold_tag + ">", 4096, 1024, g_ms, g_gf),
+                                        ("vit_fc1", pers_sym + "<EPI_QUICKGELU" + fold_tag + ">", 4096, 1024, g_ms, g_gf),
                                         ("vit_fc2", "gemm_ldr_kernel<EPI_RESIDUAL>" + stat_tag, 1024, 4096, prof[14], prof[17]))}},
         }
         # dominant HBM-bound kernel of the decode phase

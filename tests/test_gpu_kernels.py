@@ -40,7 +40,7 @@ def check(name, got, ref, atol, rtol):
         pytest.fail(msg)
 
 
-@pytest.fixture(params=[0, 2, 3, 4, 5], ids=["auto", "tile128", "tile256", "ldr", "persistent"])
+@pytest.fixture(params=[0, 2, 3, 4, 5, 8], ids=["auto", "tile128", "tile256", "ldr", "persistent", "w4"])
 def gemm_variant(request):
     ops.set_gemm_variant(request.param)
     yield request.param
@@ -118,26 +118,80 @@ def test_gemm_persistent_equals_loader_wave_kernel(M, N, K):
         ops.set_gemm_variant(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (9000, 2048, 256), (70000, 1024, 192), (66000, 512, 320), (3934, 6144, 1024)])
+def test_gemm_four_wave_kernel_equals_loader_wave_kernel(M, N, K):
+    """gemm_w4.hip (variant 8: the persistent 256x256 tile on 4 waves of 128x128, accumulators in AGPRs, the waves issue their own LDS-DMA pieces) against
+    gemm_ldr.hip (variant 4), bit for bit, all four epilogues: ragged M, fewer tiles than CUs, several tiles per workgroup (tickets and the static deal),
+    its A/B builds (one barrier per K-tile; L2 touches), the in-place residual, back-to-back launches, and launches alternating with gemm_pers.hip on one
+    stream (the two kernels share the stream's ticket counters)."""
+    A, W, b, R = rnd(M, K), rnd(N, K, scale=0.05), rnd(N, scale=0.5), rnd(M, N)
+    lib = E._lib.load()
+    try:
+        for epi, kw in ((E.EPI_NONE, dict(bias=b)), (E.EPI_NONE, {}), (E.EPI_QUICKGELU, dict(bias=b)), (E.EPI_RESIDUAL, dict(bias=b, R=R)), (E.EPI_SWIGLU, {})):
+            ops.set_gemm_variant(4)
+            ref = ops.gemm(A, W, epilogue=epi, **kw)
+            for walk, opt in ((500, 0), (501, 0), (500, 1), (500, 4), (500, 5)):
+                ops.set_gemm_variant(walk)
+                ops.set_gemm_variant(300 + opt)
+                for rep in range(3):
+                    ops.set_gemm_variant(8)
+                    got = ops.gemm(A, W, epilogue=epi, **kw)
+                    assert torch.equal(got, ref), (epi, walk, opt, rep, (got.float() - ref.float()).abs().max().item())
+                    if rep == 1:
+                        ops.set_gemm_variant(5)
+                        assert torch.equal(ops.gemm(A, W, epilogue=epi, **kw), ref)
+            ops.set_gemm_variant(500)
+            ops.set_gemm_variant(300)
+        ops.set_gemm_variant(4)
+        ref = ops.gemm(A, W, R=R, epilogue=E.EPI_RESIDUAL)
+        ops.set_gemm_variant(8)
+        Rc = R.clone()
+        E._lib.check(lib.trace_op_gemm(E._ptr(A), K, E._ptr(W), K, E._ptr(Rc), N, None, E._ptr(Rc), N, M, N, K, E.EPI_RESIDUAL, E._stream()))
+        assert torch.equal(Rc, ref)
+    finally:
+        ops.set_gemm_variant(500)
+        ops.set_gemm_variant(300)
+        ops.set_gemm_variant(0)
+
+
+def test_gemm_auto_routing_takes_the_four_wave_kernel_and_can_be_switched_back():
+    """auto mode (what the engine runs): shapes without a residual go to gemm_w4.hip, trace_op_set_gemm_variant(530) sends them back to gemm_pers.hip —
+    same bits either way, and equal to the forced kernels"""
+    M, N, K = 20000, 1024, 512
+    A, W, b = rnd(M, K), rnd(N, K, scale=0.05), rnd(N, scale=0.5)
+    try:
+        ops.set_gemm_variant(4)
+        ref = ops.gemm(A, W, bias=b, epilogue=E.EPI_QUICKGELU)
+        ops.set_gemm_variant(0)
+        for sw in (531, 530, 531):
+            ops.set_gemm_variant(sw)
+            assert torch.equal(ops.gemm(A, W, bias=b, epilogue=E.EPI_QUICKGELU), ref), sw
+    finally:
+        ops.set_gemm_variant(531)
+        ops.set_gemm_variant(0)
+
+
 def test_gemm_persistent_two_streams():
-    """Two persistent launches in flight on different streams: each stream has its own ticket counters."""
+    """Two persistent launches in flight on different streams: each stream has its own ticket counters (both persistent kernels)."""
     M, N, K = 40000, 1024, 256
     A1, W1, A2, W2 = rnd(M, K), rnd(N, K, scale=0.05), rnd(M, K, seed=3), rnd(N, K, scale=0.05, seed=4)
     try:
         ops.set_gemm_variant(4)
         r1, r2 = ops.gemm(A1, W1), ops.gemm(A2, W2)
-        ops.set_gemm_variant(5)
         s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-        torch.cuda.synchronize()
-        outs = []
-        for _ in range(4):
-            with torch.cuda.stream(s1):
-                o1 = ops.gemm(A1, W1)
-            with torch.cuda.stream(s2):
-                o2 = ops.gemm(A2, W2)
-            outs.append((o1, o2))
-        torch.cuda.synchronize()
-        for o1, o2 in outs:
-            assert torch.equal(o1, r1) and torch.equal(o2, r2)
+        for v in (5, 8):                               # gemm_pers.hip, gemm_w4.hip
+            ops.set_gemm_variant(v)
+            torch.cuda.synchronize()
+            outs = []
+            for _ in range(4):
+                with torch.cuda.stream(s1):
+                    o1 = ops.gemm(A1, W1)
+                with torch.cuda.stream(s2):
+                    o2 = ops.gemm(A2, W2)
+                outs.append((o1, o2))
+            torch.cuda.synchronize()
+            for o1, o2 in outs:
+                assert torch.equal(o1, r1) and torch.equal(o2, r2), v
     finally:
         ops.set_gemm_variant(0)
 

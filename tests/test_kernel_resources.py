@@ -38,8 +38,8 @@ def res(tmp_path_factory):
     if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
         pytest.skip("hipcc not available")
     tmp = str(tmp_path_factory.mktemp("kres"))
-    names = ["gemm_ldr", "gemm_pers", "gemm", "attn", "decode"]
-    with cf.ThreadPoolExecutor(max_workers=5) as ex:
+    names = ["gemm_ldr", "gemm_pers", "gemm_w4", "gemm", "attn", "decode"]
+    with cf.ThreadPoolExecutor(max_workers=6) as ex:
         return dict(zip(names, ex.map(lambda n: _resources(n, tmp), names)))
 
 
@@ -63,6 +63,24 @@ def test_persistent_gemm_keeps_its_k_loop_in_registers(res):
     for k, v in _pick(res["gemm_pers"], "gemm_pers_kernel").items():
         assert v["VGPRs"] + v.get("AGPRs", 0) <= 168 and v["Occupancy"] >= 3, (k, v)
         assert v["ScratchSize"] <= (24 if "ILi1E" in k else 0), (k, v)
+
+
+def test_four_wave_gemm_owns_its_agprs(res, tmp_path):
+    """gemm_w4.hip: one wave per SIMD, the 256 accumulators in AGPRs that only the inline asm names.  Nothing in scratch (a scratch access is a VMEM
+    operation the kernel's counted s_waitcnt vmcnt(N) waits do not know about), and hipcc must not have parked anything of its own in an AGPR: it
+    believes them free between the MFMAs that clobber them, and a spilled VGPR there would overwrite an accumulator."""
+    for k, v in _pick(res["gemm_w4"], "gemm_w4_kernel").items():
+        assert v["ScratchSize"] == 0 and v["VGPRs"] <= 256 and v.get("AGPRs", 0) == 256, (k, v)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    for f16 in (False, True):
+        out = str(tmp_path / ("w4_f16.s" if f16 else "w4.s"))
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", os.path.join(CSRC, "gemm_w4.hip"), "-I", CSRC, "-o", out]
+                           + (["-DTRACE_F16"] if f16 else []), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        isa = open(out).read()
+        assert "v_accvgpr_write" not in isa and "v_accvgpr_mov" not in isa, "hipcc moved a value of its own into an AGPR"
+        assert isa.count("v_mfma_f32_16x16x32") >= 4 * 5 * 64        # 4 epilogues x (first k-step 0, k-step 0, three k-step 1 variants) x 64 MFMAs, per build
+        assert "scratch_" not in isa
 
 
 def test_plain_gemm_kernels_do_not_spill(res):
@@ -103,8 +121,8 @@ def test_fp16_build_keeps_the_budgets(res, tmp_path_factory):
     scratch wherever the bf16 build does (two gemm_ldr instantiations are allowed their measured 8 bytes; the fp8 GEMM instantiations are
     unreachable in that build)."""
     tmp = str(tmp_path_factory.mktemp("kres16"))
-    names = ["gemm_ldr", "gemm_pers", "gemm", "attn", "decode"]
-    with cf.ThreadPoolExecutor(max_workers=5) as ex:
+    names = ["gemm_ldr", "gemm_pers", "gemm_w4", "gemm", "attn", "decode"]
+    with cf.ThreadPoolExecutor(max_workers=6) as ex:
         r16 = dict(zip(names, ex.map(lambda n: _resources(n, tmp, True), names)))
     for n in names:
         assert set(r16[n]) == set(res[n]), n

@@ -371,6 +371,11 @@ int launch_glds(const GemmArgs& p, int epi, hipStream_t s) {
 int g_gemm_variant = 0;   // 0 = auto, 2 = 128^2 tiles, 3 = this file's 256^2 kernel, 4 = the loader-wave 256^2 kernel, 5 / 6 = the persistent one
                           // (gemm_pers.hip; 6 = static tile deal) — tests / microbench
 extern int g_gemm_pers_static;
+int g_gemm_w4 = -1;          // non-residual 256^2 shapes on gemm_w4.hip in auto mode: 1 / 0 (trace_op_set_gemm_variant(530 + x)); -1 = not decided yet: TRACE_GEMM_W4 or the default
+static bool gemm_w4_enabled() {
+    if (g_gemm_w4 < 0) { const char* e = getenv("TRACE_GEMM_W4"); g_gemm_w4 = e ? (atoi(e) != 0) : 1; }
+    return g_gemm_w4 != 0;
+}
 int g_gemm_resid_pers = 0;   // 1: residual shapes also run on the persistent kernel in auto mode (trace_op_set_gemm_variant(520 + x); A/B runs)
 
 // split-K partial-row GEMM for decode batches above SKINNY_ROWS: M <= 128 rows (one row panel), 128x128 tiles, ks chunks of K
@@ -431,6 +436,10 @@ int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
         // -5 .. +14 % against it depending on the box.
         const bool pers_ok = p.N % 256 == 0 && !p.fp8 && p.K >= 128 && (long)p.M * p.ldc < (1L << 30) &&
                              (epi != EPI_RESIDUAL || (long)p.M * p.ldr < (1L << 30));
+        if (g_gemm_variant == 8 && pers_ok && p.K >= 192 && (long)p.M * p.lda < (1L << 31) && (long)p.N * p.ldw < (1L << 31)) {
+            g_gemm_pers_static = 0;
+            return launch_gemm_w4(p, epi, s);                  // the 4-wave persistent kernel (A/B runs)
+        }
         if ((g_gemm_variant >= 5 && g_gemm_variant <= 7) && pers_ok) {
             g_gemm_pers_static = g_gemm_variant - 5;        // 5 ticketed, 6 static deal, 7 one workgroup per tile
             return launch_gemm_pers(p, epi, s);
@@ -438,7 +447,10 @@ int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s) {
         if (p.N % 256 == 0 && (g_gemm_variant == 4 || (g_gemm_variant == 0 && v == 3))) {
             if (g_gemm_variant == 0 && pers_ok && (epi != EPI_RESIDUAL || g_gemm_resid_pers)) {
                 g_gemm_pers_static = 0;
-                const int rc = launch_gemm_pers(p, epi, s);
+                // without a residual: the 4-wave form of the persistent kernel (gemm_w4.hip; same bits), unless switched off
+                // (trace_op_set_gemm_variant(530) / TRACE_GEMM_W4=0: A/B runs)
+                const bool w4 = gemm_w4_enabled() && epi != EPI_RESIDUAL && p.K >= 192 && (long)p.M * p.lda < (1L << 31) && (long)p.N * p.ldw < (1L << 31);
+                const int rc = w4 ? launch_gemm_w4(p, epi, s) : launch_gemm_pers(p, epi, s);
                 // no ticket counters for this stream and none can be made inside a capture: the one-workgroup-per-tile kernel gives the same bits
                 if (rc != TRACE_ERR_STATE) return rc;
             }

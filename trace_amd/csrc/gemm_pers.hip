@@ -628,6 +628,20 @@ void gemm_pers_release(int dev) {
     }
 }
 
+// The stream's ticket counters and the persistent grid for `total` tiles, for gemm_w4.hip (launches on one stream are ordered, so the two kernels share them)
+int gemm_pers_plan(hipStream_t s, int total, int** ctr, int* nblk) {
+    int ncu = 0;
+    CtrState* st = counters_for(s, &ncu);
+    if (!st) return TRACE_ERR_STATE;
+    int stream_cap;
+    { std::lock_guard<std::mutex> lk(g_ctr_mu); stream_cap = st->cap; }
+    const int cap = stream_cap > 0 ? stream_cap : g_gemm_pers_grid_cap;
+    if (cap > 0 && cap < ncu) ncu = cap < 8 ? 8 : cap;
+    *ctr = st->ctr;
+    *nblk = total < ncu ? total : ncu;
+    return TRACE_OK;
+}
+
 // TRACE_ERR_STATE: no ticket counters for this stream and none can be made now (capturing): the caller falls back to gemm_ldr
 int launch_gemm_pers(const GemmArgs& p0, int epi, hipStream_t s) {
     GemmArgs p = p0;

@@ -60,6 +60,8 @@ int launch_gemm_bf16(const GemmArgs& p, int epi, hipStream_t s);
 int gemm_partial_ks(int N, int K);                                // K-chunks launch_gemm_bf16(EPI_PARTIAL) should be given for an [<= 128, K] x [N, K]^T product
 int launch_gemm_ldr(const GemmArgs& p, int epi, hipStream_t s);    // gemm_ldr.hip: 256x256 tiles, 8 MFMA + 4 loader waves (N % 256 == 0)
 int launch_gemm_pers(const GemmArgs& p, int epi, hipStream_t s);   // gemm_pers.hip: the same tile, persistent workgroups, register epilogue (bf16, K >= 128)
+int launch_gemm_w4(const GemmArgs& p, int epi, hipStream_t s);     // gemm_w4.hip: the persistent 256x256 tile on 4 waves of 128x128 (bf16, K >= 192)
+int gemm_pers_plan(hipStream_t s, int total, int** ctr, int* nblk);   // the stream's ticket counters + persistent grid size (shared by gemm_pers / gemm_w4)
 int gemm_pers_init(hipStream_t s);                                 // creates the (current device, stream) ticket counters ahead of its first launch (optional)
 int gemm_pers_set_cap(hipStream_t s, int cap);                       // at most `cap` workgroups per persistent launch on this stream (0 = #CUs)
 void gemm_pers_forget(hipStream_t s);                               // drops one (idle) stream's counters before the stream is destroyed

@@ -1,5 +1,5 @@
 """Small fixed workload for rocprofv3 --pmc passes: the two roofline kernels of bench.py at the launch shapes it brackets — the ViT fc1 GEMM of one
-170-frame tower call (gemm_pers_kernel<2, 0>; round 3 measured the LayerNorm-fold form <2, 16>) and the decode attention of a 128-sequence step at ctx 2100 — plus
+170-frame tower call (gemm_w4_kernel<2, 0> since round 5; rounds 2-4: gemm_pers_kernel<2, ..>) and the decode attention of a 128-sequence step at ctx 2100 — plus
 the ViT attention and the batch-64 gate|up GEMV of the earlier rounds; round 5: `tower` (the four GEMMs of a ViT layer + both attention kernels at 170 frames) and
 `decgemm` (the wide decode step's weight-side GEMMs at 128 rows).   python tools/pmc_kernels.py [attn] [gemm] [attn_decode] [gemv] [tower] [decgemm]"""
 import math, os, sys, torch
@@ -15,11 +15,11 @@ if "all" in what or "attn" in what:
         ops.attention(q, k, v, False, 0.125)
 if "all" in what or "gemm" in what:
     A, W, b = rnd(170 * 577, 1024), rnd(4096, 1024, scale=0.02), rnd(4096)      # the bench's probe shape: one 170-frame ViT call
-    for _ in range(3):                                   # as shipped since round 4: the LayerNorm is a kernel of its own, the GEMM is gemm_pers_kernel<2, 0>
+    for _ in range(3):                                   # as shipped: the LayerNorm is a kernel of its own, the GEMM is gemm_w4_kernel<2, 0>
         ops.gemm(A, W, bias=b, epilogue=E.EPI_QUICKGELU)
 if "tower" in what:
-    # round 5: one launch set of a ViT layer at the bench's call shape (170 frames): the four GEMMs as the tower routes them (qkv and fc1 on the persistent
-    # kernel, out-proj and fc2 with the residual on the loader-wave kernel) and the attention (the 192-row kernel and, for comparison, the 4 x 32-row one)
+    # round 5: one launch set of a ViT layer at the bench's call shape (170 frames): the four GEMMs as the tower routes them (qkv and fc1 on the 4-wave persistent
+    # kernel gemm_w4 — and once more on gemm_pers, for the counters side by side —, out-proj and fc2 with the residual on the loader-wave kernel) and the attention (the 192-row kernel and, for comparison, the 4 x 32-row one)
     M = 170 * 577
     X1, X4 = rnd(M, 1024), rnd(M, 4096)
     Wq, bq = rnd(3072, 1024, scale=0.02), rnd(3072)
@@ -33,6 +33,11 @@ if "tower" in what:
         ops.gemm(X1, W1, bias=b1, epilogue=E.EPI_QUICKGELU)
         ops.gemm(X4, W2, bias=b2, R=R, epilogue=E.EPI_RESIDUAL)
     del X4
+    ops.set_gemm_variant(530)                            # the same two shapes on gemm_pers.hip
+    for _ in range(3):
+        ops.gemm(X1, Wq, bias=bq)
+        ops.gemm(X1, W1, bias=b1, epilogue=E.EPI_QUICKGELU)
+    ops.set_gemm_variant(531)
     q, k, v = rnd(170, 577, 16, 64), rnd(170, 577, 16, 64), rnd(170, 577, 16, 64)
     for var in (190, 192):
         ops.set_gemm_variant(var)

@@ -24,8 +24,19 @@ aw_kb, a2 = counter_mean(sys.argv[2], "WRITE_SIZE", "attn_decode_kernel")
 AD_B, AD_CTX = 128, 2100       # tools/pmc_kernels.py attn_decode
 a_alg = AD_B * AD_CTX * 8 * 128 * 2 * 2
 a_total = af_kb * 1024 * 2 + aw_kb * 1024
-gf_kb, g1 = counter_mean(sys.argv[1], "FETCH_SIZE", "gemm_pers_kernel<2")
-gw_kb, g2 = counter_mean(sys.argv[2], "WRITE_SIZE", "gemm_pers_kernel<2")
+def fc1_kernel(d):            # the ViT fc1 launch: gemm_w4_kernel<2, ..> since round 5 (gemm_pers_kernel<2, ..> with TRACE_GEMM_W4=0)
+    for sub in ("gemm_w4_kernel<2", "gemm_pers_kernel<2"):
+        try:
+            counter_mean(d, "FETCH_SIZE" if d == sys.argv[1] else "WRITE_SIZE", sub)
+            return sub
+        except SystemExit:
+            pass
+    raise SystemExit("no fc1 GEMM rows under " + d)
+
+
+FC1_SYM = fc1_kernel(sys.argv[1])
+gf_kb, g1 = counter_mean(sys.argv[1], "FETCH_SIZE", FC1_SYM)
+gw_kb, g2 = counter_mean(sys.argv[2], "WRITE_SIZE", FC1_SYM)
 FC1_M = 170 * 577       # tools/pmc_kernels.py: one 170-frame ViT call (the bench's probe shape)
 g_alg = FC1_M * 1024 * 2 + 4096 * 1024 * 2 + FC1_M * 4096 * 2
 g_total = gf_kb * 1024 * 2 + gw_kb * 1024
@@ -42,7 +53,7 @@ json.dump({
     "gemm_fc1_bytes_per_launch": g_total,
     "gemm_fc1_M": FC1_M,
     "gemm_fc1_detail": {
-        "kernel": "gemm_pers_kernel<EPI_QUICKGELU> (ViT fc1; M=%d N=4096 K=1024), 3 launches" % FC1_M,
+        "kernel": FC1_SYM.split("<")[0] + "<EPI_QUICKGELU> (ViT fc1; M=%d N=4096 K=1024), 3 launches" % FC1_M,
         "FETCH_SIZE_KB_mean": gf_kb, "WRITE_SIZE_KB_mean": gw_kb, "launches": [g1, g2],
         "correction": "FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 (same gfx950 corrections as below; operand panels re-read by "
                       "other column tiles are served by L2 / infinity cache and only partly reach the memory-side counters)",

@@ -27,6 +27,7 @@ python bench.py --config c4 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c4
 python bench.py --config c5 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c5_fp8.json 2> $O/bench_c5.err; echo "bench c5 rc=$?"
 python bench.py --config stc --steps 10 --warmup 2 > $O/bench_stc.json 2> $O/bench_stc.err; echo "bench stc rc=$?"; cat $O/bench_stc.json
 timeout 400 python tools/pipeline_stress.py --steps 60 --max-new 200 --plan 0 > $O/pipeline_stress.txt 2>&1; echo "stress rc=$?"; tail -3 $O/pipeline_stress.txt
+timeout 300 python tools/gemm_w4_check.py --time > $O/gemm_w4_check.txt 2>&1; echo "w4 check rc=$?"; grep -c "^ok" $O/gemm_w4_check.txt; grep "mismatching" $O/gemm_w4_check.txt
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_vitstream -- python $R/tools/vit_stream_profile.py > $R/$O/prof_vitstream.log 2>&1; echo "prof vit stream rc=$?"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_dec128 -- python $R/tools/decode_profile.py --batch 128 --steps 32 --eager > $R/$O/prof_dec128.log 2>&1; echo "prof dec128 rc=$?"

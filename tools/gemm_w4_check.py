@@ -1,5 +1,5 @@
 """gemm_w4.hip (variant 8: the persistent 256x256 tile on 4 waves of 128x128) against gemm_ldr.hip (variant 4) and gemm_pers.hip (variant 5): bit equality
-on small / ragged / large shapes with every epilogue, then interleaved timings on the ViT and prefill shapes (the library GEMM beside them as a yardstick).\npython tools/gemm_w4_check.py [--time]"""
+on small / ragged / large shapes with every epilogue, then interleaved timings on the ViT and prefill shapes (the library GEMM beside them as a yardstick).\npython tools/gemm_w4_check.py [--time] [--soak N]"""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trace_amd import engine as E
@@ -33,6 +33,22 @@ for (M, N, K) in [(300, 256, 192), (256, 512, 256), (1000, 1024, 1024), (5000, 5
             else:
                 print(f"ok M={M} N={N} K={K} {nm} bias={has_bias}", flush=True)
 print("mismatching cases:", bad)
+if "--soak" in sys.argv:
+    # many launches of the multi-tile walks (6 and 17 tiles per workgroup), every result compared: the kernel's counted waits are the kind of code that fails rarely
+    n = int(sys.argv[sys.argv.index("--soak") + 1])
+    for (M, N, K, epi) in [(98090, 1024, 1024, E.EPI_NONE), (70000, 4096, 1024, E.EPI_QUICKGELU), (3934, 28672, 4096, E.EPI_SWIGLU), (98090, 1024, 1024, E.EPI_RESIDUAL)]:
+        A, W = rnd(M, K), rnd(N, K, scale=0.03)
+        bias = rnd(N) if epi != E.EPI_SWIGLU else None
+        R = rnd(M, N) if epi == E.EPI_RESIDUAL else None
+        ref = run(4, A, W, bias, R, epi)
+        wrong = 0
+        ops.set_gemm_variant(8)
+        for i in range(n):
+            out = ops.gemm(A, W, bias=bias, R=R, epilogue=epi)
+            if i % 2:                                        # (every other launch runs back to back with the next: the compare is a different kernel mix in between)
+                wrong += int(not torch.equal(out, ref))
+        ops.set_gemm_variant(0)
+        print(f"soak M={M} N={N} K={K} epi={epi}: {wrong} wrong of {n // 2} compared launches ({n} launched)", flush=True)
 if "--time" in sys.argv:
     def timed(fn, n=5):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -30,10 +30,13 @@
 #include <unordered_map>
 #include "common.h"
 #include "kernels.h"
+#include "gemm_tilewalk.h"
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64, WM = 2, WN = 4;
+using tilewalk::BM; using tilewalk::BN; using tilewalk::BK; using tilewalk::CTR_STRIDE;
+using tilewalk::tile_coords; using tilewalk::Sched; using tilewalk::make_sched; using tilewalk::swap16;
+constexpr int WM = 2, WN = 4;
 constexpr int NMT = WM * WN * 64;                 // 512 MFMA threads
 constexpr int NLW = 4;                            // loader waves
 constexpr int NTHR = NMT + NLW * 64;              // 768
@@ -43,21 +46,9 @@ constexpr int CTL_OFF = 2 * STAGE;                // int s_next[2] | 2 x 512-byt
 constexpr int BIAS_OFF = CTL_OFF + 64;
 constexpr int TOUCH_OFF = BIAS_OFF + 2 * 512;    // 4 x 256 bytes: where the loader waves' L2 touches land (never read)
 constexpr int LDS_BYTES = TOUCH_OFF + 4 * 256;
-constexpr int CTR_STRIDE = 32;                    // ints between the per-XCD ticket counters (one 128-byte line each)
 
 __device__ __forceinline__ int swz(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ bf16x8_t lds16(const char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
-
-// logical tile id -> (row panel, column panel): groups of 8 row panels x all column panels (gemm.hip's order)
-__device__ __forceinline__ void tile_coords(int t, int ntm, int ntn, int& tm, int& tn) {
-    constexpr int GM = 8;
-    const int per_group = GM * ntn;
-    const int gid = t / per_group, first = gid * GM;
-    const int gsz = min(ntm - first, GM);
-    const int in_g = t - gid * per_group;
-    tm = first + in_g % gsz;
-    tn = in_g / gsz;
-}
 
 // One k-step (32 k of the 64-wide K-tile) of a wave's 128x64 sub-tile: 32 MFMAs.  wf / ac hold this step's W fragments and first
 // two A fragments on entry and the NEXT step's on exit (NEXT): the A fragments of m-tile pairs 1..3 are read a pair ahead as in
@@ -154,12 +145,6 @@ __device__ __forceinline__ void kstep(f32x4_t (&acc)[TM][TN], bf16x8_t (&wf)[TN]
     PERS_FENCE();
 }
 
-// v_permlane16_swap: rows (16 lanes) 1 and 3 of a <-> rows 0 and 2 of b
-__device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
-    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-    const u2_t r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
-    a = r[0]; b = r[1];
-}
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // rows I0 .. I0+NI-1 (16-row m-tiles) of the wave's sub-tile: activation in registers, lane transposition, stores.  C and R are addressed
@@ -287,22 +272,6 @@ __device__ __forceinline__ void residual_store(u32x4 (&out)[TM][2], u32x4 (&rr)[
             for (int e = 0; e < 4; ++e) v[e] = pack2bf(bflo(v[e]) + bflo(q[e]), bfhi(v[e]) + bfhi(q[e]));
             __builtin_amdgcn_raw_buffer_store_b128(v, crs, coff + i * cstep + h * (cstep >> 1), 0, 2);
         }
-}
-
-// which tiles this workgroup walks: its XCD's contiguous chunk of logical tile ids (common.h xcd_remap's split), first tile = its slot
-struct Sched {
-    int ntm, ntn, nk, xcd, slot, cnt, base, nwg;
-};
-__device__ __forceinline__ Sched make_sched(const GemmArgs& p) {
-    Sched sc;
-    sc.ntn = p.N / BN; sc.ntm = (p.M + BM - 1) / BM; sc.nk = p.K / BK;
-    const int total = sc.ntm * sc.ntn, G = gridDim.x;
-    sc.xcd = blockIdx.x & 7; sc.slot = blockIdx.x >> 3;
-    const int q8 = total >> 3, r8 = total & 7;
-    sc.cnt = q8 + (sc.xcd < r8 ? 1 : 0);
-    sc.base = (sc.xcd < r8) ? sc.xcd * (q8 + 1) : r8 * (q8 + 1) + (sc.xcd - r8) * q8;
-    sc.nwg = (G >> 3) + (sc.xcd < (G & 7) ? 1 : 0);                // workgroups on this XCD (<= cnt: the launcher keeps G <= total)
-    return sc;
 }
 
 // ---------------- loader wave lw: pieces of 8 tile rows x 128 bytes; lw 0,1 -> A rows 0..127 / 128..255, lw 2,3 -> W ----------------

@@ -20,10 +20,12 @@
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
+#include "gemm_tilewalk.h"
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64;
+using tilewalk::BM; using tilewalk::BN; using tilewalk::BK; using tilewalk::CTR_STRIDE;
+using tilewalk::tile_coords; using tilewalk::Sched; using tilewalk::make_sched; using tilewalk::swap16;
 constexpr int NTHR = 256;
 constexpr int TM = 8, TN = 8;                     // 16x16 fragments of a wave's 128x128 sub-tile
 constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
@@ -31,22 +33,11 @@ constexpr int CTL_OFF = 2 * STAGE;                // int s_next[2] | 2 x 512-byt
 constexpr int BIAS_OFF = CTL_OFF + 64;
 constexpr int TOUCH_OFF = BIAS_OFF + 2 * 512;     // 256 bytes: where the L2 touches land (never read)
 constexpr int LDS_BYTES = TOUCH_OFF + 256;
-constexpr int CTR_STRIDE = 32;
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 __device__ __forceinline__ uint32_t swz(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ uint32_t lds_u32(char* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)p; }
-
-__device__ __forceinline__ void tile_coords(int t, int ntm, int ntn, int& tm, int& tn) {      // gemm_pers.hip's order: groups of 8 row panels x all column panels
-    constexpr int GM = 8;
-    const int per_group = GM * ntn;
-    const int gid = t / per_group, first = gid * GM;
-    const int gsz = min(ntm - first, GM);
-    const int in_g = t - gid * per_group;
-    tm = first + in_g % gsz;
-    tn = in_g / gsz;
-}
 
 template <int OFF>
 __device__ __forceinline__ void lds_rd(bf16x8_t& d, uint32_t a) {
@@ -104,12 +95,6 @@ __device__ __forceinline__ f32x4_t acc_get(int n) {
 }
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-__device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
-    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-    const u2_t r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
-    a = r[0]; b = r[1];
-}
-
 // Four packed fragments of one 16-row m-tile (64 consecutive output columns; pk[f] = lane's 4 columns of fragment f) -> two 16-byte stores, each
 // 8 rows x one full 128-byte line (gemm_pers.hip epilogue_rows: v_permlane16_swap makes 8 consecutive columns per lane, DPP row_ror:8 trades a
 // piece between rows r and r + 8).  `off` = byte offset of the lane's piece in the first store; the second is 8 rows further.
@@ -128,21 +113,6 @@ __device__ __forceinline__ void line_pieces(uint32_t (&pk)[4][2], u32x4& A, u32x
         A[e] = hi8 ? rcv : P[0][e];
         B[e] = hi8 ? P[1][e] : rcv;
     }
-}
-
-struct Sched {
-    int ntm, ntn, nk, xcd, slot, cnt, base, nwg;
-};
-__device__ __forceinline__ Sched make_sched(const GemmArgs& p) {
-    Sched sc;
-    sc.ntn = p.N / BN; sc.ntm = (p.M + BM - 1) / BM; sc.nk = p.K / BK;
-    const int total = sc.ntm * sc.ntn, G = gridDim.x;
-    sc.xcd = blockIdx.x & 7; sc.slot = blockIdx.x >> 3;
-    const int q8 = total >> 3, r8 = total & 7;
-    sc.cnt = q8 + (sc.xcd < r8 ? 1 : 0);
-    sc.base = (sc.xcd < r8) ? sc.xcd * (q8 + 1) : r8 * (q8 + 1) + (sc.xcd - r8) * q8;
-    sc.nwg = (G >> 3) + (sc.xcd < (G & 7) ? 1 : 0);
-    return sc;
 }
 
 // stores per wave and tile that an epilogue leaves behind the next tile's first pieces (the in-order counter is waited down to them, not to 0)

@@ -172,7 +172,7 @@ int trace_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int l
                   int ldr, int M, int N, int K, int epilogue, void* stream);
 /* GEMM kernel selection for tests / microbenchmarks (process-wide): 0 auto, 2 = 128^2 tiles, 3 = 256^2 tiles (gemm.hip), 4 = gemm_ldr.hip, 5-7 = gemm_pers.hip
  * (ticketed / static deal / one tile per workgroup), 8 = gemm_w4.hip.  Other ranges are A/B switches of single kernels (engine.hip trace_op_set_gemm_variant:
- * 300 + opt K-loop builds, 500-501 tile walk, 520-521 residual shapes on the persistent kernel, 530-531 gemm_pers / gemm_w4 in auto mode, 190-192 ViT attention ...). */
+ * 300 + opt K-loop builds, 500-501 tile walk, 520-521 residual shapes on the persistent kernel, 530-531 gemm_pers / gemm_w4 in auto mode, 540 + opt gemm_w4 builds, 190-192 ViT attention ...). */
 int trace_op_set_gemm_variant(int variant);
 /* profiling: device buffer of 8 x uint64 per workgroup receiving phase time stamps of every later GEMM launch (NULL = off) */
 int trace_op_set_gemm_trace(void* buf);

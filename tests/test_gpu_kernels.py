@@ -132,7 +132,7 @@ def test_gemm_four_wave_kernel_equals_loader_wave_kernel(M, N, K):
             ref = ops.gemm(A, W, epilogue=epi, **kw)
             for walk, opt in ((500, 0), (501, 0), (500, 1), (500, 4), (500, 5)):
                 ops.set_gemm_variant(walk)
-                ops.set_gemm_variant(300 + opt)
+                ops.set_gemm_variant(540 + opt)
                 for rep in range(3):
                     ops.set_gemm_variant(8)
                     got = ops.gemm(A, W, epilogue=epi, **kw)
@@ -141,7 +141,7 @@ def test_gemm_four_wave_kernel_equals_loader_wave_kernel(M, N, K):
                         ops.set_gemm_variant(5)
                         assert torch.equal(ops.gemm(A, W, epilogue=epi, **kw), ref)
             ops.set_gemm_variant(500)
-            ops.set_gemm_variant(300)
+            ops.set_gemm_variant(540)
         ops.set_gemm_variant(4)
         ref = ops.gemm(A, W, R=R, epilogue=E.EPI_RESIDUAL)
         ops.set_gemm_variant(8)
@@ -150,7 +150,7 @@ def test_gemm_four_wave_kernel_equals_loader_wave_kernel(M, N, K):
         assert torch.equal(Rc, ref)
     finally:
         ops.set_gemm_variant(500)
-        ops.set_gemm_variant(300)
+        ops.set_gemm_variant(540)
         ops.set_gemm_variant(0)
 
 

@@ -76,11 +76,11 @@ if "--time" in sys.argv:
                 if v < 0:
                     ts[k].append(timed(lambda: torch.nn.functional.linear(A, W, bias)))
                 else:
-                    ops.set_gemm_variant(300 + o)
+                    ops.set_gemm_variant(540 + o)
                     ops.set_gemm_variant(v)
                     ts[k].append(timed(lambda: ops.gemm(A, W, bias=bias, R=R, epilogue=epi)))
                     ops.set_gemm_variant(0)
-                    ops.set_gemm_variant(300)
+                    ops.set_gemm_variant(540)
         med = {k: statistics.median(v[1:]) for k, v in ts.items()}
         tf = lambda t: 2.0 * M * N * K / t / 1e6
         print("%-20s M=%6d N=%5d K=%5d | " % (name, M, N, K) + " | ".join("%s %7.1f us %6.1f TF" % (k, med[k], tf(med[k])) for k in med), flush=True)

@@ -1418,6 +1418,7 @@ extern int g_gemm_ldr_opt;
 extern int g_gemm_pers_walk;
 extern int g_gemm_resid_pers;
 extern int g_gemm_w4;
+extern int g_gemm_w4_opt;
 extern int g_attn_vit_big;
 extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 1000 && variant <= 1000 + 1024) { g_gemm_pers_grid_cap = variant - 1000; return TRACE_OK; }   // persistent GEMM: at most n workgroups (0 = #CUs)
@@ -1434,7 +1435,8 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }
     if (variant >= 500 && variant <= 501) { g_gemm_pers_walk = variant - 500; return TRACE_OK; }   // the persistent GEMM's tile walk on every route (gemm_pers.hip)
     if (variant >= 520 && variant <= 521) { g_gemm_resid_pers = variant - 520; return TRACE_OK; }
-    if (variant >= 530 && variant <= 531) { g_gemm_w4 = variant - 530; return TRACE_OK; }   // non-residual 256^2 shapes: 0 = gemm_pers.hip, 1 = gemm_w4.hip (auto routing)   // residual GEMMs on the persistent kernel too (auto routing)
+    if (variant >= 530 && variant <= 531) { g_gemm_w4 = variant - 530; return TRACE_OK; }
+    if (variant >= 540 && variant < 548) { g_gemm_w4_opt = variant - 540; return TRACE_OK; }   // gemm_w4.hip A/B builds: bit 0 = one barrier per K-tile, bit 2 = L2 touches of the A panel   // non-residual 256^2 shapes: 0 = gemm_pers.hip, 1 = gemm_w4.hip (auto routing)   // residual GEMMs on the persistent kernel too (auto routing)
     if (variant >= 400 && variant < 404) { g_gemm_ldr_opt = variant - 400; return TRACE_OK; }   // gemm_ldr A/B: bit 0 = no residual touches, bit 1 = no A-panel touches
     if (variant < 0 || variant > 8) return fail(TRACE_ERR_ARG, "variant must be 0..8");
     g_gemm_variant = variant;

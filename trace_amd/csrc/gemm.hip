@@ -371,10 +371,10 @@ int launch_glds(const GemmArgs& p, int epi, hipStream_t s) {
 int g_gemm_variant = 0;   // 0 = auto, 2 = 128^2 tiles, 3 = this file's 256^2 kernel, 4 = the loader-wave 256^2 kernel, 5 / 6 = the persistent one
                           // (gemm_pers.hip; 6 = static tile deal) — tests / microbench
 extern int g_gemm_pers_static;
-int g_gemm_w4 = -1;          // non-residual 256^2 shapes on gemm_w4.hip in auto mode: 1 / 0 (trace_op_set_gemm_variant(530 + x)); -1 = not decided yet: TRACE_GEMM_W4 or the default
+int g_gemm_w4 = -1;          // non-residual 256^2 shapes on gemm_w4.hip in auto mode: 1 / 0 (trace_op_set_gemm_variant(530 + x)); -1 = TRACE_GEMM_W4 from the environment, else on
 static bool gemm_w4_enabled() {
-    if (g_gemm_w4 < 0) { const char* e = getenv("TRACE_GEMM_W4"); g_gemm_w4 = e ? (atoi(e) != 0) : 1; }
-    return g_gemm_w4 != 0;
+    static const int env = getenv("TRACE_GEMM_W4") ? (atoi(getenv("TRACE_GEMM_W4")) != 0) : 1;      // (read once; the pipeline's two host threads both come through here)
+    return g_gemm_w4 < 0 ? env != 0 : g_gemm_w4 != 0;
 }
 int g_gemm_resid_pers = 0;   // 1: residual shapes also run on the persistent kernel in auto mode (trace_op_set_gemm_variant(520 + x); A/B runs)
 

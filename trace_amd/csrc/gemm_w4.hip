@@ -394,7 +394,7 @@ void launch_opt(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
 }
 template <int EPI>
 void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
-    switch (p.opt & 5) {          // A/B builds (trace_op_set_gemm_variant(300 + opt)): bit 0 = without the re-aligning barrier, bit 2 = with the L2 touches of the A panel
+    switch (p.opt & 5) {          // A/B builds (trace_op_set_gemm_variant(540 + opt)): bit 0 = without the re-aligning barrier, bit 2 = with the L2 touches of the A panel
         case 1: launch_opt<EPI, 1>(p, nblk, dynamic, ctr, s); break;
         case 4: launch_opt<EPI, 4>(p, nblk, dynamic, ctr, s); break;
         case 5: launch_opt<EPI, 5>(p, nblk, dynamic, ctr, s); break;
@@ -404,12 +404,13 @@ void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
 
 }  // namespace
 
-extern int g_gemm_pers_static, g_gemm_pers_walk, g_gemm_pers_opt;
+extern int g_gemm_pers_static, g_gemm_pers_walk;
+int g_gemm_w4_opt = 0;             // A/B builds of this kernel (trace_op_set_gemm_variant(540 + opt)): bit 0 = without the re-aligning barrier, bit 2 = with the L2 touches of the A panel
 
 // TRACE_ERR_STATE: no ticket counters for this stream and none can be made now (capturing): the caller falls back
 int launch_gemm_w4(const GemmArgs& p0, int epi, hipStream_t s) {
     GemmArgs p = p0;
-    p.opt = g_gemm_pers_opt;
+    p.opt = g_gemm_w4_opt;
     if (p.M < 1 || p.N % BN || p.K % BK || p.K < 3 * BK || p.fp8) return TRACE_ERR_ARG;
     if ((long)p.M * p.ldc >= (1L << 30) || (epi == EPI_RESIDUAL && (long)p.M * p.ldr >= (1L << 30))) return TRACE_ERR_ARG;   // 32-bit byte offsets
     if ((long)p.M * p.lda >= (1L << 31) || (long)p.N * p.ldw >= (1L << 31)) return TRACE_ERR_ARG;                            // 32-bit piece offsets

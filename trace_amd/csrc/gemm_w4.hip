@@ -3,7 +3,7 @@
 // Why: gemm_pers.hip's 8 MFMA waves hold 128x64 each, so a K-tile costs 192 KB of fragment reads (12 KB per wave and k-step) for its 2048 MFMA
 // cycles per SIMD; a 128x128 sub-tile needs 16 KB per wave and k-step for TWICE the MFMAs — 128 KB per K-tile, a third less LDS traffic per flop
 // (tools/gemm_lib_yardstick.py: the vendor library's kernels for these shapes are 256x256x64 tiles on 4 waves and run 2-9 % ahead of gemm_pers).
-// The price: 256 accumulator registers per lane (they live in AGPRs: the MFMAs are inline asm with "a" operands), ONE wave per SIMD — nothing
+// The price: 256 accumulator registers per lane (they live in AGPRs that only the inline asm names: gemm_agpr.h), ONE wave per SIMD — nothing
 // hides a stall, so the wave's own instruction stream is the schedule — and no spare waves to do the loading: the four waves issue the LDS-DMA
 // pieces themselves, between their MFMAs.
 //
@@ -13,7 +13,9 @@
 //   landed; s_barrier — so have everyone's, and the stage of K-tile q is free;
 //   k-step 1: 64 MFMAs on buffer 1; under them this wave's 16 LDS-DMA pieces of K-tile q + 2 into the freed stage, and the 16 fragment reads
 //   of K-tile q + 1's k-step 0 into buffer 0.
-// One barrier per K-tile, one K-tile period of load slack (as gemm_pers.hip), the stream of K-tiles runs across output tiles.
+// One hand-over barrier per K-tile (plus one at its start that only re-aligns the four waves), half to one K-tile period of load slack, the stream of K-tiles runs
+// across output tiles.  Waits are counted by hand (s_waitcnt vmcnt(N): 0 in a tile, the epilogue's store count behind one): every VMEM operation of the kernel has a
+// fixed place in the wave's instruction stream, and tests/test_kernel_resources.py fails a build that spills (a scratch access is a VMEM operation the counts do not know).
 // All LDS reads are inline asm: hipcc's wait-count pass cannot tell a ds_read from the LDS-DMA writes in flight and would put s_waitcnt vmcnt(0)
 // in front of every one (cdna_hip_programming.md, "Pipelining across barriers"; attn.hip's 192-row kernel met the same thing).
 // Same LDS image (XOR swizzle on the DMA source), same K order, same fp32 -> bf16 roundings as gemm_pers.hip / gemm_ldr.hip: bit-identical results.
@@ -92,9 +94,6 @@ __device__ __forceinline__ void line_pieces(uint32_t (&pk)[4][2], u32x4& A, u32x
         B[e] = hi8 ? P[1][e] : rcv;
     }
 }
-
-// stores per wave and tile that an epilogue leaves behind the next tile's first pieces (the in-order counter is waited down to them, not to 0)
-template <int EPI> constexpr int epi_stores() { return EPI == EPI_SWIGLU ? 2 * TM : 4 * TM; }
 
 template <int EPI, int OPT>
 __global__ __launch_bounds__(NTHR) void gemm_w4_kernel(GemmArgs p, int* ctr, int dynamic) {

@@ -335,9 +335,10 @@ def main():
     ap.add_argument("--fp8-scheme", choices=["w8a8", "weight_only"], default="weight_only",
                     help="fp8 path: W8A8 everywhere, or W8A8 prefill GEMMs + weight-only (bf16 activations) decode GEMVs (default; tests/test_gpu_fp8.py: fewer 13-way arg-max flips)")
     ap.add_argument("--plumbing-check", action="store_true", help="launcher / rendezvous / gather only, no kernels (CPU-testable)")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the captured hipGraph for decode steps (default: eager launches, which run at the same speed "
-                         "— the step is GPU-bound — and allow the per-launch HIP-event roofline probe in the timed region)")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=False,
+                    help="replay the captured hipGraph for decode steps; the roofline_hbm bracket (a per-launch HIP-event pair, which a graph cannot carry) is "
+                         "then taken in a short eager pass after the timed region and the line says so")
+    ap.add_argument("--eager", dest="graph", action="store_false", help="decode steps as eager launches (the per-launch roofline probe sits in the timed region)")
     ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=True,
                     help="(the default since round 4) two-stage pipeline over the timed steps — batch k decodes on one stream while batch k+1 runs its ViT + prefill "
                          "on another (TraceEngine.generate_stream): +2-3 %% videos/s.  Round 3 kept it off: over ~100 pipelined steps one video's ViT features "
@@ -438,6 +439,7 @@ def main():
 
     run(args.warmup)
     eng.set_profile(2)
+    eng.stage_timing(True)               # event pairs around the tower / slot-pool / prefill calls of the batch(es) that have the GPU to themselves
     tdist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     outs = run(args.steps)
@@ -460,20 +462,31 @@ def main():
               file=sys.stderr, flush=True)
     steps_repeat = tdist.max_over_ranks(1.0 if repeat_detail else 0.0) == 0.0          # over all ranks (a collective: every rank gets here)
     prof = eng.get_profile()
+    in_region = eng.stage_times()        # the fill batch of the pipeline (or every batch of a sequential run): tower / slot pool / prefill ms by events
+    eng.stage_timing(False)
     eng.set_profile(0)
 
-    # stage breakdown (outside the timed region; rank 0 only prints it)
-    def ev_time(fn):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); fn(); b.record(); torch.cuda.synchronize()
-        return a.elapsed_time(b)
-    if B >= 2 and eng.vit_batch_frames > args.frames:          # as in generate(): the tower runs over the whole batch's frame stream
+    # stage breakdown (outside the timed region; rank 0 only prints it).  Every stage is run once untimed in the call shape it is then timed in
+    # (round 5's single cold shot gave 0.367 / 0.400 for the same binary: profiles/README.md), then timed REPS times: median, min, max.
+    REPS = 3
+
+    def ev_stat(fn, reps=REPS):
+        fn(); torch.cuda.synchronize()
+        ts_ = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); torch.cuda.synchronize()
+            ts_.append(a.elapsed_time(b))
+        return float(np.median(ts_)), float(min(ts_)), float(max(ts_))
+    if B >= 2 and eng.vit_batch_frames > args.frames:          # as in generate(): the tower runs over the batch's frame stream, 12 GB of features at a time
         def enc_all():
-            for f, t in zip(eng.vit_forward_many(videos), ts):
-                eng.encode_features(f, t)
-        t_enc = ev_time(enc_all) / B
+            for g0, g1 in eng.feature_groups(videos):
+                for f, t in zip(eng.vit_forward_many(videos[g0:g1]), ts[g0:g1]):
+                    eng.encode_features(f, t)
+        enc3 = [x / B for x in ev_stat(enc_all)]
     else:
-        t_enc = ev_time(lambda: eng.encode_video(videos[0], ts[0]))
+        enc3 = list(ev_stat(lambda: eng.encode_video(videos[0], ts[0])))
+    t_enc = enc3[0]
     # the KV slots of the last timed batch are still prefilled (a decode only appends behind the prompt): the decode stage is re-timed on them; the
     # prefill stage is timed into slots of the other bank (pipelined) or over the first slots (the same prompts again)
     slot_base = ((args.steps - 1) % 2) * B if pipelined else 0
@@ -485,17 +498,32 @@ def main():
         Ls, e = eng.splice(ids, want_output=True)
         embs.append(e.clone())
     if npf >= 3:                                     # as in generate(): runs of equal-length neighbours share one prefill pass
-        t_pre = ev_time(lambda: eng.prefill_multi(pf_slot, embs)) / npf
+        pre3 = [x / npf for x in ev_stat(lambda: eng.prefill_multi(pf_slot, embs))]
     elif npf == 2:
-        t_pre = ev_time(lambda: eng.prefill_pair(pf_slot, embs[0], embs[1])) / 2
+        pre3 = [x / 2 for x in ev_stat(lambda: eng.prefill_pair(pf_slot, embs[0], embs[1]))]
     else:
-        t_pre = ev_time(lambda: eng.prefill(pf_slot, Ls, embeds=embs[0]))
-    eng.decode_begin(list(range(slot_base, slot_base + B)), heads, n_new, -1, forced)
-    t_dec = ev_time(lambda: eng.decode_steps(n_new - 1, use_graph=args.graph))
+        pre3 = list(ev_stat(lambda: eng.prefill(pf_slot, Ls, embeds=embs[0])))
+    t_pre = pre3[0]
+
+    def dec_all():
+        eng.decode_begin(list(range(slot_base, slot_base + B)), heads, n_new, -1, forced)       # every repetition restarts at the prefilled context
+        eng.decode_steps(n_new - 1, use_graph=args.graph)
+    dec3 = list(ev_stat(dec_all, reps=2 if n_new > 64 else REPS))
+    t_dec = dec3[0]
+    prof_k = prof
+    if args.graph and n_new > 1:
+        # hipGraph replay leaves no room for per-launch event brackets (event-record nodes inside a graph give no usable timestamps on ROCm 7.2):
+        # the `roofline_hbm` bracket is taken here, in a short EAGER pass over the same prefilled slots, outside the timed region
+        eng.set_profile(2)
+        eng.decode_begin(list(range(slot_base, slot_base + B)), heads, n_new, -1, forced)
+        eng.decode_steps(min(n_new - 1, 32), use_graph=False)
+        torch.cuda.synchronize()
+        prof_k = eng.get_profile()
+        eng.set_profile(0)
     # the drivers' shape of use: ONE video, batch 1, end to end (latency, not part of `value`)
     one = lambda: eng.generate(videos[:1], ts[:1], prompt[:1], heads[:1], n_new, eos=-1, use_graph=True, forced=forced[:1])
-    one()                                            # captures the batch-1 decode graph
-    t_one = ev_time(one)
+    one3 = list(ev_stat(one))                        # (the untimed first call captures the batch-1 decode graph)
+    t_one = one3[0]
 
     # per-rank figures (a collective: every rank gets here): a sub-linear N-GPU curve must show which rank was slow and in which stage
     rank_keys = ["ms_per_step", "vit_slotpool_per_video_ms", "prefill_per_video_ms", "decode_ms_per_step", "weights_load_s", "single_video_latency_ms", "numa_node"]
@@ -505,7 +533,7 @@ def main():
         vps = world * B * args.steps / dt
         vit_flops = args.frames * (366.0e9 if not args.tiny else 0.0)
         pre_flops = 2 * 6.979e9 * Ls + 32 * 2 * Ls * Ls * 4096 if not args.tiny else 0.0
-        k_ms, k_n, k_bytes = prof[2], int(prof[3]), prof[4]
+        k_ms, k_n, k_bytes = prof_k[2], int(prof_k[3]), prof_k[4]
         ach = (k_bytes / (k_ms * 1e-3) / 1e9) if k_ms > 0 else None
         traffic = g_traffic = g_traffic_M = None
         traffic_src = None
@@ -518,9 +546,9 @@ def main():
                 traffic_src = {"file": "profiles/traffic.json", "measured": tj.get("measured", "round 4"),
                                "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_kernels.py (same launch shapes as the brackets of this run), FETCH_SIZE x 2 (gfx950)"}
                 traffic, g_traffic, g_traffic_M = tj.get("skinny_gateup_bytes_per_launch"), tj.get("gemm_fc1_bytes_per_launch"), tj.get("gemm_fc1_M", 73856)
-                if int(prof[8]) == 3:      # the wide decode step brackets the decode attention: the committed PMC pass measured it at one batch / context
+                if int(prof_k[8]) == 3:      # the wide decode step brackets the decode attention: the committed PMC pass measured it at one batch / context
                     traffic = tj.get("attn_decode_bytes_per_launch") if tj.get("attn_decode_batch") == B else None
-                elif int(prof[8]) != 1 or args.fp8:
+                elif int(prof_k[8]) != 1 or args.fp8:
                     traffic = None
             except Exception:
                 traffic = g_traffic = None
@@ -543,7 +571,7 @@ def main():
                                     f"{preset['name'].replace(' bf16', ' ' + args.dtype)}, {args.frames}x336^2 frames, prefill L={Ls}, {n_new} greedy tokens, heads=[1]"),
                        "baseline_config": args.config,
                        "videos_per_step_per_gpu": B, "frames": args.frames, "prefill_len": Ls, "new_tokens": n_new, "head_schedule": ("forced MR pattern: 14 time + 4 score + 14 text steps per 32 tokens" if preset["schedule"] == "mr" else "forced DVC pattern per event: 14 time + 4 score + 33 text steps") + " (argmax still computed every step)",
-                       "decode_launch": "hipGraph" if args.graph else "eager", "parallelism": f"dp{world} (replica per GPU)",
+                       "decode_launch": ("hipGraph replay (the roofline_hbm bracket is taken in a short eager pass after the timed region)" if args.graph else "eager"), "parallelism": f"dp{world} (replica per GPU)",
                        "step_schedule": ("two-stage pipeline over the timed steps: step k's decode on one HIP stream under step k+1's ViT + prefill on another "
                                          "(fill and drain inside the timed region; the roofline brackets are taken in the fill / drain phases only)"
                                          if pipelined else "steps strictly one after the other"),
@@ -562,7 +590,20 @@ def main():
             "stages_ms": {"vit_slotpool_per_video": t_enc, "prefill_per_video": t_pre, f"decode_{n_new - 1}_steps_batch{B}": t_dec,
                           "decode_ms_per_step": t_dec / (n_new - 1), "weights_load_s": t_load},
             "single_video_latency_ms": t_one,
-            "mfma_util": {"vit": vit_flops / (t_enc * 1e-3) / 2.5e15, "prefill": pre_flops / (t_pre * 1e-3) / 2.5e15},
+            # medians of REPS warm repetitions after the timed region (min / max beside them), and the same two fractions from HIP events INSIDE the
+            # timed region: the pipeline's fill batch (sequential runs: every batch), while the encode stage has the GPU to itself
+            "mfma_util": {"vit": vit_flops / (t_enc * 1e-3) / 2.5e15, "prefill": pre_flops / (t_pre * 1e-3) / 2.5e15,
+                          "vit_min_max": [vit_flops / (enc3[2] * 1e-3) / 2.5e15, vit_flops / (enc3[1] * 1e-3) / 2.5e15],
+                          "prefill_min_max": [pre_flops / (pre3[2] * 1e-3) / 2.5e15, pre_flops / (pre3[1] * 1e-3) / 2.5e15],
+                          "repetitions": REPS, "how": "algorithmic FLOPs (SURVEY 8d) / median stage time / 2.5e15; each stage warmed once in its call shape, then timed REPS times",
+                          "in_timed_region": ({"vit": vit_flops * in_region["videos"] / ((in_region["tower_ms"] + in_region["slotpool_ms"]) * 1e-3) / 2.5e15,
+                                               "prefill": pre_flops * in_region["videos"] / (in_region["prefill_ms"] * 1e-3) / 2.5e15,
+                                               "videos": in_region["videos"], "tower_ms_per_video": in_region["tower_ms"] / in_region["videos"],
+                                               "slotpool_ms_per_video": in_region["slotpool_ms"] / in_region["videos"],
+                                               "prefill_ms_per_video": in_region["prefill_ms"] / in_region["videos"],
+                                               "how": "HIP-event pairs around the tower / slot-pool / prefill calls of the batch(es) that ran with the GPU to themselves inside the timed region"}
+                                              if in_region["videos"] and in_region["prefill_ms"] > 0 and in_region["tower_ms"] > 0 else None)},
+            "stages_ms_min_max": {"vit_slotpool_per_video": enc3[1:], "prefill_per_video": pre3[1:], f"decode_{n_new - 1}_steps_batch{B}": dec3[1:], "single_video_latency": one3[1:]},
             # dominant kernel of the run: the 256x256 MFMA GEMM (its four epilogue variants are ~half of GPU time; the probe
             # brackets its largest instance, the ViT fc1 projection, once per video inside the timed region)
             "roofline": {"bound": "mfma", "kernel": f"256x256-tile LDS-DMA MFMA GEMM family (gemm_ldr: 8 MFMA + 4 loader waves, one tile per workgroup; {pers_sym.split('_kernel')[0]}: persistent workgroups): by total time the run's top symbol is gemm_ldr_kernel<EPI_RESIDUAL> (ViT out-proj + fc2, prefill o / down); achieved / frac below are its largest single launch, {pers_sym}<EPI_QUICKGELU{fold_tag}> = ViT fc1 {g_M}x4096x1024 of one {eng.vit_batch_frames if B >= 2 else args.frames}-frame tower call (1 bracketed launch per call); every ViT shape of the family is in `shapes`",
@@ -584,7 +625,7 @@ def main():
                                                  + 3 * cfg.hidden_size * cfg.intermediate_size) * (0.5 if args.fp8 else 1.0)
         line["decode_step"] = {"algorithmic_gb": (kv_step + w_step) / 1e9, "weights_gb": w_step / 1e9, "kv_gb": kv_step / 1e9,
                                "tb_per_s": (kv_step + w_step) / (t_dec / (n_new - 1) * 1e-3) / 1e12, "gb_per_token": (kv_step + w_step) / B / 1e9}
-        bkind = int(prof[8])            # which launch the engine put the decode bracket around (it knows which decode path the batch took)
+        bkind = int(prof_k[8])            # which launch the engine put the decode bracket around (it knows which decode path the batch took)
         hbm_kernel = {3: "attn_decode_kernel (decode attention over the batch's KV cache, layer 0, 1 bracketed launch per decode step; wide decode step: "
                          "projections as small-M MFMA GEMMs)",
                       2: "skinny_lds_kernel<EPI_PARTIAL, fused RMSNorm prologue> (batch-1 decode gate|up GEMV, 1 bracketed launch per decode step)",
@@ -593,7 +634,9 @@ def main():
         line["roofline_hbm"] = {"bound": "hbm", "kernel": hbm_kernel,
                                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
                                 "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
-                                "algorithmic_bytes_per_launch": k_bytes, "avg_launch_ms": k_ms, "samples": k_n}
+                                "algorithmic_bytes_per_launch": k_bytes, "avg_launch_ms": k_ms, "samples": k_n,
+                                "bracket_taken": ("in a short eager pass over the same prefilled KV slots after the timed region (inside it the decode steps are hipGraph replays)"
+                                                  if args.graph else "inside the timed region (eager launches; pipelined runs: during the drain only)")}
         if world > 1:
             # timed on rank 0 of the single-GPU run only (the host cores are busy driving N ranks here): the N = 1 line of the same round carries it
             line["cpu_baseline"] = {"value": None, "unit": "videos/s", "cores": None, "kind": "port",

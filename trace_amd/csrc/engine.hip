@@ -1420,12 +1420,17 @@ extern int g_gemm_resid_pers;
 extern int g_gemm_w4;
 extern int g_gemm_w4_opt;
 extern int g_attn_vit_big;
+extern int g_partial_cfg;
+extern int g_partial_wgs;
 extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 1000 && variant <= 1000 + 1024) { g_gemm_pers_grid_cap = variant - 1000; return TRACE_OK; }   // persistent GEMM: at most n workgroups (0 = #CUs)
     if (variant >= 100 && variant < 104) { g_attn_debug = variant - 100; return TRACE_OK; }
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
+    if (variant >= 740 && variant <= 743) { g_partial_cfg = variant - 740; return TRACE_OK; }        // tile shape of the decode partial-row GEMM (gemm.hip)
+    if (variant >= 800 && variant <= 832) { g_partial_wgs = (variant - 800) * 32; return TRACE_OK; }   // its workgroup target (0 = default 256)
+    if (variant >= 700 && variant < 732) { g_decode_gemm_tiled = variant - 700; return TRACE_OK; }   // the same word with its round-6 bits: 2 = nt weight DMA, 8 / 16 = nt / write-through partial-row stores
     if (variant >= 160 && variant <= 161) { g_vit_patch_fused = variant - 160; return TRACE_OK; }
     if (variant >= 170 && variant <= 174) { g_decode_fuse_norm_rows = variant - 170; return TRACE_OK; }
     if (variant >= 180 && variant <= 181) { g_decode_fuse_swiglu = variant - 180; return TRACE_OK; }

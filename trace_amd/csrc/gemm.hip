@@ -150,9 +150,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
                                              (__attribute__((address_space(3))) void*)(sw + (i * NTHR + wid * 64) * 16), 16, 0, 0);
         }
     };
+    const bool w_nt = WT && (p.w_tiled & 2);           // A/B: non-temporal hint on the weight DMA (a stream ONE workgroup reads once)
     auto issue_w = [&](int kt) {
         char* sw = w_stage(NSTAGE > 2 ? kt % NSTAGE : kt & 1);
         const int ko = kt * (WT ? 2048 : 128);         // bytes: one K-tile = 128-byte rows / one 2 KB block per 16-row tile
+        if (w_nt) {
+#pragma unroll
+            for (int i = 0; i < W_IT; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + ko),
+                                                 (__attribute__((address_space(3))) void*)(sw + (i * NTHR + wid * 64) * 16), 16, 0, 2);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < W_IT; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + ko),
@@ -184,8 +192,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
             // tile kt landed: this thread's pieces by its own counted wait (the later tiles' A_IT + W_IT pieces each may stay in flight), everybody's
             // by the barrier — which also says every wave is done reading tile kt - 1, whose stage the DMA issued next overwrites
             constexpr int PPT = A_IT + W_IT;
+            static_assert((NSTAGE - 2) * PPT < 64, "vmcnt is a 6-bit counter");
             const int ahead = min(nk - 1 - kt, NSTAGE - 2);
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
+            if (NSTAGE >= 5 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE >= 5 ? 3 * PPT : 0) : "memory");
+            else if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -240,8 +250,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs p) {
             const int m = m0 + wm * (BM / WM) + i * 16 + r;
             if (m < p.M) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    *reinterpret_cast<f32x4_t*>(pr + (size_t)m * p.N + n0 + wn * (BN / WN) + j * 16 + g * 4) = acc[i][j];
+                for (int j = 0; j < TN; ++j) {
+                    float* dst = pr + (size_t)m * p.N + n0 + wn * (BN / WN) + j * 16 + g * 4;
+                    // A/B (w_tiled bits 3 / 4): the partial rows leave as non-temporal / write-through (sc1) stores — the next kernel reads them, and
+                    // dirty lines left in the L2s are written back at the kernel boundary (MI355X_MICROARCH.md "boundary": + bytes / 6 TB/s)
+                    if (p.w_tiled & 8) __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f32x4_t*>(dst));
+                    else if (p.w_tiled & 16) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(acc[i][j]) : "memory");
+                    else *reinterpret_cast<f32x4_t*>(dst) = acc[i][j];
+                }
             }
         }
         return;
@@ -378,20 +394,29 @@ static bool gemm_w4_enabled() {
 }
 int g_gemm_resid_pers = 0;   // 1: residual shapes also run on the persistent kernel in auto mode (trace_op_set_gemm_variant(520 + x); A/B runs)
 
-// split-K partial-row GEMM for decode batches above SKINNY_ROWS: M <= 128 rows (one row panel), 128x128 tiles, ks chunks of K
-template <int EPI, bool WT, int NSTAGE>
+// split-K partial-row GEMM for decode batches above SKINNY_ROWS: M <= 128 rows (one row panel), 128 x BN tiles, ks chunks of K
+template <int EPI, bool WT, int NSTAGE, int BN = 128, int WM = 2, int WN = 2>
 static int launch_dec(const GemmArgs& p, int nblk, hipStream_t s) {
-    constexpr int STAGE = (128 + 128) * 128, LOOPB = NSTAGE * STAGE, OBYTES = 128 * (128 * 2 + 16), LDSB = LOOPB > OBYTES ? LOOPB : OBYTES;
+    constexpr int STAGE = (128 + BN) * 128, LOOPB = NSTAGE * STAGE, OBYTES = 128 * (BN * 2 + 16), LDSB = LOOPB > OBYTES ? LOOPB : OBYTES;
     static LdsGrant grant;
-    if (!grant_dynamic_lds(grant, reinterpret_cast<const void*>(gemm_glds_kernel<128, 128, 2, 2, EPI, false, WT, NSTAGE>), LDSB)) return TRACE_ERR_HIP;
-    hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, EPI, false, WT, NSTAGE>), dim3(nblk), dim3(256), LDSB, s, p);
+    if (!grant_dynamic_lds(grant, reinterpret_cast<const void*>(gemm_glds_kernel<128, BN, WM, WN, EPI, false, WT, NSTAGE>), LDSB)) return TRACE_ERR_HIP;
+    hipLaunchKernelGGL((gemm_glds_kernel<128, BN, WM, WN, EPI, false, WT, NSTAGE>), dim3(nblk), dim3(256), LDSB, s, p);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
+// Tile shape of the partial-row GEMM (A/B: trace_op_set_gemm_variant(740 + x)): 0 = 128 x 128 on 2 x 2 waves, 4-stage ring (round 3); 1 / 2 / 3 = 128 x 64 on
+// 4 x 1 waves with a 5- / 3- / 4-stage ring (24 KB stages: half the partial-row bytes per product at the same number of workgroups, K loops twice as long;
+// the 3-stage form fits two workgroups per CU)
+int g_partial_cfg = 0;
+int g_partial_wgs = 0;      // workgroup target of gemm_partial_ks (0 = TRACE_PARTIAL_WGS from the environment, else 256; A/B: trace_op_set_gemm_variant(800 + n / 32))
+static int partial_bn() { return g_partial_cfg ? 64 : 128; }
 static int launch_partial(const GemmArgs& p, hipStream_t s) {
-    if (p.M < 1 || p.M > SK_ROWS || p.N % 128 || p.K % BK || p.fp8 || !p.part || p.ks < 1 || (p.K / BK) % p.ks) return TRACE_ERR_ARG;
+    const int bn = (p.w_tiled & 1) ? partial_bn() : 128;
+    if (p.M < 1 || p.M > SK_ROWS || p.N % bn || p.K % BK || p.fp8 || !p.part || p.ks < 1 || (p.K / BK) % p.ks) return TRACE_ERR_ARG;
     if ((p.lda % 8) || (p.ldw % 8)) return TRACE_ERR_ARG;
-    const int nblk = ((p.M + 127) / 128) * (p.N / 128) * p.ks;      // above 128 rows: two row panels (neighbours in the tile order: the second reads its weight tile from L2)
-    if (!p.w_tiled) return launch_dec<EPI_PARTIAL, false, 2>(p, nblk, s);
+    const int nblk = ((p.M + 127) / 128) * (p.N / bn) * p.ks;      // above 128 rows: two row panels (neighbours in the tile order: the second reads its weight tile from L2)
+    if (!(p.w_tiled & 1)) return launch_dec<EPI_PARTIAL, false, 2>(p, nblk, s);
+    if (bn == 64) return g_partial_cfg == 1 ? launch_dec<EPI_PARTIAL, true, 5, 64, 4, 1>(p, nblk, s) : g_partial_cfg == 2 ? launch_dec<EPI_PARTIAL, true, 3, 64, 4, 1>(p, nblk, s)
+                                                                                                  : launch_dec<EPI_PARTIAL, true, 4, 64, 4, 1>(p, nblk, s);
     return (p.w_tiled & 4) ? launch_dec<EPI_PARTIAL, true, 4>(p, nblk, s) : launch_dec<EPI_PARTIAL, true, 2>(p, nblk, s);
 }
 // gate|up of a wide decode step: [M <= 128, K] x tiled W -> SwiGLU -> bf16, one row panel of 128x128 tiles
@@ -400,11 +425,12 @@ static int launch_swiglu_tiled(const GemmArgs& p, hipStream_t s) {
     const int nblk = ((p.M + 127) / 128) * (p.N / 128);
     return (p.w_tiled & 4) ? launch_dec<EPI_SWIGLU, true, 4>(p, nblk, s) : launch_dec<EPI_SWIGLU, true, 2>(p, nblk, s);
 }
-// K-chunks for the partial-row GEMM (sized for one row panel): enough workgroups ((N / 128) x ks) to put at least one on every CU, chunks of whole K-tiles, at least 4
+// K-chunks for the partial-row GEMM (sized for one row panel): enough workgroups ((N / tile width) x ks) to put at least one on every CU, chunks of whole K-tiles, at least 4
 // K-tiles per chunk (a shorter K loop is all prologue).  TRACE_PARTIAL_WGS overrides the workgroup target (tuning runs).
 int gemm_partial_ks(int N, int K) {
-    static const int target = getenv("TRACE_PARTIAL_WGS") ? atoi(getenv("TRACE_PARTIAL_WGS")) : 256;
-    const int tiles = N / 128, nk = K / BK;
+    static const int env_target = getenv("TRACE_PARTIAL_WGS") ? atoi(getenv("TRACE_PARTIAL_WGS")) : 256;
+    const int target = g_partial_wgs > 0 ? g_partial_wgs : env_target;
+    const int tiles = N / partial_bn(), nk = K / BK;
     int ks = 1;
     while (tiles * ks < target && nk % (ks * 2) == 0 && nk / (ks * 2) >= 4) ks *= 2;
     return ks;

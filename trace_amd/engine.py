@@ -76,6 +76,8 @@ class TraceEngine:
         self.time_tower, self.score_tower = TimeTower(), ScoreTower()
         self._B = 0
         self._max_new = 0
+        self._stage_ev = None          # stage_timing(): [(kind, event, event)] while on
+        self._stage_videos = 0
         self._dbg = None               # debugging hook: callable(tag, index, tensor-or-None) called between the stages (tools/pipeline_stress.py)
 
     @property
@@ -338,13 +340,55 @@ class TraceEngine:
         return list(buf)
 
     # ---- one-call convenience: what generate() does for one batch of videos ----------------------
-    def encode_prefill(self, videos: Sequence[torch.Tensor], timestamps: Sequence, input_ids: Sequence[Sequence[int]], slot0: int = 0):
+    # ---- stage timing inside a run (bench.py): HIP-event pairs around the tower / slot-pool / prefill calls of encode_prefill ----
+    def stage_timing(self, on: bool):
+        """on: encode_prefill brackets its tower, encode_features and prefill calls with event pairs on its stream (generate(): every batch;
+        generate_stream(): only the batch that fills the pipeline, while the encode stage has the GPU to itself); read with stage_times()."""
+        self._stage_ev = [] if on else None
+        self._stage_videos = 0
+
+    def stage_times(self) -> dict:
+        """{'videos': n, 'tower_ms': .., 'slotpool_ms': .., 'prefill_ms': ..} summed over the recorded batches (synchronises the device)"""
+        torch.cuda.synchronize(self.device)
+        out = {"videos": getattr(self, "_stage_videos", 0), "tower_ms": 0.0, "slotpool_ms": 0.0, "prefill_ms": 0.0}
+        for kind, e0, e1 in (getattr(self, "_stage_ev", None) or []):
+            out[kind + "_ms"] += e0.elapsed_time(e1)
+        return out
+
+    def _bracket(self, kind: str, fn, record: bool):
+        if not record:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self._stage_ev.append((kind, e0, e1))
+        return r
+
+    def feature_groups(self, videos: Sequence[torch.Tensor]):
+        """(first, last + 1) video ranges whose ViT features (12 GB at most) one vit_forward_many call computes — encode_prefill's grouping"""
+        per_frame = self.cfg.vision_patches * self.cfg.vision_hidden_size * 2
+        groups, g0, B = [], 0, len(videos)
+        while g0 < B:
+            g1, nbytes = g0, 0
+            while g1 < B and (g1 == g0 or nbytes + videos[g1].shape[0] * per_frame <= 12 << 30):
+                nbytes += videos[g1].shape[0] * per_frame
+                g1 += 1
+            groups.append((g0, g1))
+            g0 = g1
+        return groups
+
+    def encode_prefill(self, videos: Sequence[torch.Tensor], timestamps: Sequence, input_ids: Sequence[Sequence[int]], slot0: int = 0,
+                       record_stages: bool = False):
         """Stage 1 of generate() for a batch: CLIP tower (over the batch's frame stream) -> slot pool + time rows -> splice -> prefill
         into KV slots slot0 .. slot0 + B - 1.  Runs on the current stream; touches no decode state, so it may run on another stream
         while an earlier batch (other slots) is being decoded (generate_stream)."""
         B = len(videos)
         if slot0 < 0 or slot0 + B > self.max_batch:
             raise ValueError(f"slots {slot0}..{slot0 + B - 1} exceed the engine's {self.max_batch} KV slots")
+        rec = bool(record_stages) and getattr(self, "_stage_ev", None) is not None
+        if rec:
+            self._stage_videos += B
         # prefill: runs of up to 4 neighbours whose spliced prompts have the same length share one pass (M = 4 L fills the GEMM tile grids in whole
         # rounds of the CUs); the spliced embeddings of a run wait in `held`
         held: List[torch.Tensor] = []                 # spliced embeds of slots held_slot0 .. (equal lengths)
@@ -353,39 +397,30 @@ class TraceEngine:
         def flush():
             nonlocal held
             if len(held) == 1:
-                self.prefill(held_slot0, held[0].shape[0], embeds=held[0])
+                self._bracket("prefill", lambda: self.prefill(held_slot0, held[0].shape[0], embeds=held[0]), rec)
             elif len(held) == 2:
-                self.prefill_pair(held_slot0, held[0], held[1])
+                self._bracket("prefill", lambda: self.prefill_pair(held_slot0, held[0], held[1]), rec)
             elif held:
-                self.prefill_multi(held_slot0, held)
+                self._bracket("prefill", lambda: self.prefill_multi(held_slot0, held), rec)
             held = []
 
         feats = None
         if B > 1 and self.vit_batch_frames > self.max_frames and self.cfg.mm_projector_type != "stc_connector":
-            feats = []                                # the tower runs over groups of videos (whole GEMM rounds); 12 GB of features at a time
-            per_frame = self.cfg.vision_patches * self.cfg.vision_hidden_size * 2
-            g0 = 0
-            while g0 < B:
-                g1, nbytes = g0, 0
-                while g1 < B and (g1 == g0 or nbytes + videos[g1].shape[0] * per_frame <= 12 << 30):
-                    nbytes += videos[g1].shape[0] * per_frame
-                    g1 += 1
-                feats.append((g0, g1))
-                g0 = g1
-            groups, feats = feats, {}
+            groups, feats = self.feature_groups(videos), {}      # the tower runs over groups of videos (whole GEMM rounds); 12 GB of features at a time
         for b in range(B):
             if feats is not None:
                 if b not in feats:
                     g = next(g for g in groups if g[0] <= b < g[1])
-                    feats = dict(zip(range(g[0], g[1]), self.vit_forward_many(videos[g[0]:g[1]])))
+                    feats = dict(zip(range(g[0], g[1]), self._bracket("tower", lambda: self.vit_forward_many(videos[g[0]:g[1]]), rec)))
                 fb = feats.pop(b)
                 if self._dbg is not None:
                     self._dbg("feats", slot0 + b, fb)
-                self.encode_features(fb, timestamps[b])
+                self._bracket("slotpool", lambda: self.encode_features(fb, timestamps[b]), rec)
             else:
-                self.encode_video(videos[b], timestamps[b])
+                self._bracket("tower", lambda: self.encode_video(videos[b], timestamps[b]), rec)      # (tower + slot pool in one call)
             if B == 1:
-                self.prefill(slot0, self.splice(input_ids[b]))
+                L1 = self.splice(input_ids[b])
+                self._bracket("prefill", lambda: self.prefill(slot0, L1), rec)
                 continue
             L, emb = self.splice(input_ids[b], want_output=True)
             if held and (held[0].shape[0] != L or len(held) == self.PREFILL_GROUP):
@@ -419,7 +454,7 @@ class TraceEngine:
         B = len(videos)
         if B > self.decode_batch_max:
             raise ValueError(f"batch {B} exceeds the engine's decode batch {self.decode_batch_max}")
-        self.encode_prefill(videos, timestamps, input_ids, 0)
+        self.encode_prefill(videos, timestamps, input_ids, 0, record_stages=True)
         return self.decode(range(B), heads, max_new_tokens, eos, use_graph, forced)
 
     # ---- two-stage pipeline over a stream of batches ---------------------------------------------------
@@ -480,7 +515,7 @@ class TraceEngine:
                     enc_s.wait_stream(cur)                  # the batch's frames may have been made on the caller's stream (device preprocessing)
                     try:
                         with torch.cuda.stream(enc_s):
-                            self.encode_prefill(videos, timestamps, input_ids, bank * half)
+                            self.encode_prefill(videos, timestamps, input_ids, bank * half, record_stages=pending is None)
                             if self._dbg is not None:
                                 self._dbg("prefilled", bank * half, None)
                             ready = torch.cuda.Event()

@@ -71,6 +71,33 @@ def test_graph_equals_eager_and_lengths(big):
     assert V + 1 <= a[0][0] <= V + cfg.time_vocab_size          # heads=[1]: the first token comes from the time head
 
 
+def test_prefill_last_rows_shortcut_bit_identical_at_full_size(big):
+    """the last decoder layer over the last rows only (round 6) vs over all rows, at the configurations' real prompt lengths and widths: first logits and
+    the next decode steps bit-identical (bf16 path; the fp8 context keeps the full layer)"""
+    from trace_amd.engine import ops
+    cfg, eng, ids, vids, ts, L = big
+    if eng.llm_fp8:
+        pytest.skip("the fp8 weight path runs the full last layer")
+    eng.encode_video(vids[0], ts)
+    _, e0 = eng.splice(ids, want_output=True)
+    e0 = e0.clone()
+    eng.encode_video(vids[1], ts)
+    _, e1 = eng.splice(ids, want_output=True)
+    e1 = e1.clone()
+    res = {}
+    try:
+        for mode in (0, 1):
+            ops.set_gemm_variant(750 + mode)
+            eng.prefill_pair(0, e0, e1)
+            lg = [eng.decode_begin([0, 1], [1, 1], eng.n_new, eos=-1, want_logits=True).clone()]
+            for _ in range(2):
+                lg.append(eng.decode_steps(1, use_graph=False, want_logits=True).clone())
+            res[mode] = torch.stack(lg)
+    finally:
+        ops.set_gemm_variant(751)
+    assert torch.equal(res[0], res[1]), f"max |d| {(res[0] - res[1])[torch.isfinite(res[0])].abs().max().item()}"
+
+
 def test_pair_equals_single(big):
     cfg, eng, ids, vids, ts, L = big
     n = eng.n_new

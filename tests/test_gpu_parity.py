@@ -139,6 +139,41 @@ def test_teacher_forced_logits_and_ids(setup):
     assert e2 < 0.08, f"logits differ from the bf16-emulating oracle by {e2}"
 
 
+def test_prefill_last_layer_rows_shortcut_is_bit_identical(setup):
+    """Round 6: with no hidden rows requested, the last decoder layer computes K / V for every row but q, attention, o-proj and the MLP only for each
+    prompt's last row (engine.hip prefill_impl; the reference runs all L rows, trace_mistral.py:190-200, and keeps logits[:, -1]).  Same kernels, same
+    K order: the first logits AND the decode steps that follow (they read the layer's K / V rows) must be bit-identical to the full layer, for a
+    single prompt, a pair and a run of four."""
+    from trace_amd.engine import ops
+    cfg, eng, ora, E, frames = setup
+    ts = E["timestamps"].tolist()
+    eng.encode_video(frames, ts)
+    L, emb = eng.splice(E["input_ids"].tolist(), want_output=True)
+    embs = [emb.clone(), (emb.float() * 0.5).to(emb.dtype), (emb.float() * -0.25).to(emb.dtype), (emb.float() * 0.75).to(emb.dtype)]
+    res = {}
+    try:
+        for mode in (0, 1):
+            ops.set_gemm_variant(750 + mode)
+            out = []
+            for nb in (1, 2, 4):
+                if nb == 1:
+                    eng.prefill(0, L, embeds=embs[0])
+                elif nb == 2:
+                    eng.prefill_pair(0, embs[0], embs[1])
+                else:
+                    eng.prefill_multi(0, embs)
+                lg = [eng.decode_begin(list(range(nb)), [1] * nb, 8, eos=-1, want_logits=True).clone()]
+                for _ in range(3):
+                    lg.append(eng.decode_steps(1, use_graph=False, want_logits=True).clone())
+                out.append(torch.stack(lg))
+            res[mode] = out
+    finally:
+        ops.set_gemm_variant(751)
+    for a, b in zip(res[0], res[1]):
+        assert torch.isfinite(a[torch.isfinite(b)]).all()
+        assert torch.equal(a, b), f"last-rows prefill differs from the full last layer: max |d| {(a - b)[torch.isfinite(a)].abs().max().item()}"
+
+
 def test_graph_replay_equals_eager(setup):
     cfg, eng, ora, E, frames = setup
     forced = E["forced_ids"].tolist()

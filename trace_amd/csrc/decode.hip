@@ -513,7 +513,11 @@ __global__ __launch_bounds__(1024) void add_rmsnorm_kernel(const float* __restri
 // the splits (placement-independent: no assumption on dispatch order or XCD), then re-zeroes the ticket.
 // Masked positions contribute p = 0 times whatever the cache holds there: the caches are zero-initialised and only
 // ever hold finite values.
-__global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __restrict__ qkv, int ldq, bf16_t* __restrict__ kcache,
+// NW = waves per workgroup (round 6): 4, or 3 when the launch has more workgroups than 3 x #CUs can hold of the 4-wave form — 128 sequences x 8 kv heads =
+// 1024 workgroups against 768 resident slots ran as 1.33 rounds with a tail of one workgroup per CU; as 3-wave workgroups four fit a CU (the same 12
+// waves) and all 1024 are resident from the start.  NT = HBM loads of the cache with the non-temporal hint (A/B).
+template <int NW, bool NT>
+__global__ __launch_bounds__(NW * 64, 3) void attn_decode_kernel(const bf16_t* __restrict__ qkv, int ldq, bf16_t* __restrict__ kcache,
                                                              bf16_t* __restrict__ vtcache, long slot_stride, long kv_head_stride,
                                                              int ctx_stride, const int32_t* __restrict__ slots,
                                                              const int32_t* __restrict__ pos, float* __restrict__ ws,
@@ -522,8 +526,8 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
                                                              const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                              const float* __restrict__ qpart, int qks, int dbg) {
     constexpr int HD = 128, GQ = 4;
-    __shared__ __attribute__((aligned(16))) float s_acc[4][GQ][HD];
-    __shared__ float s_m[4][GQ], s_l[4][GQ];
+    __shared__ __attribute__((aligned(16))) float s_acc[NW][GQ][HD];
+    __shared__ float s_m[NW][GQ], s_l[NW][GQ];
     __shared__ __attribute__((aligned(16))) bf16_t s_new[2 * HD];   // roped k | v of the newest position (owner split)
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -566,6 +570,10 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
     };
     const bool owner = fuse_rope && len > 0 && end == ctx;       // this split holds the newest position
 
+    auto ldc = [](const bf16_t* p) -> u32x4_t {        // one 16-byte piece of the cache
+        if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+        else return *reinterpret_cast<const u32x4_t*>(p);
+    };
     const int prow = (i >> 2) * 8 + (i & 3);          // + 4 t: position (within the block) of A-row i of S tile t
     const u32x4_t zero4 = {0u, 0u, 0u, 0u};
     u32x4_t kr[2][4], vr[8];
@@ -578,16 +586,18 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
             const bf16_t* src = kb + (size_t)p * HD + g * 16;
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
-                kr[t][s4] = ok ? *reinterpret_cast<const u32x4_t*>(src + (s4 >> 1) * 64 + (s4 & 1) * 8) : zero4;
+                kr[t][s4] = ok ? ldc(src + (s4 >> 1) * 64 + (s4 & 1) * 8) : zero4;
         }
     };
     auto load_v = [&](int it) {
         const int P0 = beg + it * 32;
         const bool vok = P0 + g * 8 < end;
-        const bf16_t* vsrc = vb + (size_t)i * ctx_stride + P0 + g * 8;
+        // (dbg == 8, timing only: the same 8 KB read as ONE contiguous block [128 d][32 positions] — what a position-blocked V^T cache would give)
+        const bf16_t* vsrc = dbg == 8 ? vb + ((size_t)(P0 >> 5) * HD + i) * 32 + g * 8 : vb + (size_t)i * ctx_stride + P0 + g * 8;
+        const size_t vstep = dbg == 8 ? 16 * 32 : (size_t)16 * ctx_stride;
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt)
-            vr[dt] = vok ? *reinterpret_cast<const u32x4_t*>(vsrc + (size_t)dt * 16 * ctx_stride) : zero4;
+            vr[dt] = vok ? ldc(vsrc + dt * vstep) : zero4;
     };
     if (wid < nit) { load_k(wid); load_v(wid); }      // cache blocks start streaming before anything else
 
@@ -635,10 +645,11 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
                 *reinterpret_cast<u32x4_t*>(&s_new[d0]) = kn[s4];
             }
         }
-        if (tid >= 128) {
-            const bf16_t x = elem((nq + nkv + kvh) * HD + tid - 128);
-            vb[(size_t)(tid - 128) * ctx_stride + p_new] = x;
-            s_new[HD + tid - 128] = x;
+        if (tid >= NW * 64 - 128) {
+            const int d = tid - (NW * 64 - 128);
+            const bf16_t x = elem((nq + nkv + kvh) * HD + d);
+            vb[(size_t)d * ctx_stride + p_new] = x;
+            s_new[HD + d] = x;
         }
         __syncthreads();                              // workgroup-uniform branch
     }
@@ -650,7 +661,7 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
 
     // single register set, refilled as soon as the MFMAs that read it have issued: the next block's K streams in
     // during this block's softmax + PV, its V^T during the next block's QK (3 waves/SIMD cover the rest)
-    for (int it = wid; it < nit; it += 4) {
+    for (int it = wid; it < nit; it += NW) {
         const int P0 = beg + it * 32;
         if (fuse_rope && p_new >= P0 && p_new < P0 + 32) {          // wave-uniform: splice the newest k / v (parked in LDS)
             const int o = p_new - P0;
@@ -684,7 +695,7 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
                 S[t] = mfma16(__builtin_bit_cast(bf16x8_t, kr[t][s4]),
                                                                __builtin_bit_cast(bf16x8_t, qf[s4]), S[t]);
         }
-        if (it + 4 < nit) load_k(it + 4);
+        if (it + NW < nit) load_k(it + NW);
         // lane (head i, group g): S[t][r] is the score of position P0 + g*8 + t*4 + r
         float sv[8];
         float mx = -1e30f;
@@ -713,7 +724,7 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
             acc[dt] = mfma16(__builtin_bit_cast(bf16x8_t, vr[dt]),
                                                               __builtin_bit_cast(bf16x8_t, pf), acc[dt]);
         }
-        if (it + 4 < nit) load_v(it + 4);
+        if (it + NW < nit) load_v(it + NW);
     }
     // ---- the k-groups of a wave share m; sum their l; then merge the 4 waves through LDS ----
     l += __shfl_xor(l, 16, 64);
@@ -729,12 +740,14 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
     {
         const size_t base = (((size_t)b * nq + kvh * GQ) * nsplit + sp) * (HD + 2);
         // write-through (sc1) stores: visible at agent scope once vmcnt drains, no L2 write-back fence needed
-        for (int x = tid; x < GQ * HD; x += 256) {
+        for (int x = tid; x < GQ * HD; x += NW * 64) {
             const int hq = x >> 7, d = x & 127;
-            const float M = fmaxf(fmaxf(s_m[0][hq], s_m[1][hq]), fmaxf(s_m[2][hq], s_m[3][hq]));
+            float M = s_m[0][hq];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) M = fmaxf(M, s_m[w][hq]);
             float o = 0.f, L = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < NW; ++w) {
                 const float f = __expf(s_m[w][hq] - M);
                 o += f * s_acc[w][hq][d];
                 L += f * s_l[w][hq];
@@ -762,8 +775,7 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(const bf16_t* __res
     }
     __syncthreads();
     if (!s_last || dbg == 3) return;
-    {   // wave w merges q-head w: lane owns d = 2*lane, 2*lane+1; split loads are independent -> issued in batches
-        const int hq = wid;
+    for (int hq = wid; hq < GQ; hq += NW) {   // wave w merges q-head w (w + NW): lane owns d = 2*lane, 2*lane+1; split loads are independent -> issued in batches
         const float* w = ws + (((size_t)b * nq + kvh * GQ + hq) * nsplit) * (HD + 2);
         float M = -1e30f;
         for (int s2 = lane; s2 < nsplit; s2 += 64) M = fmaxf(M, w[s2 * (HD + 2) + HD]);
@@ -1167,14 +1179,22 @@ int launch_qkv_finish(const float* part, int ks, int ldq, bf16_t* qout, bf16_t* 
 }
 
 int g_attn_debug = 0;   // microbenchmark-only phase cut-offs (0 = full kernel)
+int g_attn_decode_w3 = -1;  // decode attention on 3-wave workgroups: -1 = when that makes the launch resident in one round, 0 / 1 = never / always (A/B: trace_op_set_gemm_variant(760 + x), 762 = auto)
+int g_attn_decode_nt = 0;   // non-temporal cache loads in the decode attention (A/B: trace_op_set_gemm_variant(770 + x))
 int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vtcache, long slot_stride, long kv_head_stride,
                        int ctx_stride, const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,
                        int nq, int nkv, int hd, int nsplit, float scale, int fuse_rope, const float* cos_t, const float* sin_t,
                        const float* qpart, int qks, hipStream_t s) {
     if (hd != 128 || nq != 4 * nkv || nsplit < 1 || B < 1 || !tickets || ctx_stride % 32) return TRACE_ERR_ARG;
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv, B), dim3(256), 0, s, qkv, ldq, kcache, vtcache, slot_stride,
-                       kv_head_stride, ctx_stride, slots, pos, ws, tickets, O, ldo, nq, nkv, nsplit, scale, fuse_rope, cos_t, sin_t,
-                       qpart, qks, g_attn_debug);
+    // 3-wave workgroups when the 4-wave form would not be resident in one round (3 x #CUs slots) but the 3-wave form is (4 x #CUs)
+    const long wgs = (long)nsplit * nkv * B;
+    const int ncu = skinny_num_cus();
+    const bool w3 = g_attn_decode_w3 < 0 ? (wgs > 3L * ncu && wgs <= 4L * ncu) : g_attn_decode_w3 != 0;
+#define ATTN_DEC(NW_, NT_) hipLaunchKernelGGL((attn_decode_kernel<NW_, NT_>), dim3(nsplit, nkv, B), dim3(NW_ * 64), 0, s, qkv, ldq, kcache, vtcache, slot_stride, \
+                       kv_head_stride, ctx_stride, slots, pos, ws, tickets, O, ldo, nq, nkv, nsplit, scale, fuse_rope, cos_t, sin_t, qpart, qks, g_attn_debug)
+    if (w3) { if (g_attn_decode_nt) ATTN_DEC(3, true); else ATTN_DEC(3, false); }
+    else { if (g_attn_decode_nt) ATTN_DEC(4, true); else ATTN_DEC(4, false); }
+#undef ATTN_DEC
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }
 

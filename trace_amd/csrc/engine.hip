@@ -908,6 +908,7 @@ extern "C" int trace_preprocess_frames(trace_ctx* c, const void* frames_u8, int 
 // nb equal-length sequences laid end to end in pX (rows [b*L, (b+1)*L)) -> slots slot0 .. slot0+nb-1.  Two 1967-row
 // prompts give the GEMMs M = 3934: 16 row tiles fill the 256x256 tile grid in whole rounds (gate|up 1792 tiles = 7.0
 // rounds instead of 896 = 3.5) and o-proj / down-proj reach the 256^2 kernel.
+int g_prefill_last_rows = 1;   // 0: the last decoder layer of a prefill runs over all rows like the others (A/B and the bit-identity test: trace_op_set_gemm_variant(750 + x))
 static int prefill_impl(trace_ctx* c, int slot0, int nb, int L, void* hidden_out, hipStream_t s) {
     const int H = c->H, I = c->I, HD = c->HD, QKV = c->QKV, M = nb * L;
     AttnArgs a{};
@@ -923,6 +924,34 @@ static int prefill_impl(trace_ctx* c, int slot0, int nb, int L, void* hidden_out
         bf16_t* kc = c->kcache + (size_t)l * c->layer_stride;
         bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
         LCHK(launch_rmsnorm(c->pX, H, c->pH, H, W.rms1, M, H, c->c.rms_eps, s));
+        // Round 6: the LAST decoder layer of a prefill whose caller does not ask for the hidden rows.  What is consumed afterwards is the layer's K / V
+        // rows of every position (the cache) and the final hidden state of each prompt's LAST row only (the reference computes all L rows of
+        // everything, trace_mistral.py:190-200, and then uses logits[:, -1]) — so: the k | v slice of the qkv projection over all M rows, and q,
+        // attention, o-proj and the MLP for the nb last rows, on the same kernels reading / writing those rows in place (row stride L x width).
+        // Same MFMA tile kernels, same K order, same epilogues: bit-identical to the full layer (tests/test_gpu_parity.py), ~3 % of a prefill saved.
+        if (g_prefill_last_rows && l == c->NL - 1 && !hidden_out && !c->fp8 && L > 1) {
+            const int KV = 2 * c->NKV * HD, QW = c->NQ * HD;
+            const size_t last = (size_t)(L - 1);
+            TRY(gemm(c->pH, H, W.wqkv + (size_t)QW * H, H, c->pQKV + QW, QKV, nullptr, nullptr, 0, M, KV, H, EPI_NONE, s));
+            TRY(gemm(c->pH + last * H, L * H, W.wqkv, H, c->pQKV + last * QKV, L * QKV, nullptr, nullptr, 0, nb, QW, H, EPI_NONE, s));
+            LCHK(launch_rope_kv(c->pQKV, QKV, kc, nullptr, (long)c->slot_stride, (long)c->kv_head_stride, nullptr, nullptr, slot0, 0, M,
+                                c->NQ, c->NKV, HD, c->rope_cos, c->rope_sin, L, s));      // (also rotates the stale q of the other rows: 10 us, nobody reads them)
+            LCHK(launch_transpose_v(c->pQKV + (size_t)(c->NQ + c->NKV) * HD, (long)L * QKV, HD, QKV, vc + (size_t)slot0 * c->slot_stride,
+                                    (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, L, HD, c->NKV, nb, s));
+            AttnArgs a1 = a;
+            a1.Q = c->pQKV + last * QKV; a1.O = c->pO + last * H;
+            a1.nq_rows = 1;                                  // one query row per prompt: row L - 1 attends all L keys (causal offset nkv - nq)
+            a1.K = kc + (size_t)slot0 * c->slot_stride;
+            a1.V = vc + (size_t)slot0 * c->slot_stride;
+            LCHK(launch_attn_prefill(a1, s));
+            bf16_t* xl = c->pX + last * H;
+            bf16_t* hl = c->pH + last * H;
+            TRY(gemm(c->pO + last * H, L * H, W.wo, H, xl, L * H, nullptr, xl, L * H, nb, H, H, EPI_RESIDUAL, s));
+            LCHK(launch_rmsnorm(xl, L * H, hl, L * H, W.rms2, nb, H, c->c.rms_eps, s));
+            TRY(gemm(hl, L * H, W.wgu, H, c->pACT + last * I, L * I, nullptr, nullptr, 0, nb, 2 * I, H, EPI_SWIGLU, s));
+            TRY(gemm(c->pACT + last * I, L * I, W.wd, I, xl, L * H, nullptr, xl, L * H, nb, H, I, EPI_RESIDUAL, s));
+            continue;
+        }
         if (c->fp8) { TRY(gemm_fp8(c, c->pH, H, W.wqkv8, W.sqkv, c->pQKV, QKV, nullptr, 0, M, QKV, H, EPI_NONE, s)); }
         else TRY(gemm(c->pH, H, W.wqkv, H, c->pQKV, QKV, nullptr, nullptr, 0, M, QKV, H, EPI_NONE, s));
         LCHK(launch_rope_kv(c->pQKV, QKV, kc, nullptr, (long)c->slot_stride, (long)c->kv_head_stride, nullptr, nullptr, slot0, 0, M,
@@ -1421,13 +1450,18 @@ extern int g_gemm_w4;
 extern int g_gemm_w4_opt;
 extern int g_attn_vit_big;
 extern int g_partial_cfg;
+extern int g_attn_decode_w3;
+extern int g_attn_decode_nt;
 extern int g_partial_wgs;
 extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 1000 && variant <= 1000 + 1024) { g_gemm_pers_grid_cap = variant - 1000; return TRACE_OK; }   // persistent GEMM: at most n workgroups (0 = #CUs)
-    if (variant >= 100 && variant < 104) { g_attn_debug = variant - 100; return TRACE_OK; }
+    if (variant >= 100 && variant < 110) { g_attn_debug = variant - 100; return TRACE_OK; }      // decode attention knock-outs (108: V^T read as contiguous blocks, timing only)
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
+    if (variant >= 760 && variant <= 762) { g_attn_decode_w3 = variant == 762 ? -1 : variant - 760; return TRACE_OK; }
+    if (variant >= 770 && variant <= 771) { g_attn_decode_nt = variant - 770; return TRACE_OK; }
+    if (variant >= 750 && variant <= 751) { g_prefill_last_rows = variant - 750; return TRACE_OK; }
     if (variant >= 740 && variant <= 743) { g_partial_cfg = variant - 740; return TRACE_OK; }        // tile shape of the decode partial-row GEMM (gemm.hip)
     if (variant >= 800 && variant <= 832) { g_partial_wgs = (variant - 800) * 32; return TRACE_OK; }   // its workgroup target (0 = default 256)
     if (variant >= 700 && variant < 732) { g_decode_gemm_tiled = variant - 700; return TRACE_OK; }   // the same word with its round-6 bits: 2 = nt weight DMA, 8 / 16 = nt / write-through partial-row stores

@@ -8,9 +8,10 @@ namespace {
 constexpr int MAXCH = 8;   // 8 chunks x 64 lanes x 8 elements = 4096
 
 template <bool RMS>
-__global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
+// (y and res carry no __restrict__: the STC block tail calls this with y == res — each lane loads its res chunk before it stores the same y chunk)
+__global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* y, int ldy,
                                                    const bf16_t* __restrict__ w, const bf16_t* __restrict__ b, int rows,
-                                                   int D, float eps, int silu, const bf16_t* __restrict__ res = nullptr, int ldres = 0) {
+                                                   int D, float eps, int silu, const bf16_t* res = nullptr, int ldres = 0) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;

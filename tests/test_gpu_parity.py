@@ -145,7 +145,9 @@ def test_prefill_last_layer_rows_shortcut_is_bit_identical(setup):
     K order: the first logits AND the decode steps that follow (they read the layer's K / V rows) must be bit-identical to the full layer, for a
     single prompt, a pair and a run of four."""
     from trace_amd.engine import ops
-    cfg, eng, ora, E, frames = setup
+    cfg, _, ora, E, frames = setup
+    eng = TraceEngine(cfg, max_batch=4, max_ctx=256, max_frames=4, max_new_tokens=16)       # (its own engine: it prefills all four KV slots)
+    eng.load_weights(synth.state_dict(cfg).items())
     ts = E["timestamps"].tolist()
     eng.encode_video(frames, ts)
     L, emb = eng.splice(E["input_ids"].tolist(), want_output=True)
@@ -169,6 +171,7 @@ def test_prefill_last_layer_rows_shortcut_is_bit_identical(setup):
             res[mode] = out
     finally:
         ops.set_gemm_variant(751)
+    eng.close()
     for a, b in zip(res[0], res[1]):
         assert torch.isfinite(a[torch.isfinite(b)]).all()
         assert torch.equal(a, b), f"last-rows prefill differs from the full last layer: max |d| {(a - b)[torch.isfinite(a)].abs().max().item()}"
@@ -535,6 +538,42 @@ def test_batch1_swiglu_fold_is_bit_identical(golden_dir):
         assert torch.equal(runs[1][0], runs[0][0]), (runs[1][0] - runs[0][0]).abs().max()
         assert runs[1][1] == runs[0][1]
         eng.close()
+
+
+def test_batch1_persistent_step_is_bit_identical(golden_dir):
+    """Round 6: the batch-1 decode step as ONE persistent launch (decode_b1.hip: the 32 x 5 phases of the launch-per-kernel step behind grid barriers,
+    the next phase's weights requested in front of each barrier).  Same partitions, same arithmetic: the logits of every teacher-forced step and the ids
+    must equal the launch-per-kernel path's bit for bit — at the real MLP width (two layers) and at the tiny geometry, with and without the weight
+    requests in front of the barriers, eager and as a replayed hipGraph; a long free run must not trip the barrier's timeout word."""
+    import dataclasses
+    from trace_amd.engine import ops
+    for cfg in (dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336, num_hidden_layers=2), tcfg.tiny(num_frames=4)):
+        M = np.load(os.path.join(golden_dir, "medium_llm.npz"))
+        frames = synth.synth_frames(cfg, 0).to(torch.bfloat16)
+        forced = M["forced_ids"].tolist()[:20]
+        n = len(forced) + 1
+        runs = {}
+        try:
+            for mode in (0, 3, 1):
+                ops.set_gemm_variant(900 + mode)
+                eng = TraceEngine(cfg, max_batch=1, max_ctx=192, max_frames=4, max_new_tokens=64)      # (a fresh engine per mode: graphs are cached per batch size)
+                eng.load_weights(synth.iter_weights(cfg))
+                eng.encode_video(frames, M["timestamps"].tolist())
+                eng.prefill(0, eng.splice(M["input_ids"].tolist()))
+                lgs = [eng.decode_begin([0], [1], n, eos=-1, forced=[forced], want_logits=True).float().cpu()]
+                for _ in range(n - 1):
+                    lgs.append(eng.decode_steps(1, use_graph=False, want_logits=True).float().cpu())
+                ids_e = eng.decode_read()[0]
+                eng.decode_begin([0], [1], n, eos=-1, forced=[forced])
+                eng.decode_steps(n - 1, use_graph=True)
+                ids_g = eng.decode_read()[0]
+                runs[mode] = (torch.stack(lgs), ids_e, ids_g)
+                eng.close()
+        finally:
+            ops.set_gemm_variant(900)
+        for mode in (3, 1):
+            assert torch.equal(runs[mode][0], runs[0][0]), (mode, (runs[mode][0] - runs[0][0])[torch.isfinite(runs[0][0])].abs().max())
+            assert runs[mode][1] == runs[0][1] and runs[mode][2] == runs[0][2] == runs[0][1]
 
 
 @pytest.mark.parametrize("geometry", ["vit_l_14_336", "tiny"])

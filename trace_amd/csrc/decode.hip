@@ -1027,6 +1027,10 @@ size_t skinny_ws_floats(int N, int K, int epi) {
     return f;
 }
 int skinny_ks(int N, int K, int epi, int B) { return skinny_plan(N, K, epi, B).KS; }
+void skinny_plan_get(int N, int K, int epi, int B, DecodeB1Plan* out) {
+    const SkinnyPlan p = skinny_plan(N, K, epi, B);
+    *out = DecodeB1Plan{p.KS, p.chunk_units, p.T, p.WPT, p.ntiles, p.grid, p.threads};
+}
 
 template <int EPI, int NB, int NT, int PRO = 0>
 static int skinny_lds_launch(const SkinnyPlan& p, const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo,
@@ -1179,7 +1183,8 @@ int launch_qkv_finish(const float* part, int ks, int ldq, bf16_t* qout, bf16_t* 
 }
 
 int g_attn_debug = 0;   // microbenchmark-only phase cut-offs (0 = full kernel)
-int g_attn_decode_w3 = -1;  // decode attention on 3-wave workgroups: -1 = when that makes the launch resident in one round, 0 / 1 = never / always (A/B: trace_op_set_gemm_variant(760 + x), 762 = auto)
+int g_attn_decode_w3 = -1;  // waves per decode-attention workgroup (A/B: trace_op_set_gemm_variant(760 + x)): 0 / 2 (-1) = 4 (ships), 1 = 3, 3 = 6, 4 = 8
+int g_attn_decode_lds_pad = 0;   // KB of unused dynamic LDS per decode-attention workgroup (A/B: trace_op_set_gemm_variant(780 + KB / 8))
 int g_attn_decode_nt = 0;   // non-temporal cache loads in the decode attention (A/B: trace_op_set_gemm_variant(770 + x))
 int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vtcache, long slot_stride, long kv_head_stride,
                        int ctx_stride, const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,
@@ -1189,10 +1194,15 @@ int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vtcac
     // 3-wave workgroups when the 4-wave form would not be resident in one round (3 x #CUs slots) but the 3-wave form is (4 x #CUs)
     const long wgs = (long)nsplit * nkv * B;
     const int ncu = skinny_num_cus();
-    const bool w3 = g_attn_decode_w3 < 0 ? (wgs > 3L * ncu && wgs <= 4L * ncu) : g_attn_decode_w3 != 0;
-#define ATTN_DEC(NW_, NT_) hipLaunchKernelGGL((attn_decode_kernel<NW_, NT_>), dim3(nsplit, nkv, B), dim3(NW_ * 64), 0, s, qkv, ldq, kcache, vtcache, slot_stride, \
-                       kv_head_stride, ctx_stride, slots, pos, ws, tickets, O, ldo, nq, nkv, nsplit, scale, fuse_rope, cos_t, sin_t, qpart, qks, g_attn_debug)
-    if (w3) { if (g_attn_decode_nt) ATTN_DEC(3, true); else ATTN_DEC(3, false); }
+    const int nw = g_attn_decode_w3 < 0 ? 4 : g_attn_decode_w3 == 1 ? 3 : g_attn_decode_w3 == 3 ? 6 : g_attn_decode_w3 == 4 ? 8 : 4;
+    (void)wgs; (void)ncu;
+    const size_t pad = (size_t)g_attn_decode_lds_pad * 1024;       // A/B: dynamic LDS nobody uses, caps the workgroups per CU
+#define ATTN_DEC(NW_, NT_) do { static LdsGrantSized grant_; if (pad && !grant_dynamic_lds(grant_, reinterpret_cast<const void*>(attn_decode_kernel<NW_, NT_>), pad)) return TRACE_ERR_HIP; \
+    hipLaunchKernelGGL((attn_decode_kernel<NW_, NT_>), dim3(nsplit, nkv, B), dim3(NW_ * 64), pad, s, qkv, ldq, kcache, vtcache, slot_stride, \
+                       kv_head_stride, ctx_stride, slots, pos, ws, tickets, O, ldo, nq, nkv, nsplit, scale, fuse_rope, cos_t, sin_t, qpart, qks, g_attn_debug); } while (0)
+    if (nw == 3) { if (g_attn_decode_nt) ATTN_DEC(3, true); else ATTN_DEC(3, false); }
+    else if (nw == 6) ATTN_DEC(6, false);
+    else if (nw == 8) ATTN_DEC(8, false);
     else { if (g_attn_decode_nt) ATTN_DEC(4, true); else ATTN_DEC(4, false); }
 #undef ATTN_DEC
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;

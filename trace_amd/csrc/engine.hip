@@ -87,6 +87,9 @@ struct trace_ctx {
     float* sk_ws = nullptr; unsigned int* sk_tickets = nullptr; size_t sk_ws_floats = 0; int sk_ntickets = 0;   // decode GEMV K-chunk partials
     float* sk_ws2 = nullptr;           // second partial-row buffer and residual rows: the fused-norm GEMVs of small batches read one and write the other
     bf16_t* dX2 = nullptr;
+    DecodeB1Layer* b1_layers = nullptr;  // device table of the persistent batch-1 step (decode_b1.hip), built on first use
+    unsigned int* b1_bar = nullptr;      // its barrier words + one sticky error word behind them
+    int b1_used = 0;                     // the persistent step ran since trace_decode_begin: trace_decode_read checks the error word
     float* part_val; int32_t* part_idx;
     float* hl_val; int32_t* hl_idx;        // trace_llm_head_logits' own partial buffers
     int32_t *d_slots, *d_pos, *d_heads, *d_done, *d_out_ids, *d_out_len, *d_step, *d_forced, *d_params;
@@ -1162,6 +1165,52 @@ static int decode_step_fused(trace_ctx* c, float* logits_out, hipStream_t s) {
     return head_and_select(c, c->dH, 1, logits_out, s);
 }
 
+int g_decode_b1_persistent = 0;   // batch-1 step as ONE persistent launch (decode_b1.hip): 0 = off, 1 / 2 / 3 = on with no / one / two weight batches requested in front of
+                                   // each grid barrier (trace_op_set_gemm_variant(900 + x))
+// One decode step for ONE sequence as a single persistent launch of the 32 x 5 phases of decode_step_fused (same arithmetic, same partitions: bit-identical
+// ids and logits), followed by the final norm and the heads as before.
+// the persistent step's device-side layer table and barrier words (made outside any stream capture: trace_decode_begin)
+static int b1_prepare(trace_ctx* c) {
+    if (!c->b1_layers) {
+        std::vector<DecodeB1Layer> h((size_t)c->NL);
+        for (int l = 0; l < c->NL; ++l) {
+            const LlmLayer& W = c->llm[l];
+            h[l] = DecodeB1Layer{W.wqkv_d, W.wo_d, W.wgu_d, W.wd_d, W.rms1, W.rms2, c->kcache + (size_t)l * c->layer_stride, c->vcache + (size_t)l * c->layer_stride};
+        }
+        void* p = nullptr;
+        HIPCHK(hipMalloc(&p, h.size() * sizeof(DecodeB1Layer)));
+        c->allocs.push_back(p);
+        HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(DecodeB1Layer), hipMemcpyHostToDevice));
+        c->b1_layers = (DecodeB1Layer*)p;
+        HIPCHK(hipMalloc(&p, decode_b1_bar_bytes() + 256));
+        c->allocs.push_back(p);
+        HIPCHK(hipMemset(p, 0, decode_b1_bar_bytes() + 256));
+        c->b1_bar = (unsigned int*)p;
+    }
+    return TRACE_OK;
+}
+static int decode_step_b1_persistent(trace_ctx* c, float* logits_out, hipStream_t s) {
+    const int H = c->H, I = c->I, QKV = c->QKV;
+    if (!c->b1_layers) return fail(TRACE_ERR_STATE, "persistent batch-1 step: tables not prepared (trace_decode_begin)");
+    DecodeB1Args a{};
+    a.layers = c->b1_layers; a.NL = c->NL;
+    skinny_plan_get(QKV, H, EPI_PARTIAL, 1, &a.pq); skinny_plan_get(H, H, EPI_PARTIAL, 1, &a.po);
+    skinny_plan_get(2 * I, H, EPI_PARTIAL, 1, &a.pg); skinny_plan_get(H, I, EPI_PARTIAL, 1, &a.pd);
+    a.H = H; a.I = I; a.QKV = QKV; a.NQ = c->NQ; a.NKV = c->NKV;
+    a.xa = c->dX; a.xb = c->dX2; a.ws = c->sk_ws; a.ws2 = c->sk_ws2; a.dO = c->dO; a.attn_ws = c->attn_ws; a.tickets = c->tickets;
+    a.cos_t = c->rope_cos; a.sin_t = c->rope_sin; a.slots = c->d_slots; a.pos = c->d_pos;
+    a.slot_stride = (long)c->slot_stride; a.kv_head_stride = (long)c->kv_head_stride; a.ctx_stride = c->ctx_pad;
+    a.nsplit = decode_nsplit(1); a.scale = 1.0f / sqrtf((float)c->HD); a.eps = c->c.rms_eps;
+    a.bar = c->b1_bar; a.err = c->b1_bar + decode_b1_bar_bytes() / 4;
+    a.prefetch = g_decode_b1_persistent - 1;
+    const int rc = launch_decode_b1_persistent(a, s);
+    if (rc != TRACE_OK) return fail(rc, "persistent batch-1 decode launch failed");
+    c->b1_used = 1;
+    // an even number of fused GEMVs per layer: the residual row is back in dX; the last layer's down partials + residual -> final norm -> heads
+    LCHK(launch_add_rmsnorm(c->sk_ws, a.pd.KS, c->dX, H, c->dX, H, c->final_norm, c->dH, H, 1, H, c->c.rms_eps, s));
+    return head_and_select(c, c->dH, 1, logits_out, s);
+}
+
 int g_decode_unfused = 0;   // RoPE + cache append as a kernel of its own before the decode attention: 0 = from batch 32 up (bit-identical to the fused
                             // prologue, 1 % faster per 64-sequence step, one launch more — which batch 1 would feel), 1 = always, 2 = never
                             // (trace_op_set_gemm_variant(120 + x), tools/decode_ab.py)
@@ -1172,6 +1221,8 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
     // 5-8 us of dependent round trips per GEMV): qkv -> attention (RoPE + cache append + attention) -> o -> [sum + residual
     // -> new residual, RMSNorm] -> gate|up -> [sum, SwiGLU] -> down -> [sum + residual, next layer's / the final RMSNorm].
     if (B > SKINNY_ROWS || (B >= g_decode_wide_min && !c->fp8)) return decode_step_wide(c, logits_out, s);      // (fp8 contexts: at most 64 rows, checked at begin)
+    if (B == 1 && g_decode_b1_persistent && g_decode_fuse_norm_rows >= 1 && g_decode_fuse_swiglu && !c->fp8 && c->HD == 128 && skinny_fused_norm_ok(QKV, H, B) &&
+        skinny_fused_norm_ok(2 * I, H, B)) return decode_step_b1_persistent(c, logits_out, s);
     if (B <= g_decode_fuse_norm_rows && !c->fp8 && skinny_fused_norm_ok(QKV, H, B) && skinny_fused_norm_ok(2 * I, H, B)) return decode_step_fused(c, logits_out, s);
     const bool wo = c->fp8 && c->fp8_wonly;          // weight-only decode GEMVs: bf16 activations straight from dH / dO / dACT, no quantiser launches
     const bool f8 = c->fp8 && !wo;
@@ -1262,7 +1313,9 @@ extern "C" int trace_decode_begin(trace_ctx* c, const int32_t* slots, int B, con
     HIPCHK(hipMemsetAsync(c->d_out_ids, 0, (size_t)B * max_new * 4, s));
     const int32_t prm[3] = {max_new, eos, c->host_mode};
     HIPCHK(hipMemcpyAsync(c->d_params, prm, 12, hipMemcpyHostToDevice, s));
-    c->fed = 0; c->steps_done = 0;
+    c->fed = 0; c->steps_done = 0; c->b1_used = 0;
+    if (B == 1 && g_decode_b1_persistent && !c->fp8) TRY(b1_prepare(c));
+    if (c->b1_bar) HIPCHK(hipMemsetAsync(c->b1_bar + decode_b1_bar_bytes() / 4, 0, 4, s));
     if (forced) HIPCHK(hipMemcpyAsync(c->d_forced, forced, (size_t)B * max_new * 4, hipMemcpyHostToDevice, s));
     else HIPCHK(hipMemsetAsync(c->d_forced, 0xff, (size_t)B * max_new * 4, s));      // -1 = not forced
     // gather the prefill hidden rows of the chosen slots into dH, then head + select (no position advance)
@@ -1288,7 +1341,7 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
     if (!use_graph) {
         for (int i = 0; i < n; ++i) { c->step_in_call = steps_before + i; TRY(decode_step(c, logits_out, s)); }
     } else {
-        const int key = c->B;
+        const int key = c->B;      // (A/B switches that change the step's launches must not be flipped between replays of one context: tests use eager launches or fresh engines)
         hipGraphExec_t* slot_g = &c->graphs[key];
         if (!*slot_g) {
             hipGraph_t g = nullptr;
@@ -1337,7 +1390,10 @@ extern "C" int trace_decode_read(trace_ctx* c, int32_t* out_ids, int32_t* out_le
     if (out_ids) HIPCHK(hipMemcpyAsync(out_ids, c->d_out_ids, (size_t)c->B * c->max_new * 4, hipMemcpyDeviceToHost, s));
     if (out_len) HIPCHK(hipMemcpyAsync(out_len, c->d_out_len, c->B * 4, hipMemcpyDeviceToHost, s));
     if (heads) HIPCHK(hipMemcpyAsync(heads, c->d_heads, c->B * 4, hipMemcpyDeviceToHost, s));
+    unsigned int b1_err = 0;
+    if (c->b1_used && c->b1_bar) HIPCHK(hipMemcpyAsync(&b1_err, c->b1_bar + decode_b1_bar_bytes() / 4, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (b1_err) return fail(TRACE_ERR_STATE, "the persistent batch-1 decode step gave up at a grid barrier (not all of its workgroups were resident): ids are invalid");
     return TRACE_OK;
 }
 
@@ -1452,6 +1508,7 @@ extern int g_attn_vit_big;
 extern int g_partial_cfg;
 extern int g_attn_decode_w3;
 extern int g_attn_decode_nt;
+extern int g_attn_decode_lds_pad;
 extern int g_partial_wgs;
 extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 1000 && variant <= 1000 + 1024) { g_gemm_pers_grid_cap = variant - 1000; return TRACE_OK; }   // persistent GEMM: at most n workgroups (0 = #CUs)
@@ -1459,7 +1516,9 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
-    if (variant >= 760 && variant <= 762) { g_attn_decode_w3 = variant == 762 ? -1 : variant - 760; return TRACE_OK; }
+    if (variant >= 900 && variant <= 903) { g_decode_b1_persistent = variant - 900; return TRACE_OK; }
+    if (variant >= 760 && variant <= 764) { g_attn_decode_w3 = variant == 762 ? -1 : variant - 760; return TRACE_OK; }
+    if (variant >= 780 && variant <= 799) { g_attn_decode_lds_pad = (variant - 780) * 8; return TRACE_OK; }
     if (variant >= 770 && variant <= 771) { g_attn_decode_nt = variant - 770; return TRACE_OK; }
     if (variant >= 750 && variant <= 751) { g_prefill_last_rows = variant - 750; return TRACE_OK; }
     if (variant >= 740 && variant <= 743) { g_partial_cfg = variant - 740; return TRACE_OK; }        // tile shape of the decode partial-row GEMM (gemm.hip)

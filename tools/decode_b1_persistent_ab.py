@@ -18,7 +18,9 @@ import dataclasses
 cfg = tcfg.trace_7b()
 if a.layers:
     cfg = dataclasses.replace(cfg, num_hidden_layers=a.layers)
-names = {900: "launch per kernel (ships)", 901: "persistent, no loads before barriers", 902: "persistent, one load batch ahead", 903: "persistent, two load batches ahead"}
+names = {900: "launch per kernel", 901: "persistent, no loads before barriers", 902: "persistent, one load batch ahead", 903: "persistent, two load batches ahead",
+         906: "persistent, one batch ahead, wave 0 polls first", 907: "persistent, two batches ahead, wave 0 polls first",
+         917: "TIMING ONLY: 901 without acquire fences", 923: "TIMING ONLY: 907 without acquire fences"}
 arms = [int(x) for x in a.arms.split(",")]
 engs, lg = {}, {}
 torch.manual_seed(0)
@@ -50,7 +52,7 @@ for rnd in range(7):
         torch.cuda.synchronize()
         ts[v].append((time.perf_counter() - t0) / a.steps * 1e3)
         e.decode_read()
-ops.set_gemm_variant(900)
+ops.set_gemm_variant(907)
 for v in arms:
     m = statistics.median(ts[v][1:])
-    print(f"batch 1 ctx {a.ctx}: {names[v]:40s} {m:.3f} ms/step = {1e3 / m:.0f} tok/s  (rounds: {' '.join('%.3f' % t for t in ts[v])})")
+    print(f"batch 1 ctx {a.ctx}: {names.get(v, str(v)):48s} {m:.3f} ms/step = {1e3 / m:.0f} tok/s  (rounds: {' '.join('%.3f' % t for t in ts[v])})")

@@ -28,6 +28,12 @@ __device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 union Frag { uint4 u; bf16x8_t v; };
+// What one workgroup hands to another inside the launch leaves as WRITE-THROUGH (sc1) stores: visible to the other XCDs once the storing wave's vmcnt
+// has drained, without the L2 write-back of a release fence (buffer_wbl2: measured 1 us per barrier, 0.16 ms of a 3.1 ms step).  base is wave-uniform.
+__device__ __forceinline__ void st_wt16(void* base, size_t byte_off, u32x4_t v) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7ffffff0, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 16);                  // aux 16 = sc1
+}
 
 constexpr int BAR_STRIDE = 32;                 // words between two barrier counters (128 bytes: one L2 line each)
 constexpr int BAR_CNT = 0, BAR_TOP = 8, BAR_GEN = 9, BAR_ERR = 17, BAR_WORDS = 18 * BAR_STRIDE;
@@ -39,6 +45,7 @@ struct GridBar {
     unsigned epoch;        // barriers passed so far (same in every workgroup)
     int nwg;
     bool dead;             // a spin timed out somewhere: skip all further work
+    int opt;               // A/B bits (DecodeB1Args::prefetch >> 2): 1 = wave 0 polls before it requests its own weights, 4 = no acquire fence (TIMING ONLY)
 };
 
 __device__ __forceinline__ unsigned bar_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -48,8 +55,7 @@ __device__ __forceinline__ void bar_arrive(GridBar& gb) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (every cross-workgroup payload store of this file is write-through and has drained: no release fence)
         __hip_atomic_fetch_add(gb.w + (BAR_CNT + (blockIdx.x & 7)) * BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     gb.epoch += 1;
@@ -84,7 +90,7 @@ __device__ __forceinline__ void bar_wait(GridBar& gb, int* s_flag) {
             __hip_atomic_store(gb.w + BAR_ERR * BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(gb.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // sticky: the host reads it in trace_decode_read
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!(gb.opt & 4)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         *s_flag = ok ? 0 : 1;
     }
     __syncthreads();
@@ -105,7 +111,7 @@ struct Pro {                                   // skinny_lds_kernel's SkinnyPro
 // One GEMV phase for ONE activation row: skinny_lds_kernel<EPI_PARTIAL, NB = 1, NT, PRO> with tiled weights, B = 1.  Waves beyond the plan's thread count
 // and workgroups beyond its grid only keep the barriers company.
 template <int NT, int PRO>
-__device__ __attribute__((noinline)) void gemv_phase(unsigned char* smem, const B1Plan& P, const bf16_t* X, const bf16_t* W, int N, int K, float* ws, const Pro& pro,
+__device__ __forceinline__ void gemv_phase(unsigned char* smem, const B1Plan& P, const bf16_t* X, const bf16_t* W, int N, int K, float* ws, const Pro& pro,
                                            GridBar& gb, bool wait_first, int prefetch, int* s_flag, float* s_ss) {
     constexpr int UN = (NT == 2) ? 2 : 4;
     u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem);                                          // [unit][half][lane]
@@ -141,13 +147,16 @@ __device__ __attribute__((noinline)) void gemv_phase(unsigned char* smem, const 
     bool work = active && ua < ub;
     bool wb_ready = false;
     // the weight stream starts before the barrier that releases this phase's activations (weights depend on nothing)
-    if (work && (prefetch || !wait_first)) {
+    const int depth = prefetch & 3;
+    // (opt bit 1: the polling wave keeps its vector-memory queue empty — a poll's reply returns behind every load the wave issued before it)
+    const bool early = !wait_first || (depth > 0 && !((gb.opt & 1) && wid == 0));
+    if (work && early) {
         loadw(wa, ua);
-        if (prefetch > 1 && ua + UN < ub) { loadw(wb, ua + UN); wb_ready = true; }
+        if (depth > 1 && ua + UN < ub) { loadw(wb, ua + UN); wb_ready = true; }
     }
     if (wait_first) bar_wait(gb, s_flag);
     if (gb.dead) return;
-    if (work && !(prefetch || !wait_first)) loadw(wa, ua);
+    if (work && !early) loadw(wa, ua);
 
     // ---- park the activation row's K-chunk in LDS in fragment order: combo c = unit*2 + half, lane (r, g) holds X[(u_beg + unit)*64 + g*16 + half*8 .. +8] ----
     if constexpr (PRO == 1) {
@@ -181,7 +190,7 @@ __device__ __attribute__((noinline)) void gemv_phase(unsigned char* smem, const 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ss = fmaf(bflo(u[e]), bflo(u[e]), fmaf(bfhi(u[e]), bfhi(u[e]), ss));
                     const int unit = e8 >> 3;
-                    if (rg == 0 && unit >= u_beg && unit < u_beg + nu) *reinterpret_cast<uint4*>(pro.xout + e8 * 8) = xo;
+                    if (rg == 0 && unit >= u_beg && unit < u_beg + nu) st_wt16(pro.xout, (size_t)e8 * 16, u32x4_t{xo.x, xo.y, xo.z, xo.w});
                 }
             }
             ss = wave_sum(ss);
@@ -293,9 +302,9 @@ __device__ __attribute__((noinline)) void gemv_phase(unsigned char* smem, const 
             }
         }
         if (active && wsub == 0 && r == 0) {          // row m = r = 0 of the fragment: out[n0 + t*16 + g*4 .. +4]
-            float* pr = ws + (size_t)ks * SK_ROWS * N + tile * 16 * NT;
+            const size_t po = ((size_t)ks * SK_ROWS * N + tile * 16 * NT) * 4;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4_t*>(pr + t * 16 + g * 4) = acc[t];
+            for (int t = 0; t < NT; ++t) st_wt16(ws, po + (size_t)(t * 16 + g * 4) * 4, __builtin_bit_cast(u32x4_t, acc[t]));
         }
         first = false;
         task += nteams;
@@ -380,10 +389,11 @@ __device__ __attribute__((noinline)) void attn_phase(unsigned char* smem, const 
             vr[dt] = vok ? *reinterpret_cast<const u32x4_t*>(vsrc + (size_t)dt * 16 * ctx_stride) : zero4;
     };
     // the cache rows of earlier tokens depend on nothing this step produced: they stream while the barrier in front of this phase is counted
-    if (real && wid < nit && A.prefetch) { load_k(wid); load_v(wid); }
+    const bool early = (A.prefetch & 3) && !((gb.opt & 1) && wid == 0);
+    if (real && wid < nit && early) { load_k(wid); load_v(wid); }
     bar_wait(gb, s_flag);
     if (gb.dead || !mine) return;
-    if (real && wid < nit && !A.prefetch) { load_k(wid); load_v(wid); }
+    if (real && wid < nit && !early) { load_k(wid); load_v(wid); }
 
     auto rope_head = [&](int col, u32x4_t (&out)[4]) {
         u32x4_t x[4];
@@ -520,7 +530,7 @@ __device__ __attribute__((noinline)) void attn_phase(unsigned char* smem, const 
                 o += f * s_acc[w][hq][d];
                 L += f * s_l[w][hq];
             }
-            if (nsplit == 1) { A.dO[(size_t)(kvh * GQ + hq) * HD + d] = f2bf(o / L); continue; }
+            if (nsplit == 1) { __hip_atomic_store(&A.dO[(size_t)(kvh * GQ + hq) * HD + d], f2bf(o / L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
             __hip_atomic_store(&A.attn_ws[base + (size_t)hq * nsplit * (HD + 2) + d], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (d == 0) {
                 __hip_atomic_store(&A.attn_ws[base + (size_t)hq * nsplit * (HD + 2) + HD], M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -566,7 +576,8 @@ __device__ __attribute__((noinline)) void attn_phase(unsigned char* smem, const 
                 }
             }
             const float inv = 1.f / den;
-            *reinterpret_cast<uint32_t*>(A.dO + (size_t)(kvh * GQ + hq) * HD + 2 * lane) = pack2bf(num0 * inv, num1 * inv);
+            __hip_atomic_store(reinterpret_cast<uint32_t*>(A.dO + (size_t)(kvh * GQ + hq) * HD + 2 * lane), pack2bf(num0 * inv, num1 * inv), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (tid == 0) __hip_atomic_store(&A.tickets[b * nkv + kvh], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -576,7 +587,7 @@ __global__ __launch_bounds__(512) void decode_b1_persistent_kernel(B1Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_flag;
     __shared__ float s_ss[8];
-    GridBar gb{A.bar, A.err, 0u, (int)gridDim.x, false};
+    GridBar gb{A.bar, A.err, 0u, (int)gridDim.x, false, A.prefetch >> 2};
     bf16_t *xa = A.xa, *xb = A.xb;
     for (int l = 0; l < A.NL; ++l) {
         const B1Layer Lw = A.layers[l];
@@ -596,7 +607,8 @@ __global__ __launch_bounds__(512) void decode_b1_persistent_kernel(B1Args A) {
         }
         {
             const Pro pro{A.ws, A.po.KS, xa, xb, Lw.rms2, A.eps};
-            gemv_phase<2, 1>(smem, A.pg, nullptr, Lw.wgu, 2 * A.I, A.H, A.ws2, pro, gb, true, A.prefetch, &s_flag, s_ss);
+            if (A.pg.NT == 2) gemv_phase<2, 1>(smem, A.pg, nullptr, Lw.wgu, 2 * A.I, A.H, A.ws2, pro, gb, true, A.prefetch, &s_flag, s_ss);
+            else gemv_phase<1, 1>(smem, A.pg, nullptr, Lw.wgu, 2 * A.I, A.H, A.ws2, pro, gb, true, A.prefetch, &s_flag, s_ss);
             bf16_t* t = xa; xa = xb; xb = t;
             bar_arrive(gb);
         }
@@ -612,17 +624,27 @@ __global__ __launch_bounds__(512) void decode_b1_persistent_kernel(B1Args A) {
 }  // namespace
 
 size_t decode_b1_bar_bytes() { return (size_t)BAR_WORDS * 4; }
+int decode_b1_num_cus() {          // CUs of the current device (cached per device id)
+    static std::atomic<int> cache[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return -1;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    cache[dev].store(prop.multiProcessorCount, std::memory_order_relaxed);
+    return prop.multiProcessorCount;
+}
 
 int launch_decode_b1_persistent(const DecodeB1Args& a, hipStream_t s) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return TRACE_ERR_HIP;
-    const int ncu = prop.multiProcessorCount;
+    const int ncu = decode_b1_num_cus();
+    if (ncu <= 0) return TRACE_ERR_HIP;
     const DecodeB1Plan* pl[4] = {&a.pq, &a.po, &a.pg, &a.pd};
     size_t lds = 0;
     int maxgrid = a.nsplit * a.NKV;
     for (int i = 0; i < 4; ++i) {
-        const int NT = i == 2 ? 2 : 1;
+        const int NT = pl[i]->NT;
+        if (NT != 1 && !(i == 2 && NT == 2)) return TRACE_ERR_STATE;      // two tiles per task: the gate|up product only
         const size_t need = (size_t)pl[i]->chunk_units * 2 * 1024 + (pl[i]->WPT > 1 ? (size_t)pl[i]->T * pl[i]->WPT * NT * 1024 : 0);
         lds = need > lds ? need : lds;
         if (pl[i]->threads > 512) return TRACE_ERR_STATE;

@@ -1165,8 +1165,11 @@ static int decode_step_fused(trace_ctx* c, float* logits_out, hipStream_t s) {
     return head_and_select(c, c->dH, 1, logits_out, s);
 }
 
-int g_decode_b1_persistent = 0;   // batch-1 step as ONE persistent launch (decode_b1.hip): 0 = off, 1 / 2 / 3 = on with no / one / two weight batches requested in front of
-                                   // each grid barrier (trace_op_set_gemm_variant(900 + x))
+// batch-1 step as ONE persistent launch (decode_b1.hip).  0 = the launch-per-kernel step; x >= 1: DecodeB1Args::prefetch = x - 1.  Ships: 7 = two weight load
+// batches requested in front of each grid barrier by every wave but the polling one (profiles/r06_decode_b1_persistent_ab.txt: 2.88 vs 3.45 ms per token).
+// TRACE_DECODE_B1_PERSISTENT=0 in the environment (read once) or trace_op_set_gemm_variant(900) switch it off; trace_op_set_gemm_variant(900 + x) sets x.
+static int b1_default() { const char* e = getenv("TRACE_DECODE_B1_PERSISTENT"); return e ? (atoi(e) > 0 ? (atoi(e) == 1 ? 7 : atoi(e)) : 0) : 7; }
+int g_decode_b1_persistent = b1_default();
 // One decode step for ONE sequence as a single persistent launch of the 32 x 5 phases of decode_step_fused (same arithmetic, same partitions: bit-identical
 // ids and logits), followed by the final norm and the heads as before.
 // the persistent step's device-side layer table and barrier words (made outside any stream capture: trace_decode_begin)
@@ -1188,6 +1191,16 @@ static int b1_prepare(trace_ctx* c) {
         c->b1_bar = (unsigned int*)p;
     }
     return TRACE_OK;
+}
+// geometries the persistent kernel takes: every phase within one workgroup per CU, one 16-row tile per task except the gate|up product (others keep the launch-per-kernel step)
+static bool b1_persistent_fits(trace_ctx* c) {
+    DecodeB1Plan p[4];
+    skinny_plan_get(c->QKV, c->H, EPI_PARTIAL, 1, &p[0]); skinny_plan_get(c->H, c->H, EPI_PARTIAL, 1, &p[1]);
+    skinny_plan_get(2 * c->I, c->H, EPI_PARTIAL, 1, &p[2]); skinny_plan_get(c->H, c->I, EPI_PARTIAL, 1, &p[3]);
+    const int ncu = decode_b1_num_cus();
+    for (int i = 0; i < 4; ++i)
+        if (p[i].threads > 512 || p[i].grid > ncu || (p[i].NT != 1 && !(i == 2 && p[i].NT == 2))) return false;
+    return decode_nsplit(1) * c->NKV <= ncu && (c->H >> 3) <= 2 * p[0].threads && (c->H >> 3) <= 2 * p[2].threads;
 }
 static int decode_step_b1_persistent(trace_ctx* c, float* logits_out, hipStream_t s) {
     const int H = c->H, I = c->I, QKV = c->QKV;
@@ -1222,7 +1235,7 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
     // -> new residual, RMSNorm] -> gate|up -> [sum, SwiGLU] -> down -> [sum + residual, next layer's / the final RMSNorm].
     if (B > SKINNY_ROWS || (B >= g_decode_wide_min && !c->fp8)) return decode_step_wide(c, logits_out, s);      // (fp8 contexts: at most 64 rows, checked at begin)
     if (B == 1 && g_decode_b1_persistent && g_decode_fuse_norm_rows >= 1 && g_decode_fuse_swiglu && !c->fp8 && c->HD == 128 && skinny_fused_norm_ok(QKV, H, B) &&
-        skinny_fused_norm_ok(2 * I, H, B)) return decode_step_b1_persistent(c, logits_out, s);
+        skinny_fused_norm_ok(2 * I, H, B) && b1_persistent_fits(c)) return decode_step_b1_persistent(c, logits_out, s);
     if (B <= g_decode_fuse_norm_rows && !c->fp8 && skinny_fused_norm_ok(QKV, H, B) && skinny_fused_norm_ok(2 * I, H, B)) return decode_step_fused(c, logits_out, s);
     const bool wo = c->fp8 && c->fp8_wonly;          // weight-only decode GEMVs: bf16 activations straight from dH / dO / dACT, no quantiser launches
     const bool f8 = c->fp8 && !wo;
@@ -1341,7 +1354,9 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
     if (!use_graph) {
         for (int i = 0; i < n; ++i) { c->step_in_call = steps_before + i; TRY(decode_step(c, logits_out, s)); }
     } else {
-        const int key = c->B;      // (A/B switches that change the step's launches must not be flipped between replays of one context: tests use eager launches or fresh engines)
+        // one captured step per batch size; slot 0 = the persistent single-launch form of the batch-1 step (so that switching it off — trace_op_set_gemm_variant(900),
+        // the host's fallback after a barrier timeout — is not answered with the graph that holds it)
+        const int key = (c->B == 1 && g_decode_b1_persistent && !c->fp8 && c->b1_layers) ? 0 : c->B;
         hipGraphExec_t* slot_g = &c->graphs[key];
         if (!*slot_g) {
             hipGraph_t g = nullptr;
@@ -1516,7 +1531,7 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
-    if (variant >= 900 && variant <= 903) { g_decode_b1_persistent = variant - 900; return TRACE_OK; }
+    if (variant >= 900 && variant <= 932) { g_decode_b1_persistent = variant - 900; return TRACE_OK; }      // 0 off; x >= 1: DecodeB1Args::prefetch = x - 1 (bits 0-1 load batches ahead, 4 = the polling wave loads late, 8 / 16 = fence knock-outs, timing only)
     if (variant >= 760 && variant <= 764) { g_attn_decode_w3 = variant == 762 ? -1 : variant - 760; return TRACE_OK; }
     if (variant >= 780 && variant <= 799) { g_attn_decode_lds_pad = (variant - 780) * 8; return TRACE_OK; }
     if (variant >= 770 && variant <= 771) { g_attn_decode_nt = variant - 770; return TRACE_OK; }

@@ -178,7 +178,7 @@ int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vtcac
                        int nq, int nkv, int hd, int nsplit, float scale, int fuse_rope, const float* cos_t, const float* sin_t,
                        const float* qpart, int qks, hipStream_t s);   // qpart: fp32 partial rows [qks][SK_ROWS][ldq] instead of bf16 qkv
 // ---- the batch-1 decode step as one persistent launch (decode_b1.hip, round 6) ----
-struct DecodeB1Plan { int KS, chunk_units, T, WPT, ntiles, grid, threads; };     // decode.hip's SkinnyPlan of one GEMV (skinny_plan_get)
+struct DecodeB1Plan { int KS, chunk_units, T, WPT, ntiles, grid, threads, NT; };     // decode.hip's SkinnyPlan of one GEMV + its 16-row tiles per task (skinny_plan_get)
 struct DecodeB1Layer {
     const bf16_t *wqkv, *wo, *wgu, *wd;      // decode tile copies
     const bf16_t *rms1, *rms2;
@@ -201,6 +201,7 @@ struct DecodeB1Args {
     int prefetch;                            // weight / cache loads in front of the barriers: 0 none (A/B), 1 one batch, 2 two batches
 };
 size_t decode_b1_bar_bytes();
+int decode_b1_num_cus();
 int launch_decode_b1_persistent(const DecodeB1Args& a, hipStream_t s);
 void skinny_plan_get(int N, int K, int epi, int B, DecodeB1Plan* out);          // decode.hip
 

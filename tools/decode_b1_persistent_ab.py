@@ -20,11 +20,15 @@ if a.layers:
     cfg = dataclasses.replace(cfg, num_hidden_layers=a.layers)
 names = {900: "launch per kernel", 901: "persistent, no loads before barriers", 902: "persistent, one load batch ahead", 903: "persistent, two load batches ahead",
          906: "persistent, one batch ahead, wave 0 polls first", 907: "persistent, two batches ahead, wave 0 polls first",
-         917: "TIMING ONLY: 901 without acquire fences", 923: "TIMING ONLY: 907 without acquire fences"}
+         917: "TIMING ONLY: 901 without acquire fences", 923: "TIMING ONLY: 907 without acquire fences", 965: "TIMING ONLY: 901 with free barriers",
+         971: "TIMING ONLY: 907 with free barriers"}
 arms = [int(x) for x in a.arms.split(",")]
-engs, lg = {}, {}
+lg = {}
 torch.manual_seed(0)
 emb = (torch.randn(a.ctx, cfg.hidden_size, device="cuda") * 0.02).to(torch.bfloat16)
+# ONE engine per arm, created, measured and closed under its own variant (the switch is process-wide: an engine's decode_begin / graph capture follow the value
+# it has at that moment); rounds are therefore not interleaved — run the tool twice to see the box's repeatability
+ts = {v: [] for v in arms}
 for v in arms:
     ops.set_gemm_variant(v)
     e = TraceEngine(cfg, max_batch=1, max_ctx=a.ctx + 320, max_frames=128, max_new_tokens=256)
@@ -35,15 +39,8 @@ for v in arms:
         steps.append(e.decode_steps(1, use_graph=False, want_logits=True).clone())
     e.decode_read()
     lg[v] = torch.stack(steps)
-    e.decode_begin([0], [1], 256, eos=-1)
-    e.decode_steps(4, use_graph=True)                  # captures this engine's batch-1 graph under variant v
-    torch.cuda.synchronize()
-    e.decode_read()
-    engs[v] = e
-    print(f"arm {v} ready; logits over 7 steps bit-identical to arm {arms[0]}: {torch.equal(lg[v], lg[arms[0]])}", flush=True)
-ts = {v: [] for v in arms}
-for rnd in range(7):
-    for v, e in engs.items():
+    print(f"arm {v}: logits over 7 eager steps bit-identical to arm {arms[0]}: {torch.equal(lg[v], lg[arms[0]])}", flush=True)
+    for rnd in range(6):
         e.decode_begin([0], [1], 256, eos=-1)
         e.decode_steps(2, use_graph=True)
         torch.cuda.synchronize()
@@ -52,6 +49,7 @@ for rnd in range(7):
         torch.cuda.synchronize()
         ts[v].append((time.perf_counter() - t0) / a.steps * 1e3)
         e.decode_read()
+    e.close()
 ops.set_gemm_variant(907)
 for v in arms:
     m = statistics.median(ts[v][1:])

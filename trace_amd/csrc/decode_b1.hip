@@ -18,9 +18,11 @@
 // s_sleep).  Counters are monotonic within a launch (zeroed by a memset node in front of it); every spin is bounded — a timeout raises an error word
 // and the launch drains without hanging the device.
 #include "common.h"
+#include "gridbar.h"
 #include "kernels.h"
 
 namespace {
+using namespace gridbar;
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 __device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
@@ -28,76 +30,6 @@ __device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 union Frag { uint4 u; bf16x8_t v; };
-// What one workgroup hands to another inside the launch leaves as WRITE-THROUGH (sc1) stores: visible to the other XCDs once the storing wave's vmcnt
-// has drained, without the L2 write-back of a release fence (buffer_wbl2: measured 1 us per barrier, 0.16 ms of a 3.1 ms step).  base is wave-uniform.
-__device__ __forceinline__ void st_wt16(void* base, size_t byte_off, u32x4_t v) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7ffffff0, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 16);                  // aux 16 = sc1
-}
-
-constexpr int BAR_STRIDE = 32;                 // words between two barrier counters (128 bytes: one L2 line each)
-constexpr int BAR_CNT = 0, BAR_TOP = 8, BAR_GEN = 9, BAR_ERR = 17, BAR_WORDS = 18 * BAR_STRIDE;
-constexpr unsigned SPIN_LIMIT = 4u << 20;       // polls (each followed by s_sleep): a few seconds; then the launch gives up
-
-struct GridBar {
-    unsigned* w;
-    unsigned* err;         // sticky error word (not reset per launch)
-    unsigned epoch;        // barriers passed so far (same in every workgroup)
-    int nwg;
-    bool dead;             // a spin timed out somewhere: skip all further work
-    int opt;               // A/B bits (DecodeB1Args::prefetch >> 2): 1 = wave 0 polls before it requests its own weights, 4 = no acquire fence (TIMING ONLY)
-};
-
-__device__ __forceinline__ unsigned bar_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// end of a phase: every wave's stores have left (vmcnt), the workgroup meets, one lane makes them visible to the other XCDs and checks in
-__device__ __forceinline__ void bar_arrive(GridBar& gb) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // (every cross-workgroup payload store of this file is write-through and has drained: no release fence)
-        __hip_atomic_fetch_add(gb.w + (BAR_CNT + (blockIdx.x & 7)) * BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    gb.epoch += 1;
-}
-// wait until every workgroup has checked in for the current epoch; returns with the workgroup synchronised and its caches acquired
-__device__ __forceinline__ void bar_wait(GridBar& gb, int* s_flag) {
-    if (threadIdx.x == 0) {
-        const int g = blockIdx.x & 7;
-        const unsigned members = (unsigned)((gb.nwg - g + 7) >> 3), groups = (unsigned)(gb.nwg < 8 ? gb.nwg : 8);
-        bool ok = true;
-        unsigned spins = 0;
-        if ((int)blockIdx.x < 8) {
-            while (bar_load(gb.w + (BAR_CNT + g) * BAR_STRIDE) < members * gb.epoch) {
-                if (++spins > SPIN_LIMIT || bar_load(gb.w + BAR_ERR * BAR_STRIDE)) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (ok) {
-                __hip_atomic_fetch_add(gb.w + BAR_TOP * BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while (bar_load(gb.w + BAR_TOP * BAR_STRIDE) < groups * gb.epoch) {
-                    if (++spins > SPIN_LIMIT || bar_load(gb.w + BAR_ERR * BAR_STRIDE)) { ok = false; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            if (ok) __hip_atomic_store(gb.w + (BAR_GEN + g) * BAR_STRIDE, gb.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            while (bar_load(gb.w + (BAR_GEN + g) * BAR_STRIDE) < gb.epoch) {
-                if (++spins > SPIN_LIMIT || bar_load(gb.w + BAR_ERR * BAR_STRIDE)) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        if (!ok) {
-            __hip_atomic_store(gb.w + BAR_ERR * BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(gb.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // sticky: the host reads it in trace_decode_read
-        }
-        if (!(gb.opt & 4)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *s_flag = ok ? 0 : 1;
-    }
-    __syncthreads();
-    if (*s_flag) gb.dead = true;
-    __syncthreads();
-}
-
 typedef DecodeB1Plan B1Plan;
 typedef DecodeB1Layer B1Layer;
 typedef DecodeB1Args B1Args;
@@ -588,6 +520,9 @@ __global__ __launch_bounds__(512) void decode_b1_persistent_kernel(B1Args A) {
     __shared__ int s_flag;
     __shared__ float s_ss[8];
     GridBar gb{A.bar, A.err, 0u, (int)gridDim.x, false, A.prefetch >> 2};
+    bar_begin(gb, &s_flag);
+    const unsigned final_epoch = gb.epoch + 5u * (unsigned)A.NL - 1u;     // five barriers per layer, none behind the last phase (its consumer is the next kernel):
+                                                                          // every bar_arrive has its bar_wait, so the counters of all three levels agree at the end
     bf16_t *xa = A.xa, *xb = A.xb;
     for (int l = 0; l < A.NL; ++l) {
         const B1Layer Lw = A.layers[l];
@@ -615,15 +550,16 @@ __global__ __launch_bounds__(512) void decode_b1_persistent_kernel(B1Args A) {
         {
             const Pro pro{A.ws2, A.pg.KS, nullptr, nullptr, nullptr, 0.f};
             gemv_phase<1, 2>(smem, A.pd, nullptr, Lw.wd, A.H, A.I, A.ws, pro, gb, true, A.prefetch, &s_flag, s_ss);
-            bar_arrive(gb);
+            if (l + 1 < A.NL) bar_arrive(gb);
         }
         if (gb.dead) return;
     }
+    bar_end(gb, final_epoch);          // (workgroup 0 is past the last bar_wait: every workgroup has read BASE)
 }
 
 }  // namespace
 
-size_t decode_b1_bar_bytes() { return (size_t)BAR_WORDS * 4; }
+size_t decode_b1_bar_bytes() { return gridbar::bar_bytes(); }
 int decode_b1_num_cus() {          // CUs of the current device (cached per device id)
     static std::atomic<int> cache[32];
     int dev = 0;
@@ -656,7 +592,6 @@ int launch_decode_b1_persistent(const DecodeB1Args& a, hipStream_t s) {
     if (maxgrid > ncu || (a.H >> 3) > 2 * a.pq.threads || (a.H >> 3) > 2 * a.pg.threads || a.nsplit < 1 || !a.bar || !a.err || !a.layers) return TRACE_ERR_STATE;
     static LdsGrantSized grant;
     if (!grant_dynamic_lds(grant, reinterpret_cast<const void*>(decode_b1_persistent_kernel), lds)) return TRACE_ERR_HIP;
-    if (hipMemsetAsync(a.bar, 0, decode_b1_bar_bytes(), s) != hipSuccess) return TRACE_ERR_HIP;
     hipLaunchKernelGGL(decode_b1_persistent_kernel, dim3(ncu), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }

@@ -87,6 +87,7 @@ struct trace_ctx {
     float* sk_ws = nullptr; unsigned int* sk_tickets = nullptr; size_t sk_ws_floats = 0; int sk_ntickets = 0;   // decode GEMV K-chunk partials
     float* sk_ws2 = nullptr;           // second partial-row buffer and residual rows: the fused-norm GEMVs of small batches read one and write the other
     bf16_t* dX2 = nullptr;
+    unsigned int* wide_bar = nullptr;    // barrier words + sticky error word of the wide step's persistent chain (decode_wide.hip)
     DecodeB1Layer* b1_layers = nullptr;  // device table of the persistent batch-1 step (decode_b1.hip), built on first use
     unsigned int* b1_bar = nullptr;      // its barrier words + one sticky error word behind them
     int b1_used = 0;                     // the persistent step ran since trace_decode_begin: trace_decode_read checks the error word
@@ -106,6 +107,7 @@ struct trace_ctx {
     int host_mode = 0, fed = 0;        // host-driven token selection (sampling): head logits only, ids fed back by the host
     int steps_done = 0;                // decode steps taken since trace_decode_begin (bounded by max_new - 1: the KV slot and the RoPE tables end at max_ctx)
     hipGraphExec_t graphs[SK_ROWS + 1] = {nullptr};   // one captured decode step per batch size
+    int graph_chain[SK_ROWS + 1] = {0};               // g_decode_wide_chain each was captured under
     hipStream_t cap_stream = nullptr;
     std::vector<hipStream_t> streams;   // trace_stream_create
     // profiling
@@ -1071,11 +1073,20 @@ int g_decode_gemm_tiled = 5;   // wide decode step, GemmArgs::w_tiled: bit 0 = w
 // no combine kernel — and qkv / o / down cut along K into gemm_partial_ks() chunks whose fp32 partial rows the same consumers as below sum on
 // load.  The weights (14 GB per step) are then streamed once per 128 tokens instead of once per 64: bytes per token 0.50 -> 0.39 GB at
 // ctx ~2100, where the KV stream (0.27 GB per token) is the larger part.
+extern int g_partial_cfg;
+int g_decode_wide_chain = 0;   // the projections between two attentions of a wide step as ONE persistent launch (decode_wide.hip): 0 off, 1 on, 2 on + weight tiles requested in
+                               // front of the grid barriers (trace_op_set_gemm_variant(990 + x))
+static bool wide_chain_fits(trace_ctx* c, int ks_q, int ks_o, int ks_d) {
+    const int ncu = decode_b1_num_cus();
+    return c->B <= 128 && !c->fp8 && (g_decode_gemm_tiled & 5) == 5 && g_partial_cfg == 0 && c->H <= 4096 && c->H % 128 == 0 && c->QKV % 128 == 0 && (2 * c->I) % 128 == 0 &&
+           c->HD == 128 && (c->H / 128) * ks_o <= ncu && (c->H / 128) * ks_d <= ncu && (c->QKV / 128) * ks_q <= ncu && (2 * c->I) / 128 <= ncu && c->wide_bar;
+}
 static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
     const int H = c->H, I = c->I, HD = c->HD, QKV = c->QKV, B = c->B;
     if (c->fp8) return fail(TRACE_ERR_STATE, "the fp8 weight path decodes at most 64 sequences together");
     const int ks_q = gemm_partial_ks(QKV, H), ks_o = gemm_partial_ks(H, H), ks_d = gemm_partial_ks(H, I);
     const int wt = g_decode_gemm_tiled;      // bit 0: weights from the decode tile copies, bit 1: non-temporal weight loads
+    const bool chain = g_decode_wide_chain && wide_chain_fits(c, ks_q, ks_o, ks_d);
     auto pgemm = [&](const bf16_t* A, int lda, const bf16_t* Wrow, const bf16_t* Wtile, int ldw, int N, int K, int ks) -> int {
         GemmArgs g{A, lda, (wt & 1) ? Wtile : Wrow, ldw, nullptr, 0, nullptr, nullptr, 0, B, N, K, nullptr, 0, nullptr, nullptr, 0, c->sk_ws, ks, (wt & 1) ? wt : 0};
         if ((size_t)ks * SK_ROWS * N > c->sk_ws_floats) return fail(TRACE_ERR_STATE, "partial-row workspace too small");
@@ -1088,9 +1099,11 @@ static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
         const LlmLayer& W = c->llm[l];
         bf16_t* kc = c->kcache + (size_t)l * c->layer_stride;
         bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
-        TRY(pgemm(c->dH, H, W.wqkv, W.wqkv_d, H, QKV, H, ks_q));
-        LCHK(launch_qkv_finish(c->sk_ws, ks_q, QKV, c->dQKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots,
-                               c->d_pos, B, c->NQ, c->NKV, c->rope_cos, c->rope_sin, s));
+        if (!chain || l == 0) {          // (with the chain, layer l's qkv projection + finish ran at the end of layer l - 1's launch)
+            TRY(pgemm(c->dH, H, W.wqkv, W.wqkv_d, H, QKV, H, ks_q));
+            LCHK(launch_qkv_finish(c->sk_ws, ks_q, QKV, c->dQKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots,
+                                   c->d_pos, B, c->NQ, c->NKV, c->rope_cos, c->rope_sin, s));
+        }
         // roofline probe (profile == 2, eager launches): HIP events around ONE launch of the step's dominant kernel — the layer-0 decode
         // attention, which streams the batch's whole KV cache of that layer
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1104,6 +1117,24 @@ static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
                                 H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, decode_nsplit(B), 1.0f / sqrtf((float)HD), 0,
                                 nullptr, nullptr, nullptr, 0, s));
         if (e1) hipEventRecord(e1, s);
+        if (chain) {
+            const bool last = l + 1 == c->NL;
+            DecodeWideArgs a{};
+            a.dO = c->dO; a.dX = c->dX; a.dH = c->dH; a.dACT = c->dACT; a.dQKV = c->dQKV; a.part = c->sk_ws;
+            a.wo = W.wo_d; a.wgu = W.wgu_d; a.wd = W.wd_d; a.wqkv_next = last ? nullptr : c->llm[l + 1].wqkv_d;
+            a.rms2 = W.rms2; a.rms_next = last ? c->final_norm : c->llm[l + 1].rms1;
+            a.B = B; a.H = H; a.I = I; a.QKV = QKV; a.NQ = c->NQ; a.NKV = c->NKV; a.ks_o = ks_o; a.ks_d = ks_d; a.ks_q = ks_q;
+            a.eps = c->c.rms_eps; a.last = last ? 1 : 0;
+            a.kc_next = last ? nullptr : c->kcache + (size_t)(l + 1) * c->layer_stride;
+            a.vc_next = last ? nullptr : c->vcache + (size_t)(l + 1) * c->layer_stride;
+            a.slot_stride = (long)c->slot_stride; a.kv_head_stride = (long)c->kv_head_stride; a.ctx_stride = c->ctx_pad;
+            a.slots = c->d_slots; a.pos = c->d_pos; a.cos_t = c->rope_cos; a.sin_t = c->rope_sin;
+            a.bar = c->wide_bar; a.err = c->wide_bar + decode_wide_bar_bytes() / 4; a.prefetch = g_decode_wide_chain > 1;
+            const int rc = launch_decode_wide_chain(a, s);
+            if (rc != TRACE_OK) return fail(rc, "persistent wide-step chain launch failed");
+            c->b1_used = 2;
+            continue;
+        }
         TRY(pgemm(c->dO, H, W.wo, W.wo_d, H, H, H, ks_o));
         LCHK(launch_add_rmsnorm(c->sk_ws, ks_o, c->dX, H, c->dX, H, W.rms2, c->dH, H, B, H, c->c.rms_eps, s));
         if (wt & 1) {
@@ -1328,7 +1359,15 @@ extern "C" int trace_decode_begin(trace_ctx* c, const int32_t* slots, int B, con
     HIPCHK(hipMemcpyAsync(c->d_params, prm, 12, hipMemcpyHostToDevice, s));
     c->fed = 0; c->steps_done = 0; c->b1_used = 0;
     if (B == 1 && g_decode_b1_persistent && !c->fp8) TRY(b1_prepare(c));
-    if (c->b1_bar) HIPCHK(hipMemsetAsync(c->b1_bar + decode_b1_bar_bytes() / 4, 0, 4, s));
+    if (!c->wide_bar && g_decode_wide_chain && !c->fp8) {
+        void* p = nullptr;
+        HIPCHK(hipMalloc(&p, decode_wide_bar_bytes() + 256));
+        c->allocs.push_back(p);
+        HIPCHK(hipMemset(p, 0, decode_wide_bar_bytes() + 256));
+        c->wide_bar = (unsigned int*)p;
+    }
+    if (c->wide_bar) HIPCHK(hipMemsetAsync(c->wide_bar, 0, decode_wide_bar_bytes() + 16, s));
+    if (c->b1_bar) HIPCHK(hipMemsetAsync(c->b1_bar, 0, decode_b1_bar_bytes() + 16, s));          // barrier counters + error record: zeroed only here, while no decode kernel runs
     if (forced) HIPCHK(hipMemcpyAsync(c->d_forced, forced, (size_t)B * max_new * 4, hipMemcpyHostToDevice, s));
     else HIPCHK(hipMemsetAsync(c->d_forced, 0xff, (size_t)B * max_new * 4, s));      // -1 = not forced
     // gather the prefill hidden rows of the chosen slots into dH, then head + select (no position advance)
@@ -1357,6 +1396,8 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
         // one captured step per batch size; slot 0 = the persistent single-launch form of the batch-1 step (so that switching it off — trace_op_set_gemm_variant(900),
         // the host's fallback after a barrier timeout — is not answered with the graph that holds it)
         const int key = (c->B == 1 && g_decode_b1_persistent && !c->fp8 && c->b1_layers) ? 0 : c->B;
+        if (c->graph_chain[key] != g_decode_wide_chain && *(&c->graphs[key])) { hipGraphExecDestroy(c->graphs[key]); c->graphs[key] = nullptr; }      // captured under another setting of the chain switch
+        c->graph_chain[key] = g_decode_wide_chain;
         hipGraphExec_t* slot_g = &c->graphs[key];
         if (!*slot_g) {
             hipGraph_t g = nullptr;
@@ -1406,9 +1447,16 @@ extern "C" int trace_decode_read(trace_ctx* c, int32_t* out_ids, int32_t* out_le
     if (out_len) HIPCHK(hipMemcpyAsync(out_len, c->d_out_len, c->B * 4, hipMemcpyDeviceToHost, s));
     if (heads) HIPCHK(hipMemcpyAsync(heads, c->d_heads, c->B * 4, hipMemcpyDeviceToHost, s));
     unsigned int b1_err = 0;
-    if (c->b1_used && c->b1_bar) HIPCHK(hipMemcpyAsync(&b1_err, c->b1_bar + decode_b1_bar_bytes() / 4, 4, hipMemcpyDeviceToHost, s));
+    if (c->b1_used == 1 && c->b1_bar) HIPCHK(hipMemcpyAsync(&b1_err, c->b1_bar + decode_b1_bar_bytes() / 4, 4, hipMemcpyDeviceToHost, s));
+    if (c->b1_used == 2 && c->wide_bar) HIPCHK(hipMemcpyAsync(&b1_err, c->wide_bar + decode_wide_bar_bytes() / 4, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (b1_err) return fail(TRACE_ERR_STATE, "the persistent batch-1 decode step gave up at a grid barrier (not all of its workgroups were resident): ids are invalid");
+    if (b1_err) {
+        unsigned int rec[4] = {0, 0, 0, 0};
+        hipMemcpy(rec, c->b1_used == 1 ? c->b1_bar + decode_b1_bar_bytes() / 4 : c->wide_bar + decode_wide_bar_bytes() / 4, 16, hipMemcpyDeviceToHost);
+        return fail(TRACE_ERR_STATE, "a persistent decode kernel gave up at a grid barrier (barrier " + std::to_string(rec[1]) + ", workgroup " + std::to_string(rec[2]) + ", after " +
+                                         std::to_string(rec[3]) + " polls; not all of its workgroups were resident?): ids are invalid");
+    }
+    if (false) return fail(TRACE_ERR_STATE, "a persistent decode kernel gave up at a grid barrier (not all of its workgroups were resident): ids are invalid");
     return TRACE_OK;
 }
 
@@ -1531,7 +1579,8 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
-    if (variant >= 900 && variant <= 932) { g_decode_b1_persistent = variant - 900; return TRACE_OK; }      // 0 off; x >= 1: DecodeB1Args::prefetch = x - 1 (bits 0-1 load batches ahead, 4 = the polling wave loads late, 8 / 16 = fence knock-outs, timing only)
+        if (variant >= 990 && variant <= 992) { g_decode_wide_chain = variant - 990; return TRACE_OK; }
+    if (variant >= 900 && variant <= 989) { g_decode_b1_persistent = variant - 900; return TRACE_OK; }      // 0 off; x >= 1: DecodeB1Args::prefetch = x - 1 (bits 0-1 load batches ahead, 4 = the polling wave loads late, 8 / 16 = fence knock-outs, timing only)
     if (variant >= 760 && variant <= 764) { g_attn_decode_w3 = variant == 762 ? -1 : variant - 760; return TRACE_OK; }
     if (variant >= 780 && variant <= 799) { g_attn_decode_lds_pad = (variant - 780) * 8; return TRACE_OK; }
     if (variant >= 770 && variant <= 771) { g_attn_decode_nt = variant - 770; return TRACE_OK; }

@@ -205,6 +205,24 @@ int decode_b1_num_cus();
 int launch_decode_b1_persistent(const DecodeB1Args& a, hipStream_t s);
 void skinny_plan_get(int N, int K, int epi, int B, DecodeB1Plan* out);          // decode.hip
 
+// ---- the wide decode step's projection chain as one persistent launch per layer (decode_wide.hip, round 6) ----
+struct DecodeWideArgs {
+    const bf16_t* dO; bf16_t* dX; bf16_t* dH; bf16_t* dACT; bf16_t* dQKV; float* part;      // attention output, residual rows (in / out), normed rows, SwiGLU rows, q rows, partial rows
+    const bf16_t *wo, *wgu, *wd, *wqkv_next;      // decode tile copies (wqkv_next: the NEXT layer's)
+    const bf16_t *rms2, *rms_next;                // post-attention norm; the next layer's input norm (last layer: the final norm)
+    int B, H, I, QKV, NQ, NKV, ks_o, ks_d, ks_q;  // ks_*: gemm_partial_ks of the three split-K products
+    float eps;
+    int last;                                     // 1: stop after the second add + RMSNorm (no next layer)
+    bf16_t *kc_next, *vc_next;                    // the next layer's caches (qkv finish appends k / v)
+    long slot_stride, kv_head_stride; int ctx_stride;
+    const int32_t *slots, *pos;
+    const float *cos_t, *sin_t;
+    unsigned *bar, *err;                          // decode_wide_bar_bytes() of barrier words (zeroed by the launcher); one sticky error word
+    int prefetch;                                 // 1: weight tiles requested in front of the grid barriers
+};
+size_t decode_wide_bar_bytes();
+int launch_decode_wide_chain(const DecodeWideArgs& a, hipStream_t s);
+
 // heads: logits over [text V+1 | time Tv | score Sv] rows of Wh [NV_pad, H]; only tiles intersecting an active
 // head's range are computed.  part: [B, ntiles] (max,idx).  logits_out optional [B, NV] fp32 (masked -inf).
 int launch_head_logits(const bf16_t* X, int ldx, const bf16_t* Wh, int H, const int32_t* heads, int V, int Tv, int Sv,

@@ -540,76 +540,6 @@ def test_batch1_swiglu_fold_is_bit_identical(golden_dir):
         eng.close()
 
 
-def test_batch1_persistent_step_is_bit_identical(golden_dir):
-    """Round 6: the batch-1 decode step as ONE persistent launch (decode_b1.hip: the 32 x 5 phases of the launch-per-kernel step behind grid barriers,
-    the next phase's weights requested in front of each barrier).  Same partitions, same arithmetic: the logits of every teacher-forced step and the ids
-    must equal the launch-per-kernel path's bit for bit — at the real MLP width (two layers) and at the tiny geometry, with and without the weight
-    requests in front of the barriers, eager and as a replayed hipGraph; a long free run must not trip the barrier's timeout word."""
-    import dataclasses
-    from trace_amd.engine import ops
-    for cfg in (dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336, num_hidden_layers=2), tcfg.tiny(num_frames=4)):
-        M = np.load(os.path.join(golden_dir, "medium_llm.npz"))
-        frames = synth.synth_frames(cfg, 0).to(torch.bfloat16)
-        forced = M["forced_ids"].tolist()[:20]
-        n = len(forced) + 1
-        runs = {}
-        try:
-            for mode in (0, 7, 1):              # launch per kernel; the shipped persistent form (two load batches ahead, the polling wave loads late); no loads ahead
-                ops.set_gemm_variant(900 + mode)
-                eng = TraceEngine(cfg, max_batch=1, max_ctx=192, max_frames=4, max_new_tokens=64)      # (a fresh engine per mode: graphs are cached per batch size)
-                eng.load_weights(synth.iter_weights(cfg))
-                eng.encode_video(frames, M["timestamps"].tolist())
-                eng.prefill(0, eng.splice(M["input_ids"].tolist()))
-                lgs = [eng.decode_begin([0], [1], n, eos=-1, forced=[forced], want_logits=True).float().cpu()]
-                for _ in range(n - 1):
-                    lgs.append(eng.decode_steps(1, use_graph=False, want_logits=True).float().cpu())
-                ids_e = eng.decode_read()[0]
-                eng.decode_begin([0], [1], n, eos=-1, forced=[forced])
-                eng.decode_steps(n - 1, use_graph=True)
-                ids_g = eng.decode_read()[0]
-                runs[mode] = (torch.stack(lgs), ids_e, ids_g)
-                eng.close()
-        finally:
-            ops.set_gemm_variant(907)
-        for mode in (7, 1):
-            assert torch.equal(runs[mode][0], runs[0][0]), (mode, (runs[mode][0] - runs[0][0])[torch.isfinite(runs[0][0])].abs().max())
-            assert runs[mode][1] == runs[0][1] and runs[mode][2] == runs[0][2] == runs[0][1]
-
-
-@pytest.mark.parametrize("nb", [40, 128])
-def test_wide_chain_is_bit_identical(golden_dir, nb):
-    """Round 6: the projections between two attentions of a wide decode step (o GEMM, add + RMSNorm, gate|up GEMM + SwiGLU, down GEMM, add + RMSNorm, the next
-    layer's qkv GEMM + finish) as ONE persistent launch per layer (decode_wide.hip) instead of seven.  Same tile kernels, same K order, same reduction
-    trees: the logits of every step and the ids must equal the launch-per-kernel step's bit for bit — at the real MLP width (two layers: K-chunked down
-    projection) and at the tiny geometry (a two-tile K loop), with and without the weight requests in front of the barriers, eager and replayed."""
-    import dataclasses
-    from trace_amd.engine import ops
-    for cfg in (dataclasses.replace(tcfg.tiny(num_frames=4), intermediate_size=14336, num_hidden_layers=2), tcfg.tiny(num_frames=4)):
-        M = np.load(os.path.join(golden_dir, "medium_llm.npz"))
-        f0 = synth.synth_frames(cfg, 0).to(torch.bfloat16)
-        f1 = synth.synth_frames(cfg, 1).to(torch.bfloat16)
-        ts, ids = M["timestamps"].tolist(), M["input_ids"].tolist()
-        n = 6
-        runs = {}
-        try:
-            for mode in (0, 2, 1):
-                ops.set_gemm_variant(990 + mode)
-                eng = TraceEngine(cfg, max_batch=nb, max_ctx=192, max_frames=4, max_new_tokens=16)
-                eng.load_weights(synth.iter_weights(cfg))
-                vids = [f0 if i % 2 == 0 else f1 for i in range(nb)]
-                out_g, _ = eng.generate(vids, [ts] * nb, [ids] * nb, [1] * nb, n, use_graph=True)       # prefills every slot; ids through the replayed graph
-                lgs = [eng.decode_begin(list(range(nb)), [1] * nb, n, eos=-1, want_logits=True).float().cpu()]
-                for _ in range(n - 1):
-                    lgs.append(eng.decode_steps(1, use_graph=False, want_logits=True).float().cpu())
-                runs[mode] = (torch.stack(lgs), eng.decode_read()[0], out_g)
-                eng.close()
-        finally:
-            ops.set_gemm_variant(990)
-        for mode in (2, 1):
-            assert torch.equal(runs[mode][0], runs[0][0]), (mode, (runs[mode][0] - runs[0][0])[torch.isfinite(runs[0][0])].abs().max())
-            assert runs[mode][1] == runs[0][1] == runs[0][2] == runs[mode][2]
-
-
 @pytest.mark.parametrize("geometry", ["vit_l_14_336", "tiny"])
 def test_fused_patch_embed_matches_three_pass_front_end(geometry):
     """Round 4: the ViT front end as one kernel — patches read straight from the frame tensor (no im2col matrix), MFMA GEMM, CLS / position

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libtrace_hip.so")
 LIB_F16 = os.path.join(HERE, "libtrace_hip_f16.so")
-SOURCES = ["gemm", "gemm_ldr", "gemm_pers", "gemm_w4", "norm", "vit", "patch_embed", "attn", "slot_pool", "llm", "decode", "decode_b1", "decode_wide", "fp8", "stc", "preproc", "engine"]
+SOURCES = ["gemm", "gemm_ldr", "gemm_pers", "gemm_w4", "norm", "vit", "patch_embed", "attn", "slot_pool", "llm", "decode", "fp8", "stc", "preproc", "engine"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 

@@ -1027,10 +1027,6 @@ size_t skinny_ws_floats(int N, int K, int epi) {
     return f;
 }
 int skinny_ks(int N, int K, int epi, int B) { return skinny_plan(N, K, epi, B).KS; }
-void skinny_plan_get(int N, int K, int epi, int B, DecodeB1Plan* out) {
-    const SkinnyPlan p = skinny_plan(N, K, epi, B);
-    *out = DecodeB1Plan{p.KS, p.chunk_units, p.T, p.WPT, p.ntiles, p.grid, p.threads, skinny_nt(N, epi)};
-}
 
 template <int EPI, int NB, int NT, int PRO = 0>
 static int skinny_lds_launch(const SkinnyPlan& p, const bf16_t* X, int ldx, const bf16_t* W, int ldw, bf16_t* out, int ldo,

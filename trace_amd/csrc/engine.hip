@@ -87,10 +87,6 @@ struct trace_ctx {
     float* sk_ws = nullptr; unsigned int* sk_tickets = nullptr; size_t sk_ws_floats = 0; int sk_ntickets = 0;   // decode GEMV K-chunk partials
     float* sk_ws2 = nullptr;           // second partial-row buffer and residual rows: the fused-norm GEMVs of small batches read one and write the other
     bf16_t* dX2 = nullptr;
-    unsigned int* wide_bar = nullptr;    // barrier words + sticky error word of the wide step's persistent chain (decode_wide.hip)
-    DecodeB1Layer* b1_layers = nullptr;  // device table of the persistent batch-1 step (decode_b1.hip), built on first use
-    unsigned int* b1_bar = nullptr;      // its barrier words + one sticky error word behind them
-    int b1_used = 0;                     // the persistent step ran since trace_decode_begin: trace_decode_read checks the error word
     float* part_val; int32_t* part_idx;
     float* hl_val; int32_t* hl_idx;        // trace_llm_head_logits' own partial buffers
     int32_t *d_slots, *d_pos, *d_heads, *d_done, *d_out_ids, *d_out_len, *d_step, *d_forced, *d_params;
@@ -107,7 +103,6 @@ struct trace_ctx {
     int host_mode = 0, fed = 0;        // host-driven token selection (sampling): head logits only, ids fed back by the host
     int steps_done = 0;                // decode steps taken since trace_decode_begin (bounded by max_new - 1: the KV slot and the RoPE tables end at max_ctx)
     hipGraphExec_t graphs[SK_ROWS + 1] = {nullptr};   // one captured decode step per batch size
-    int graph_chain[SK_ROWS + 1] = {0};               // g_decode_wide_chain each was captured under
     hipStream_t cap_stream = nullptr;
     std::vector<hipStream_t> streams;   // trace_stream_create
     // profiling
@@ -1073,20 +1068,11 @@ int g_decode_gemm_tiled = 5;   // wide decode step, GemmArgs::w_tiled: bit 0 = w
 // no combine kernel — and qkv / o / down cut along K into gemm_partial_ks() chunks whose fp32 partial rows the same consumers as below sum on
 // load.  The weights (14 GB per step) are then streamed once per 128 tokens instead of once per 64: bytes per token 0.50 -> 0.39 GB at
 // ctx ~2100, where the KV stream (0.27 GB per token) is the larger part.
-extern int g_partial_cfg;
-int g_decode_wide_chain = 0;   // the projections between two attentions of a wide step as ONE persistent launch (decode_wide.hip): 0 off, 1 on, 2 on + weight tiles requested in
-                               // front of the grid barriers (trace_op_set_gemm_variant(990 + x))
-static bool wide_chain_fits(trace_ctx* c, int ks_q, int ks_o, int ks_d) {
-    const int ncu = decode_b1_num_cus();
-    return c->B <= 128 && !c->fp8 && (g_decode_gemm_tiled & 5) == 5 && g_partial_cfg == 0 && c->H <= 4096 && c->H % 128 == 0 && c->QKV % 128 == 0 && (2 * c->I) % 128 == 0 &&
-           c->HD == 128 && (c->H / 128) * ks_o <= ncu && (c->H / 128) * ks_d <= ncu && (c->QKV / 128) * ks_q <= ncu && (2 * c->I) / 128 <= ncu && c->wide_bar;
-}
 static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
     const int H = c->H, I = c->I, HD = c->HD, QKV = c->QKV, B = c->B;
     if (c->fp8) return fail(TRACE_ERR_STATE, "the fp8 weight path decodes at most 64 sequences together");
     const int ks_q = gemm_partial_ks(QKV, H), ks_o = gemm_partial_ks(H, H), ks_d = gemm_partial_ks(H, I);
     const int wt = g_decode_gemm_tiled;      // bit 0: weights from the decode tile copies, bit 1: non-temporal weight loads
-    const bool chain = g_decode_wide_chain && wide_chain_fits(c, ks_q, ks_o, ks_d);
     auto pgemm = [&](const bf16_t* A, int lda, const bf16_t* Wrow, const bf16_t* Wtile, int ldw, int N, int K, int ks) -> int {
         GemmArgs g{A, lda, (wt & 1) ? Wtile : Wrow, ldw, nullptr, 0, nullptr, nullptr, 0, B, N, K, nullptr, 0, nullptr, nullptr, 0, c->sk_ws, ks, (wt & 1) ? wt : 0};
         if ((size_t)ks * SK_ROWS * N > c->sk_ws_floats) return fail(TRACE_ERR_STATE, "partial-row workspace too small");
@@ -1099,11 +1085,9 @@ static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
         const LlmLayer& W = c->llm[l];
         bf16_t* kc = c->kcache + (size_t)l * c->layer_stride;
         bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
-        if (!chain || l == 0) {          // (with the chain, layer l's qkv projection + finish ran at the end of layer l - 1's launch)
-            TRY(pgemm(c->dH, H, W.wqkv, W.wqkv_d, H, QKV, H, ks_q));
-            LCHK(launch_qkv_finish(c->sk_ws, ks_q, QKV, c->dQKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots,
-                                   c->d_pos, B, c->NQ, c->NKV, c->rope_cos, c->rope_sin, s));
-        }
+        TRY(pgemm(c->dH, H, W.wqkv, W.wqkv_d, H, QKV, H, ks_q));
+        LCHK(launch_qkv_finish(c->sk_ws, ks_q, QKV, c->dQKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots,
+                               c->d_pos, B, c->NQ, c->NKV, c->rope_cos, c->rope_sin, s));
         // roofline probe (profile == 2, eager launches): HIP events around ONE launch of the step's dominant kernel — the layer-0 decode
         // attention, which streams the batch's whole KV cache of that layer
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1117,24 +1101,6 @@ static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
                                 H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, decode_nsplit(B), 1.0f / sqrtf((float)HD), 0,
                                 nullptr, nullptr, nullptr, 0, s));
         if (e1) hipEventRecord(e1, s);
-        if (chain) {
-            const bool last = l + 1 == c->NL;
-            DecodeWideArgs a{};
-            a.dO = c->dO; a.dX = c->dX; a.dH = c->dH; a.dACT = c->dACT; a.dQKV = c->dQKV; a.part = c->sk_ws;
-            a.wo = W.wo_d; a.wgu = W.wgu_d; a.wd = W.wd_d; a.wqkv_next = last ? nullptr : c->llm[l + 1].wqkv_d;
-            a.rms2 = W.rms2; a.rms_next = last ? c->final_norm : c->llm[l + 1].rms1;
-            a.B = B; a.H = H; a.I = I; a.QKV = QKV; a.NQ = c->NQ; a.NKV = c->NKV; a.ks_o = ks_o; a.ks_d = ks_d; a.ks_q = ks_q;
-            a.eps = c->c.rms_eps; a.last = last ? 1 : 0;
-            a.kc_next = last ? nullptr : c->kcache + (size_t)(l + 1) * c->layer_stride;
-            a.vc_next = last ? nullptr : c->vcache + (size_t)(l + 1) * c->layer_stride;
-            a.slot_stride = (long)c->slot_stride; a.kv_head_stride = (long)c->kv_head_stride; a.ctx_stride = c->ctx_pad;
-            a.slots = c->d_slots; a.pos = c->d_pos; a.cos_t = c->rope_cos; a.sin_t = c->rope_sin;
-            a.bar = c->wide_bar; a.err = c->wide_bar + decode_wide_bar_bytes() / 4; a.prefetch = g_decode_wide_chain > 1;
-            const int rc = launch_decode_wide_chain(a, s);
-            if (rc != TRACE_OK) return fail(rc, "persistent wide-step chain launch failed");
-            c->b1_used = 2;
-            continue;
-        }
         TRY(pgemm(c->dO, H, W.wo, W.wo_d, H, H, H, ks_o));
         LCHK(launch_add_rmsnorm(c->sk_ws, ks_o, c->dX, H, c->dX, H, W.rms2, c->dH, H, B, H, c->c.rms_eps, s));
         if (wt & 1) {
@@ -1196,65 +1162,6 @@ static int decode_step_fused(trace_ctx* c, float* logits_out, hipStream_t s) {
     return head_and_select(c, c->dH, 1, logits_out, s);
 }
 
-// batch-1 step as ONE persistent launch (decode_b1.hip).  0 = the launch-per-kernel step; x >= 1: DecodeB1Args::prefetch = x - 1.  Ships: 7 = two weight load
-// batches requested in front of each grid barrier by every wave but the polling one (profiles/r06_decode_b1_persistent_ab.txt: 2.88 vs 3.45 ms per token).
-// TRACE_DECODE_B1_PERSISTENT=0 in the environment (read once) or trace_op_set_gemm_variant(900) switch it off; trace_op_set_gemm_variant(900 + x) sets x.
-static int b1_default() { const char* e = getenv("TRACE_DECODE_B1_PERSISTENT"); return e ? (atoi(e) > 0 ? (atoi(e) == 1 ? 7 : atoi(e)) : 0) : 7; }
-int g_decode_b1_persistent = b1_default();
-// One decode step for ONE sequence as a single persistent launch of the 32 x 5 phases of decode_step_fused (same arithmetic, same partitions: bit-identical
-// ids and logits), followed by the final norm and the heads as before.
-// the persistent step's device-side layer table and barrier words (made outside any stream capture: trace_decode_begin)
-static int b1_prepare(trace_ctx* c) {
-    if (!c->b1_layers) {
-        std::vector<DecodeB1Layer> h((size_t)c->NL);
-        for (int l = 0; l < c->NL; ++l) {
-            const LlmLayer& W = c->llm[l];
-            h[l] = DecodeB1Layer{W.wqkv_d, W.wo_d, W.wgu_d, W.wd_d, W.rms1, W.rms2, c->kcache + (size_t)l * c->layer_stride, c->vcache + (size_t)l * c->layer_stride};
-        }
-        void* p = nullptr;
-        HIPCHK(hipMalloc(&p, h.size() * sizeof(DecodeB1Layer)));
-        c->allocs.push_back(p);
-        HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(DecodeB1Layer), hipMemcpyHostToDevice));
-        c->b1_layers = (DecodeB1Layer*)p;
-        HIPCHK(hipMalloc(&p, decode_b1_bar_bytes() + 256));
-        c->allocs.push_back(p);
-        HIPCHK(hipMemset(p, 0, decode_b1_bar_bytes() + 256));
-        c->b1_bar = (unsigned int*)p;
-    }
-    return TRACE_OK;
-}
-// geometries the persistent kernel takes: every phase within one workgroup per CU, one 16-row tile per task except the gate|up product (others keep the launch-per-kernel step)
-static bool b1_persistent_fits(trace_ctx* c) {
-    DecodeB1Plan p[4];
-    skinny_plan_get(c->QKV, c->H, EPI_PARTIAL, 1, &p[0]); skinny_plan_get(c->H, c->H, EPI_PARTIAL, 1, &p[1]);
-    skinny_plan_get(2 * c->I, c->H, EPI_PARTIAL, 1, &p[2]); skinny_plan_get(c->H, c->I, EPI_PARTIAL, 1, &p[3]);
-    const int ncu = decode_b1_num_cus();
-    for (int i = 0; i < 4; ++i)
-        if (p[i].threads > 512 || p[i].grid > ncu || (p[i].NT != 1 && !(i == 2 && p[i].NT == 2))) return false;
-    return decode_nsplit(1) * c->NKV <= ncu && (c->H >> 3) <= 2 * p[0].threads && (c->H >> 3) <= 2 * p[2].threads;
-}
-static int decode_step_b1_persistent(trace_ctx* c, float* logits_out, hipStream_t s) {
-    const int H = c->H, I = c->I, QKV = c->QKV;
-    if (!c->b1_layers) return fail(TRACE_ERR_STATE, "persistent batch-1 step: tables not prepared (trace_decode_begin)");
-    DecodeB1Args a{};
-    a.layers = c->b1_layers; a.NL = c->NL;
-    skinny_plan_get(QKV, H, EPI_PARTIAL, 1, &a.pq); skinny_plan_get(H, H, EPI_PARTIAL, 1, &a.po);
-    skinny_plan_get(2 * I, H, EPI_PARTIAL, 1, &a.pg); skinny_plan_get(H, I, EPI_PARTIAL, 1, &a.pd);
-    a.H = H; a.I = I; a.QKV = QKV; a.NQ = c->NQ; a.NKV = c->NKV;
-    a.xa = c->dX; a.xb = c->dX2; a.ws = c->sk_ws; a.ws2 = c->sk_ws2; a.dO = c->dO; a.attn_ws = c->attn_ws; a.tickets = c->tickets;
-    a.cos_t = c->rope_cos; a.sin_t = c->rope_sin; a.slots = c->d_slots; a.pos = c->d_pos;
-    a.slot_stride = (long)c->slot_stride; a.kv_head_stride = (long)c->kv_head_stride; a.ctx_stride = c->ctx_pad;
-    a.nsplit = decode_nsplit(1); a.scale = 1.0f / sqrtf((float)c->HD); a.eps = c->c.rms_eps;
-    a.bar = c->b1_bar; a.err = c->b1_bar + decode_b1_bar_bytes() / 4;
-    a.prefetch = g_decode_b1_persistent - 1;
-    const int rc = launch_decode_b1_persistent(a, s);
-    if (rc != TRACE_OK) return fail(rc, "persistent batch-1 decode launch failed");
-    c->b1_used = 1;
-    // an even number of fused GEMVs per layer: the residual row is back in dX; the last layer's down partials + residual -> final norm -> heads
-    LCHK(launch_add_rmsnorm(c->sk_ws, a.pd.KS, c->dX, H, c->dX, H, c->final_norm, c->dH, H, 1, H, c->c.rms_eps, s));
-    return head_and_select(c, c->dH, 1, logits_out, s);
-}
-
 int g_decode_unfused = 0;   // RoPE + cache append as a kernel of its own before the decode attention: 0 = from batch 32 up (bit-identical to the fused
                             // prologue, 1 % faster per 64-sequence step, one launch more — which batch 1 would feel), 1 = always, 2 = never
                             // (trace_op_set_gemm_variant(120 + x), tools/decode_ab.py)
@@ -1265,8 +1172,6 @@ static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
     // 5-8 us of dependent round trips per GEMV): qkv -> attention (RoPE + cache append + attention) -> o -> [sum + residual
     // -> new residual, RMSNorm] -> gate|up -> [sum, SwiGLU] -> down -> [sum + residual, next layer's / the final RMSNorm].
     if (B > SKINNY_ROWS || (B >= g_decode_wide_min && !c->fp8)) return decode_step_wide(c, logits_out, s);      // (fp8 contexts: at most 64 rows, checked at begin)
-    if (B == 1 && g_decode_b1_persistent && g_decode_fuse_norm_rows >= 1 && g_decode_fuse_swiglu && !c->fp8 && c->HD == 128 && skinny_fused_norm_ok(QKV, H, B) &&
-        skinny_fused_norm_ok(2 * I, H, B) && b1_persistent_fits(c)) return decode_step_b1_persistent(c, logits_out, s);
     if (B <= g_decode_fuse_norm_rows && !c->fp8 && skinny_fused_norm_ok(QKV, H, B) && skinny_fused_norm_ok(2 * I, H, B)) return decode_step_fused(c, logits_out, s);
     const bool wo = c->fp8 && c->fp8_wonly;          // weight-only decode GEMVs: bf16 activations straight from dH / dO / dACT, no quantiser launches
     const bool f8 = c->fp8 && !wo;
@@ -1357,17 +1262,7 @@ extern "C" int trace_decode_begin(trace_ctx* c, const int32_t* slots, int B, con
     HIPCHK(hipMemsetAsync(c->d_out_ids, 0, (size_t)B * max_new * 4, s));
     const int32_t prm[3] = {max_new, eos, c->host_mode};
     HIPCHK(hipMemcpyAsync(c->d_params, prm, 12, hipMemcpyHostToDevice, s));
-    c->fed = 0; c->steps_done = 0; c->b1_used = 0;
-    if (B == 1 && g_decode_b1_persistent && !c->fp8) TRY(b1_prepare(c));
-    if (!c->wide_bar && g_decode_wide_chain && !c->fp8) {
-        void* p = nullptr;
-        HIPCHK(hipMalloc(&p, decode_wide_bar_bytes() + 256));
-        c->allocs.push_back(p);
-        HIPCHK(hipMemset(p, 0, decode_wide_bar_bytes() + 256));
-        c->wide_bar = (unsigned int*)p;
-    }
-    if (c->wide_bar) HIPCHK(hipMemsetAsync(c->wide_bar, 0, decode_wide_bar_bytes() + 16, s));
-    if (c->b1_bar) HIPCHK(hipMemsetAsync(c->b1_bar, 0, decode_b1_bar_bytes() + 16, s));          // barrier counters + error record: zeroed only here, while no decode kernel runs
+    c->fed = 0; c->steps_done = 0;
     if (forced) HIPCHK(hipMemcpyAsync(c->d_forced, forced, (size_t)B * max_new * 4, hipMemcpyHostToDevice, s));
     else HIPCHK(hipMemsetAsync(c->d_forced, 0xff, (size_t)B * max_new * 4, s));      // -1 = not forced
     // gather the prefill hidden rows of the chosen slots into dH, then head + select (no position advance)
@@ -1393,11 +1288,7 @@ extern "C" int trace_decode_steps(trace_ctx* c, int n, int use_graph, float* log
     if (!use_graph) {
         for (int i = 0; i < n; ++i) { c->step_in_call = steps_before + i; TRY(decode_step(c, logits_out, s)); }
     } else {
-        // one captured step per batch size; slot 0 = the persistent single-launch form of the batch-1 step (so that switching it off — trace_op_set_gemm_variant(900),
-        // the host's fallback after a barrier timeout — is not answered with the graph that holds it)
-        const int key = (c->B == 1 && g_decode_b1_persistent && !c->fp8 && c->b1_layers) ? 0 : c->B;
-        if (c->graph_chain[key] != g_decode_wide_chain && *(&c->graphs[key])) { hipGraphExecDestroy(c->graphs[key]); c->graphs[key] = nullptr; }      // captured under another setting of the chain switch
-        c->graph_chain[key] = g_decode_wide_chain;
+        const int key = c->B;
         hipGraphExec_t* slot_g = &c->graphs[key];
         if (!*slot_g) {
             hipGraph_t g = nullptr;
@@ -1446,17 +1337,7 @@ extern "C" int trace_decode_read(trace_ctx* c, int32_t* out_ids, int32_t* out_le
     if (out_ids) HIPCHK(hipMemcpyAsync(out_ids, c->d_out_ids, (size_t)c->B * c->max_new * 4, hipMemcpyDeviceToHost, s));
     if (out_len) HIPCHK(hipMemcpyAsync(out_len, c->d_out_len, c->B * 4, hipMemcpyDeviceToHost, s));
     if (heads) HIPCHK(hipMemcpyAsync(heads, c->d_heads, c->B * 4, hipMemcpyDeviceToHost, s));
-    unsigned int b1_err = 0;
-    if (c->b1_used == 1 && c->b1_bar) HIPCHK(hipMemcpyAsync(&b1_err, c->b1_bar + decode_b1_bar_bytes() / 4, 4, hipMemcpyDeviceToHost, s));
-    if (c->b1_used == 2 && c->wide_bar) HIPCHK(hipMemcpyAsync(&b1_err, c->wide_bar + decode_wide_bar_bytes() / 4, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (b1_err) {
-        unsigned int rec[4] = {0, 0, 0, 0};
-        hipMemcpy(rec, c->b1_used == 1 ? c->b1_bar + decode_b1_bar_bytes() / 4 : c->wide_bar + decode_wide_bar_bytes() / 4, 16, hipMemcpyDeviceToHost);
-        return fail(TRACE_ERR_STATE, "a persistent decode kernel gave up at a grid barrier (barrier " + std::to_string(rec[1]) + ", workgroup " + std::to_string(rec[2]) + ", after " +
-                                         std::to_string(rec[3]) + " polls; not all of its workgroups were resident?): ids are invalid");
-    }
-    if (false) return fail(TRACE_ERR_STATE, "a persistent decode kernel gave up at a grid barrier (not all of its workgroups were resident): ids are invalid");
     return TRACE_OK;
 }
 
@@ -1579,8 +1460,6 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 110 && variant < 120) { g_attn_pf_debug = variant - 110; return TRACE_OK; }
     if (variant >= 120 && variant <= 122) { g_decode_unfused = variant - 120; return TRACE_OK; }
     if (variant >= 130 && variant <= 137) { g_decode_gemm_tiled = variant - 130; return TRACE_OK; }
-        if (variant >= 990 && variant <= 992) { g_decode_wide_chain = variant - 990; return TRACE_OK; }
-    if (variant >= 900 && variant <= 989) { g_decode_b1_persistent = variant - 900; return TRACE_OK; }      // 0 off; x >= 1: DecodeB1Args::prefetch = x - 1 (bits 0-1 load batches ahead, 4 = the polling wave loads late, 8 / 16 = fence knock-outs, timing only)
     if (variant >= 760 && variant <= 764) { g_attn_decode_w3 = variant == 762 ? -1 : variant - 760; return TRACE_OK; }
     if (variant >= 780 && variant <= 799) { g_attn_decode_lds_pad = (variant - 780) * 8; return TRACE_OK; }
     if (variant >= 770 && variant <= 771) { g_attn_decode_nt = variant - 770; return TRACE_OK; }

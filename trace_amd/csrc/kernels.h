@@ -177,52 +177,6 @@ int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* kcache, bf16_t* vtcac
                        int ctx_stride, const int32_t* slots, const int32_t* pos, bf16_t* O, int ldo, float* ws, unsigned int* tickets, int B,
                        int nq, int nkv, int hd, int nsplit, float scale, int fuse_rope, const float* cos_t, const float* sin_t,
                        const float* qpart, int qks, hipStream_t s);   // qpart: fp32 partial rows [qks][SK_ROWS][ldq] instead of bf16 qkv
-// ---- the batch-1 decode step as one persistent launch (decode_b1.hip, round 6) ----
-struct DecodeB1Plan { int KS, chunk_units, T, WPT, ntiles, grid, threads, NT; };     // decode.hip's SkinnyPlan of one GEMV + its 16-row tiles per task (skinny_plan_get)
-struct DecodeB1Layer {
-    const bf16_t *wqkv, *wo, *wgu, *wd;      // decode tile copies
-    const bf16_t *rms1, *rms2;
-    bf16_t *kc, *vc;                         // this layer's K / V^T caches
-};
-struct DecodeB1Args {
-    const DecodeB1Layer* layers; int NL;     // device array
-    DecodeB1Plan pq, po, pg, pd;             // qkv, o, gate|up, down (B = 1, EPI_PARTIAL)
-    int H, I, QKV, NQ, NKV;
-    bf16_t *xa, *xb;                         // residual row (in: xa), ping-pong partner
-    float *ws, *ws2;                         // fp32 partial rows [ks][SK_ROWS][N], ping-pong; the last layer's down partials end in ws
-    bf16_t* dO;                              // attention output row [H]
-    float* attn_ws; unsigned int* tickets;
-    const float *cos_t, *sin_t;
-    const int32_t *slots, *pos;
-    long slot_stride, kv_head_stride; int ctx_stride;
-    int nsplit; float scale, eps;
-    unsigned* bar;                           // decode_b1_bar_bytes() of barrier words (zeroed by the launcher)
-    unsigned* err;                           // one sticky word: set when a barrier spin timed out
-    int prefetch;                            // weight / cache loads in front of the barriers: 0 none (A/B), 1 one batch, 2 two batches
-};
-size_t decode_b1_bar_bytes();
-int decode_b1_num_cus();
-int launch_decode_b1_persistent(const DecodeB1Args& a, hipStream_t s);
-void skinny_plan_get(int N, int K, int epi, int B, DecodeB1Plan* out);          // decode.hip
-
-// ---- the wide decode step's projection chain as one persistent launch per layer (decode_wide.hip, round 6) ----
-struct DecodeWideArgs {
-    const bf16_t* dO; bf16_t* dX; bf16_t* dH; bf16_t* dACT; bf16_t* dQKV; float* part;      // attention output, residual rows (in / out), normed rows, SwiGLU rows, q rows, partial rows
-    const bf16_t *wo, *wgu, *wd, *wqkv_next;      // decode tile copies (wqkv_next: the NEXT layer's)
-    const bf16_t *rms2, *rms_next;                // post-attention norm; the next layer's input norm (last layer: the final norm)
-    int B, H, I, QKV, NQ, NKV, ks_o, ks_d, ks_q;  // ks_*: gemm_partial_ks of the three split-K products
-    float eps;
-    int last;                                     // 1: stop after the second add + RMSNorm (no next layer)
-    bf16_t *kc_next, *vc_next;                    // the next layer's caches (qkv finish appends k / v)
-    long slot_stride, kv_head_stride; int ctx_stride;
-    const int32_t *slots, *pos;
-    const float *cos_t, *sin_t;
-    unsigned *bar, *err;                          // decode_wide_bar_bytes() of barrier words (zeroed by the launcher); one sticky error word
-    int prefetch;                                 // 1: weight tiles requested in front of the grid barriers
-};
-size_t decode_wide_bar_bytes();
-int launch_decode_wide_chain(const DecodeWideArgs& a, hipStream_t s);
-
 // heads: logits over [text V+1 | time Tv | score Sv] rows of Wh [NV_pad, H]; only tiles intersecting an active
 // head's range are computed.  part: [B, ntiles] (max,idx).  logits_out optional [B, NV] fp32 (masked -inf).
 int launch_head_logits(const bf16_t* X, int ldx, const bf16_t* Wh, int H, const int32_t* heads, int V, int Tv, int Sv,

@@ -433,20 +433,6 @@ class TraceEngine:
     def decode(self, slots: Sequence[int], heads: Sequence[int], max_new_tokens: int, eos: int = -1, use_graph: bool = True,
                forced: Optional[Sequence[Sequence[int]]] = None):
         """Stage 2 of generate(): the greedy loop over prefilled KV slots, on the current stream -> (ids per sequence, final heads)."""
-        try:
-            return self._decode(slots, heads, max_new_tokens, eos, use_graph, forced)
-        except _lib.TraceHipError as e:
-            # the persistent batch-1 step (decode_b1.hip) needs all of its workgroups resident; beside another process's persistent kernel on the same GPU its
-            # grid barrier can time out (bounded spins, an error instead of a hang).  The prefilled KV rows are intact: switch to the launch-per-kernel step, redo.
-            if "grid barrier" not in str(e):
-                raise
-            import warnings
-            warnings.warn("trace_amd: the persistent batch-1 decode step timed out at a grid barrier (GPU shared with another persistent kernel?); "
-                          "falling back to the launch-per-kernel step for this process")
-            _lib.check(self.lib.trace_op_set_gemm_variant(900))
-            return self._decode(slots, heads, max_new_tokens, eos, use_graph, forced)
-
-    def _decode(self, slots, heads, max_new_tokens, eos, use_graph, forced):
         self.decode_begin(list(slots), heads, max_new_tokens, eos, forced)
         if max_new_tokens > 1:
             if eos < 0:

@@ -385,7 +385,7 @@ def main():
     # host placement: each rank on the CPUs of its GPU's NUMA node (or an even slice of the allowed CPUs when the platform does not say): eight ranks
     # issue ~75 k launches per decode batch each, from two threads — they must not share cores
     place = tdist.bind_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-    from trace_amd.engine import TraceEngine
+    from trace_amd.engine import TraceEngine, ops
 
     cfg = tcfg.tiny(args.frames) if args.tiny else tcfg.trace_7b(args.frames)
     B, n_new = args.videos_per_step, args.max_new
@@ -399,6 +399,14 @@ def main():
     eng = TraceEngine(cfg, device=local, max_batch=2 * B if pipelined else B, max_ctx=(L + n_new + 63) // 64 * 64, max_frames=args.frames,
                       max_new_tokens=n_new, vit_batch_frames=args.vit_batch or TraceEngine.full_round_frames(cfg), llm_fp8=(args.fp8_scheme if args.fp8 else False),
                       dtype=el_dtype)
+    # the route of the GEMM shapes without a residual is SET here (gemm_w4.hip unless TRACE_GEMM_W4 says 0, read with C's atoi like the library would),
+    # so the kernel symbol printed in the line is the one this process asked for rather than a second reading of the environment
+    import re as _re
+    _w4 = os.environ.get("TRACE_GEMM_W4")
+    _m = _re.match(r"\s*[+-]?\d+", _w4) if _w4 is not None else None
+    use_w4 = True if _w4 is None else (int(_m.group()) != 0 if _m else False)
+    ops.use("f16" if args.dtype == "fp16" else "bf16")
+    ops.set_gemm_variant(530 + int(use_w4))
     t0 = time.perf_counter()
     eng.load_weights(synth.iter_weights(cfg, dtype=el_dtype, device=str(dev)))
     torch.cuda.synchronize()
@@ -558,7 +566,7 @@ def main():
             g_traffic = None                                    # the committed PMC pass measured another launch shape
         g_tf = (g_gf / g_ms) if g_ms > 0 else None             # GFLOP / ms = TFLOP/s
         # the persistent kernel the shapes without a residual run on: gemm_w4.hip (4 waves of 128x128) unless TRACE_GEMM_W4=0 sends them back to gemm_pers.hip
-        pers_sym = "gemm_pers_kernel" if os.environ.get("TRACE_GEMM_W4", "1") == "0" else "gemm_w4_kernel"
+        pers_sym = "gemm_w4_kernel" if use_w4 else "gemm_pers_kernel"
         fold_tag = stat_tag = ""                               # (rounds 3-4 tagged the LayerNorm-fold instantiations here; the fold left the product in round 5)
         line = {
             "metric": "videos/sec + decode tok/s, TRACE-7B 128-frame, 1/2/4/8 MI355X",

@@ -169,3 +169,27 @@ def test_containers_that_need_a_codec_say_so(tmp_path):
     if not has_decord:
         with pytest.raises(ImportError, match="decord"):
             process_video(str(w), _Proc(), "pad", 8)
+
+
+def test_a_reader_that_fails_while_parsing_leaves_no_descriptor_behind(tmp_path):
+    """A stream header cut short makes AviReader raise from inside its parse (struct.error): the map, the view and the file must be closed by then —
+    open_container() hands such files to decord, and a long evaluation would otherwise run out of descriptors."""
+    import os, struct
+    strh = b"strh" + struct.pack("<I", 56) + b"vids" + b"MJPG" + b"\0" * 8            # 'vids' header whose scale / rate fields lie past the end of the file
+    strl = b"LIST" + struct.pack("<I", 4 + len(strh)) + b"strl" + strh
+    hdrl = b"LIST" + struct.pack("<I", 4 + len(strl)) + b"hdrl" + strl
+    body = b"AVI " + hdrl
+    p = tmp_path / "cut.avi"
+    p.write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+    before = len(os.listdir("/proc/self/fd"))
+    for _ in range(4):
+        with pytest.raises((ValueError, struct.error)):
+            vio.AviReader(str(p))
+    assert len(os.listdir("/proc/self/fd")) == before
+    # a well-formed header with no frames takes the other exit (ValueError after the parse): closed as well
+    q = tmp_path / "empty.avi"
+    q.write_bytes(b"RIFF" + struct.pack("<I", 4) + b"AVI ")
+    for _ in range(4):
+        with pytest.raises((ValueError, vio.NeedsDecoder)):
+            vio.AviReader(str(q))
+    assert len(os.listdir("/proc/self/fd")) == before

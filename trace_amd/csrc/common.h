@@ -93,20 +93,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + idx;
 }
 
-// A pair of floats another kernel of the stream rewrites in place every layer (the ViT's LayerNorm-fold row statistics: 0.8 MB of (rstd, -mean rstd),
-// 3 MB of per-column-tile sums), moved with agent-scope atomics: the store is written through to memory, the load is served coherently across the
-// eight XCDs' L2s.  Round 4: with plain stores / loads these small, temporally cached buffers were the one thing in the tower that relied on the
-// kernel-boundary cache maintenance alone, and under a second queue's kernels one 256-row panel in ~4e5 launches saw the previous layer's values
-// (profiles/r04_pipeline_stress.txt).  The guide's rule: placement-independent hand-offs only.
-__device__ __forceinline__ float2 ld_agent_f2(const float* p) {
-    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
-}
-__device__ __forceinline__ void st_agent_f2(float* p, float a, float b) {
-    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 #define TRACE_OK 0
 #define TRACE_ERR_ARG (-1)
 #define TRACE_ERR_HIP (-2)

@@ -1059,8 +1059,12 @@ static int decode_nsplit(int B) { const int n = (40 + B / 2) / B; return n < 1 ?
 static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* logits_out, hipStream_t s);
 int g_decode_wide_min = 32;   // smallest batch that takes the wide (GEMM) decode step — ms per step, GEMV path vs wide step (r03_decode_gemm_ab.txt): 32 rows 5.39 / 5.30, 48 rows
                                  // 7.19 / 6.51, 64 rows 7.88 / 7.11; A/B: trace_op_set_gemm_variant(140 + x): 65 / 33 / 17 / 32
-int g_decode_gemm_tiled = 5;   // wide decode step, GemmArgs::w_tiled: bit 0 = weights from the decode tile copies (0 = row-major prefill copies), bit 2 = 4-stage
-                               // K-tile ring (A/B: trace_op_set_gemm_variant(130 + x))
+int g_decode_wide_fuse_qkv = 0; // wide decode step: 1 = the attention's fused prologue sums the qkv partial rows, applies RoPE and appends k / v itself (no qkv_finish launch;
+                               // same sums and roundings, bit-identical; A/B: trace_op_set_gemm_variant(144 + x))
+int g_decode_gemm_tiled = 21;  // wide decode step, GemmArgs::w_tiled: bit 0 = weights from the decode tile copies (0 = row-major prefill copies), bit 2 = 4-stage
+                               // K-tile ring, bit 4 = partial rows stored write-through (sc1): the consumer's kernel boundary has no dirty partial bytes to write back
+                               // (round 6, same bits: 10.41 -> 10.33 ms per 128-sequence step; bit 1 = nt weight DMA +2.7 %, bit 3 = nt partial stores +0.4 %: off)
+                               // (A/B: trace_op_set_gemm_variant(700 + x), 130 + x for the low three bits)
 
 // One decode step for SKINNY_ROWS < B <= SK_ROWS sequences.  A GEMV that parks its activations in LDS cannot hold more than 64 rows x 1024 k, and
 // its fp32 partial rows would grow with the row count; above 64 rows the four projections are small-M GEMMs on the MFMA tile kernel instead
@@ -1086,8 +1090,9 @@ static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
         bf16_t* kc = c->kcache + (size_t)l * c->layer_stride;
         bf16_t* vc = c->vcache + (size_t)l * c->layer_stride;
         TRY(pgemm(c->dH, H, W.wqkv, W.wqkv_d, H, QKV, H, ks_q));
-        LCHK(launch_qkv_finish(c->sk_ws, ks_q, QKV, c->dQKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots,
-                               c->d_pos, B, c->NQ, c->NKV, c->rope_cos, c->rope_sin, s));
+        const bool fq = g_decode_wide_fuse_qkv != 0;
+        if (!fq) LCHK(launch_qkv_finish(c->sk_ws, ks_q, QKV, c->dQKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots,
+                                        c->d_pos, B, c->NQ, c->NKV, c->rope_cos, c->rope_sin, s));
         // roofline probe (profile == 2, eager launches): HIP events around ONE launch of the step's dominant kernel — the layer-0 decode
         // attention, which streams the batch's whole KV cache of that layer
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1098,8 +1103,8 @@ static int decode_step_wide(trace_ctx* c, float* logits_out, hipStream_t s) {
         }
         if (e0) hipEventRecord(e0, s);
         LCHK(launch_attn_decode(c->dQKV, QKV, kc, vc, (long)c->slot_stride, (long)c->kv_head_stride, c->ctx_pad, c->d_slots, c->d_pos, c->dO,
-                                H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, decode_nsplit(B), 1.0f / sqrtf((float)HD), 0,
-                                nullptr, nullptr, nullptr, 0, s));
+                                H, c->attn_ws, c->tickets, B, c->NQ, c->NKV, HD, decode_nsplit(B), 1.0f / sqrtf((float)HD), fq ? 1 : 0,
+                                fq ? c->rope_cos : nullptr, fq ? c->rope_sin : nullptr, fq ? c->sk_ws : nullptr, fq ? ks_q : 0, s));
         if (e1) hipEventRecord(e1, s);
         TRY(pgemm(c->dO, H, W.wo, W.wo_d, H, H, H, ks_o));
         LCHK(launch_add_rmsnorm(c->sk_ws, ks_o, c->dX, H, c->dX, H, W.rms2, c->dH, H, B, H, c->c.rms_eps, s));
@@ -1471,6 +1476,7 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 170 && variant <= 174) { g_decode_fuse_norm_rows = variant - 170; return TRACE_OK; }
     if (variant >= 180 && variant <= 181) { g_decode_fuse_swiglu = variant - 180; return TRACE_OK; }
     if (variant >= 190 && variant <= 192) { g_attn_vit_big = variant - 190; return TRACE_OK; }   // ViT attention: 0 = the 4 x 32-row kernel, 1 = the 192-row kernel (4-stage ring), 2 = (3-stage ring)
+    if (variant >= 144 && variant <= 145) { g_decode_wide_fuse_qkv = variant - 144; return TRACE_OK; }
     if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : 32; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }
     if (variant >= 300 && variant < 364) { g_gemm_pers_opt = variant - 300; return TRACE_OK; }

@@ -386,7 +386,7 @@ int launch_glds(const GemmArgs& p, int epi, hipStream_t s) {
 
 int g_gemm_variant = 0;   // 0 = auto, 2 = 128^2 tiles, 3 = this file's 256^2 kernel, 4 = the loader-wave 256^2 kernel, 5 / 6 = the persistent one
                           // (gemm_pers.hip; 6 = static tile deal) — tests / microbench
-extern int g_gemm_pers_static;
+extern std::atomic<int> g_gemm_pers_static;   // (written on the launch path by both pipeline host threads, always with the value it holds: atomic so that this is defined behaviour)
 int g_gemm_w4 = -1;          // non-residual 256^2 shapes on gemm_w4.hip in auto mode: 1 / 0 (trace_op_set_gemm_variant(530 + x)); -1 = TRACE_GEMM_W4 from the environment, else on
 static bool gemm_w4_enabled() {
     static const int env = getenv("TRACE_GEMM_W4") ? (atoi(getenv("TRACE_GEMM_W4")) != 0) : 1;      // (read once; the pipeline's two host threads both come through here)
@@ -407,7 +407,7 @@ static int launch_dec(const GemmArgs& p, int nblk, hipStream_t s) {
 // 4 x 1 waves with a 5- / 3- / 4-stage ring (24 KB stages: half the partial-row bytes per product at the same number of workgroups, K loops twice as long;
 // the 3-stage form fits two workgroups per CU)
 int g_partial_cfg = 0;
-int g_partial_wgs = 0;      // workgroup target of gemm_partial_ks (0 = TRACE_PARTIAL_WGS from the environment, else 256; A/B: trace_op_set_gemm_variant(800 + n / 32))
+int g_partial_wgs = 0;      // workgroup target of gemm_partial_ks (0 = TRACE_PARTIAL_WGS from the environment, else 192; A/B: trace_op_set_gemm_variant(800 + n / 32))
 static int partial_bn() { return g_partial_cfg ? 64 : 128; }
 static int launch_partial(const GemmArgs& p, hipStream_t s) {
     const int bn = (p.w_tiled & 1) ? partial_bn() : 128;
@@ -425,10 +425,13 @@ static int launch_swiglu_tiled(const GemmArgs& p, hipStream_t s) {
     const int nblk = ((p.M + 127) / 128) * (p.N / 128);
     return (p.w_tiled & 4) ? launch_dec<EPI_SWIGLU, true, 4>(p, nblk, s) : launch_dec<EPI_SWIGLU, true, 2>(p, nblk, s);
 }
-// K-chunks for the partial-row GEMM (sized for one row panel): enough workgroups ((N / tile width) x ks) to put at least one on every CU, chunks of whole K-tiles, at least 4
-// K-tiles per chunk (a shorter K loop is all prologue).  TRACE_PARTIAL_WGS overrides the workgroup target (tuning runs).
+// K-chunks for the partial-row GEMM (sized for one row panel): enough workgroups ((N / tile width) x ks) to reach the target, chunks of whole K-tiles, at least 4
+// K-tiles per chunk (a shorter K loop is all prologue).  Target 192 since round 6 (was 256): the 7B qkv product (48 column tiles) is then cut in 4 chunks = 192 workgroups
+// in one round instead of 8 = 384 in one and a half, with half the partial-row bytes; o / down (32 tiles) keep 8 chunks = 256.  Wide step, ms per 128-sequence step at
+// ctx 1968 (profiles/r06_decode_splitk_ab.txt): target 256 11.01, 192 10.59, 160 10.41 (= 192), 128 (o / down at 4 chunks) 10.72, 96 10.96, 64 12.27.
+// TRACE_PARTIAL_WGS overrides the workgroup target (tuning runs).
 int gemm_partial_ks(int N, int K) {
-    static const int env_target = getenv("TRACE_PARTIAL_WGS") ? atoi(getenv("TRACE_PARTIAL_WGS")) : 256;
+    static const int env_target = getenv("TRACE_PARTIAL_WGS") ? atoi(getenv("TRACE_PARTIAL_WGS")) : 192;
     const int target = g_partial_wgs > 0 ? g_partial_wgs : env_target;
     const int tiles = N / partial_bn(), nk = K / BK;
     int ks = 1;

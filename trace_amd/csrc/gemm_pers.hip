@@ -560,7 +560,7 @@ void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
 }  // namespace
 
 int g_gemm_pers_opt = 0;           // A/B builds of the K loop (trace_op_set_gemm_variant(300 + opt))
-int g_gemm_pers_static = 0;        // 1: tiles dealt round-robin instead of by ticket (A/B runs)
+std::atomic<int> g_gemm_pers_static{0};        // 1: tiles dealt round-robin instead of by ticket (A/B runs)
 int g_gemm_pers_walk = 0;          // every route (trace_op_set_gemm_variant(500 + w)): 0 = tickets, atomic re-arm; 1 = static deal
 
 int g_gemm_pers_grid_cap = 0;      // tuning knob (trace_op_set_gemm_variant(1000 + n)); streams carry their own cap: gemm_pers_set_cap.  > 0: at most this many workgroups per launch (a stream confined to part of the CUs by a CU mask: the

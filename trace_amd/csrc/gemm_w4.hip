@@ -386,24 +386,26 @@ __global__ __launch_bounds__(NTHR) void gemm_w4_kernel(GemmArgs p, int* ctr, int
 }
 
 template <int EPI, int OPT>
-void launch_opt(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
+bool launch_opt(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
     static LdsGrant grant;
-    (void)grant_dynamic_lds(grant, reinterpret_cast<const void*>(gemm_w4_kernel<EPI, OPT>), LDS_BYTES);
+    if (!grant_dynamic_lds(grant, reinterpret_cast<const void*>(gemm_w4_kernel<EPI, OPT>), LDS_BYTES)) return false;      // refused (or a device id the grant table does not hold)
     hipLaunchKernelGGL((gemm_w4_kernel<EPI, OPT>), dim3(nblk), dim3(NTHR), LDS_BYTES, s, p, ctr, dynamic);
+    return true;
 }
 template <int EPI>
-void launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
+bool launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
     switch (p.opt & 5) {          // A/B builds (trace_op_set_gemm_variant(540 + opt)): bit 0 = without the re-aligning barrier, bit 2 = with the L2 touches of the A panel
-        case 1: launch_opt<EPI, 1>(p, nblk, dynamic, ctr, s); break;
-        case 4: launch_opt<EPI, 4>(p, nblk, dynamic, ctr, s); break;
-        case 5: launch_opt<EPI, 5>(p, nblk, dynamic, ctr, s); break;
-        default: launch_opt<EPI, 0>(p, nblk, dynamic, ctr, s); break;
+        case 1: return launch_opt<EPI, 1>(p, nblk, dynamic, ctr, s);
+        case 4: return launch_opt<EPI, 4>(p, nblk, dynamic, ctr, s);
+        case 5: return launch_opt<EPI, 5>(p, nblk, dynamic, ctr, s);
+        default: return launch_opt<EPI, 0>(p, nblk, dynamic, ctr, s);
     }
 }
 
 }  // namespace
 
-extern int g_gemm_pers_static, g_gemm_pers_walk;
+extern std::atomic<int> g_gemm_pers_static;
+extern int g_gemm_pers_walk;
 int g_gemm_w4_opt = 0;             // A/B builds of this kernel (trace_op_set_gemm_variant(540 + opt)): bit 0 = without the re-aligning barrier, bit 2 = with the L2 touches of the A panel
 
 // TRACE_ERR_STATE: no ticket counters for this stream and none can be made now (capturing): the caller falls back
@@ -419,12 +421,14 @@ int launch_gemm_w4(const GemmArgs& p0, int epi, hipStream_t s) {
     const int rc = gemm_pers_plan(s, total, &ctr, &nblk);
     if (rc != TRACE_OK) return rc;
     const int dynamic = (g_gemm_pers_static || g_gemm_pers_walk == 1) ? 0 : 1;
+    bool granted = false;
     switch (epi) {
-        case EPI_NONE: launch_one<EPI_NONE>(p, nblk, dynamic, ctr, s); break;
-        case EPI_RESIDUAL: launch_one<EPI_RESIDUAL>(p, nblk, dynamic, ctr, s); break;
-        case EPI_QUICKGELU: launch_one<EPI_QUICKGELU>(p, nblk, dynamic, ctr, s); break;
-        case EPI_SWIGLU: launch_one<EPI_SWIGLU>(p, nblk, dynamic, ctr, s); break;
+        case EPI_NONE: granted = launch_one<EPI_NONE>(p, nblk, dynamic, ctr, s); break;
+        case EPI_RESIDUAL: granted = launch_one<EPI_RESIDUAL>(p, nblk, dynamic, ctr, s); break;
+        case EPI_QUICKGELU: granted = launch_one<EPI_QUICKGELU>(p, nblk, dynamic, ctr, s); break;
+        case EPI_SWIGLU: granted = launch_one<EPI_SWIGLU>(p, nblk, dynamic, ctr, s); break;
         default: return TRACE_ERR_ARG;
     }
+    if (!granted) return TRACE_ERR_HIP;
     return hipGetLastError() == hipSuccess ? TRACE_OK : TRACE_ERR_HIP;
 }

@@ -199,59 +199,63 @@ class AviReader:
             buf.release(); data.close(); self._file.close()
             raise ValueError(f"{path}: not a RIFF AVI file")
         self._data = data
-        self._frames: List[Tuple[int, int]] = []
-        self._fps = 0.0
-        self._handler = b""
-        self._compression = b""
-        self.width = self.height = 0
-        self._bits = 24
-        usec = 0
+        try:
+            self._frames: List[Tuple[int, int]] = []
+            self._fps = 0.0
+            self._handler = b""
+            self._compression = b""
+            self.width = self.height = 0
+            self._bits = 24
+            usec = 0
 
-        def movi(start: int, end: int) -> None:
-            for c2, p2, n2 in _riff_chunks(buf, start, end):
-                if c2 == b"LIST" and bytes(buf[p2:p2 + 4]) == b"rec ":
-                    movi(p2 + 4, min(p2 + n2, end))                # OpenDML interleave groups
-                elif c2[2:] in (b"dc", b"db"):
-                    if n2 > 0:
-                        self._frames.append((p2, n2))
-                    elif self._frames:
-                        self._frames.append(self._frames[-1])      # dropped frame: the previous picture stays up
-        # the first RIFF chunk ('AVI ') holds the headers and the first 'movi' list; OpenDML files continue in 'RIFF....AVIX' chunks of further 'movi' lists
-        segs, pos = [], 0
-        while pos + 12 <= len(data) and data[pos:pos + 4] == b"RIFF":
-            size = struct.unpack_from("<I", buf, pos + 4)[0]
-            segs.append((bytes(buf[pos + 8:pos + 12]), pos + 12, min(pos + 8 + size, len(data))))
-            pos += 8 + size + (size & 1)
-        for form, s0, s1 in segs[1:]:
-            if form != b"AVIX":
-                segs = segs[:1]
-                break
-        for cc, p, n in (x for form, s0, s1 in segs for x in _riff_chunks(buf, s0, s1)):
-            if cc != b"LIST":
-                continue
-            kind = bytes(buf[p:p + 4])
-            if kind == b"hdrl":
-                for c2, p2, n2 in _riff_chunks(buf, p + 4, p + n):
-                    if c2 == b"avih":
-                        usec = struct.unpack_from("<I", buf, p2)[0]
-                    elif c2 == b"LIST" and bytes(buf[p2:p2 + 4]) == b"strl":
-                        is_video = False
-                        for c3, p3, n3 in _riff_chunks(buf, p2 + 4, p2 + n2):
-                            if c3 == b"strh":
-                                is_video = bytes(buf[p3:p3 + 4]) == b"vids"
-                                if is_video and not self._handler:
-                                    self._handler = bytes(buf[p3 + 4:p3 + 8])
-                                    scale, rate = struct.unpack_from("<II", buf, p3 + 20)
-                                    if scale and rate:
-                                        self._fps = rate / scale
-                            elif c3 == b"strf" and is_video and not self.width:
-                                self.width, h = struct.unpack_from("<ii", buf, p3 + 4)
-                                self.height = abs(h)
-                                self._flip = h > 0                 # positive height = bottom-up rows (DIB)
-                                self._bits = struct.unpack_from("<H", buf, p3 + 14)[0]
-                                self._compression = bytes(buf[p3 + 16:p3 + 20])
-            elif kind == b"movi":
-                movi(p + 4, min(p + n, len(data)))
+            def movi(start: int, end: int) -> None:
+                for c2, p2, n2 in _riff_chunks(buf, start, end):
+                    if c2 == b"LIST" and bytes(buf[p2:p2 + 4]) == b"rec ":
+                        movi(p2 + 4, min(p2 + n2, end))                # OpenDML interleave groups
+                    elif c2[2:] in (b"dc", b"db"):
+                        if n2 > 0:
+                            self._frames.append((p2, n2))
+                        elif self._frames:
+                            self._frames.append(self._frames[-1])      # dropped frame: the previous picture stays up
+            # the first RIFF chunk ('AVI ') holds the headers and the first 'movi' list; OpenDML files continue in 'RIFF....AVIX' chunks of further 'movi' lists
+            segs, pos = [], 0
+            while pos + 12 <= len(data) and data[pos:pos + 4] == b"RIFF":
+                size = struct.unpack_from("<I", buf, pos + 4)[0]
+                segs.append((bytes(buf[pos + 8:pos + 12]), pos + 12, min(pos + 8 + size, len(data))))
+                pos += 8 + size + (size & 1)
+            for form, s0, s1 in segs[1:]:
+                if form != b"AVIX":
+                    segs = segs[:1]
+                    break
+            for cc, p, n in (x for form, s0, s1 in segs for x in _riff_chunks(buf, s0, s1)):
+                if cc != b"LIST":
+                    continue
+                kind = bytes(buf[p:p + 4])
+                if kind == b"hdrl":
+                    for c2, p2, n2 in _riff_chunks(buf, p + 4, p + n):
+                        if c2 == b"avih":
+                            usec = struct.unpack_from("<I", buf, p2)[0]
+                        elif c2 == b"LIST" and bytes(buf[p2:p2 + 4]) == b"strl":
+                            is_video = False
+                            for c3, p3, n3 in _riff_chunks(buf, p2 + 4, p2 + n2):
+                                if c3 == b"strh":
+                                    is_video = bytes(buf[p3:p3 + 4]) == b"vids"
+                                    if is_video and not self._handler:
+                                        self._handler = bytes(buf[p3 + 4:p3 + 8])
+                                        scale, rate = struct.unpack_from("<II", buf, p3 + 20)
+                                        if scale and rate:
+                                            self._fps = rate / scale
+                                elif c3 == b"strf" and is_video and not self.width:
+                                    self.width, h = struct.unpack_from("<ii", buf, p3 + 4)
+                                    self.height = abs(h)
+                                    self._flip = h > 0                 # positive height = bottom-up rows (DIB)
+                                    self._bits = struct.unpack_from("<H", buf, p3 + 14)[0]
+                                    self._compression = bytes(buf[p3 + 16:p3 + 20])
+                elif kind == b"movi":
+                    movi(p + 4, min(p + n, len(data)))
+        except Exception:                                  # a parse error must not leave the map, the view or the descriptor behind (the caller falls back to decord)
+            buf.release(); self.close()
+            raise
         buf.release()
         if not self._fps and usec:
             self._fps = 1e6 / usec
@@ -263,6 +267,7 @@ class AviReader:
             raise NeedsDecoder(f"{path}: video stream is coded as {self._compression!r} / {self._handler!r}: only streams of independent frames (Motion-JPEG, "
                              "uncompressed 24-bit) are decoded here; transcode inter-coded video (H.264, ...) with `ffmpeg -i in.mp4 out.y4m`, or install decord")
         if not self._frames or self.width < 1 or self.height < 1 or self._fps <= 0:
+            self.close()
             raise ValueError(f"{path}: no video frames / bad stream header")
 
     def __len__(self) -> int:

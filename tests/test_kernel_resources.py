@@ -95,6 +95,37 @@ def test_attention_kernels_keep_their_occupancy(res):
         assert v["ScratchSize"] == 0 and v["Occupancy"] >= 3, (k, v)
 
 
+def test_vit_attention_tile_loop_touches_no_scratch(res, tmp_path):
+    """attn_vit_big_kernel (the shipped ViT attention): three waves per SIMD, and NOTHING reloaded from scratch inside its key-tile loop.  A scratch reload is a
+    VMEM operation; hipcc waits for it with s_waitcnt vmcnt(0), which in this loop also waits for the K / V pieces of the NEXT tiles the wave has just requested —
+    rounds 5's build did exactly that (two LDS offsets reloaded behind the LDS-DMA issue of every tile; found in the ISA in round 6 and removed by moving the pieces
+    to buffer descriptors: 8 address registers -> 4).  The prologue / epilogue may keep a few dwords in scratch."""
+    for k, v in _pick(res["attn"], "attn_vit_big_kernel").items():
+        assert v["VGPRs"] <= 168 and v["Occupancy"] >= 3 and v["ScratchSize"] <= 32, (k, v)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = str(tmp_path / "attn.s")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", os.path.join(CSRC, "attn.hip"), "-I", CSRC, "-o", out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    isa = open(out).read()
+    seen = 0
+    for m in re.finditer(r"^(_ZN\S*attn_vit_big_kernel\S*):\s.*?^\.Lfunc_end", isa, re.S | re.M):
+        body = m.group(0).splitlines()
+        bars = [i for i, l in enumerate(body) if "s_barrier" in l]
+        assert len(bars) == 1, (m.group(1), bars)                       # the one barrier per key tile
+        # the tile loop = the blocks marked "in Loop" / "Loop Header" around that barrier
+        lo = max(i for i in range(bars[0]) if body[i].startswith(".LBB") and "Loop Header" in body[i])
+        head = "Header=" + body[lo].split(":")[0].lstrip(".L")
+        mine = [i for i, l in enumerate(body) if l.startswith(".LBB") and "in Loop" in l and head in l]
+        lo, hi = min(lo, min(mine)), max(mine)                           # (hipcc places some of the loop's blocks in front of its header)
+        end = next(i for i in range(hi + 1, len(body)) if body[i].startswith(".LBB"))
+        loop = body[lo:end]
+        assert sum("v_mfma" in l for l in loop) == 54, m.group(1)          # (the whole tile body is inside)
+        assert not [l for l in loop if "scratch_" in l], (m.group(1), [l.strip() for l in loop if "scratch_" in l][:4])
+        seen += 1
+    assert seen == 2                                                    # the 3-stage (shipped) and 4-stage ring instantiations
+
+
 def test_decode_gemv_does_not_spill(res):
     for k, v in _pick(res["decode"], "skinny_lds_kernel").items():
         assert v["ScratchSize"] == 0, (k, v)

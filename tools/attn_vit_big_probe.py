@@ -13,12 +13,14 @@ def timed(fn, n=6):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 names = {190: "4 x 32-row kernel", 191: "192-row kernel, 4-stage ring", 192: "192-row kernel, 3-stage ring"}
-KO = {110: "full kernel", 111: "no K/V loads after the first tiles", 112: "no tile math (loads + barriers only)"}
+KO = {110: "full kernel", 111: "no K/V loads after the first tiles", 112: "no tile math (loads + barriers only)", 113: "without the trailing key on the VALU",
+      114: "without the output stores", 115: "without trailing key, output stores and Q fetch"}
 if "--knockout" in sys.argv:          # where the time goes: knock-out runs of both kernels (trace_op_set_gemm_variant(111 / 112))
     q, k, v = rnd(170, 577, 16, 64), rnd(170, 577, 16, 64), rnd(170, 577, 16, 64)
     for var in (190, 191, 192):
         ops.set_gemm_variant(var)
         for ko, kn in KO.items():
+            if ko > 112 and var != 192: continue          # (the round-6 knock-outs exist in the 192-row kernel only)
             ops.set_gemm_variant(ko)
             print(f"frames=170 {names[var]}, {kn}: {timed(lambda: ops.attention(q, k, v, False, 0.125)):.1f} us", flush=True)
     ops.set_gemm_variant(110); ops.set_gemm_variant(192)

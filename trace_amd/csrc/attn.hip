@@ -592,6 +592,13 @@ __device__ __forceinline__ void tr_wait(u32x2_t (&v)[4][2]) {
                  :: "memory");
 }
 
+// v_permlane16_swap: rows (16 lanes) 1 and 3 of a <-> rows 0 and 2 of b
+__device__ __forceinline__ void swap16_rows(uint32_t& a, uint32_t& b) {
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    const u2_t r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+
 template <int NST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_vit_big_kernel(AttnArgs a) {
     constexpr int HD = 64;
@@ -716,21 +723,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int vkey = (pi & 3) * 16 + (lane >> 2);
         vsrc[j] = ((uint32_t)vkey * (uint32_t)a.vr_rs + (uint32_t)((pi >> 2) * 32 + (((lane & 3) ^ (((vkey >> 2) & 1) << 1)) << 3))) * 2u;
     }
-    const size_t kstep = (size_t)BKV * a.k_rs * 2, vstep = (size_t)BKV * a.vr_rs * 2;      // bytes per key tile
+    // (round 6: through buffer descriptors — scalar head base + the per-lane 32-bit piece offset + a SCALAR tile offset: the global_load_lds form kept the four
+    // offsets as zero-extended 64-bit pairs, and the registers that cost were reloaded from scratch inside the tile loop behind an s_waitcnt vmcnt(0), i.e. every
+    // tile waited for the K / V pieces it had just requested)
+    const uint32_t kstep = (uint32_t)BKV * (uint32_t)a.k_rs * 2u, vstep = (uint32_t)BKV * (uint32_t)a.vr_rs * 2u;      // bytes per key tile
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kbase), 0, (int)((uint32_t)a.nkv_rows * (uint32_t)a.k_rs * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, (int)((uint32_t)a.nkv_rows * (uint32_t)a.vr_rs * 2u), 0x00020000);
     auto issue = [&](int t, int stage) {
         char* st = smem + stage * BSTAGE + (2 * wid) * 1024;
-        const char* kt_ = reinterpret_cast<const char*>(kbase) + (size_t)t * kstep;
-        const char* vt_ = reinterpret_cast<const char*>(vbase) + (size_t)t * vstep;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            glds16(reinterpret_cast<const bf16_t*>(kt_ + (size_t)ksrc[j]), st + j * 1024);
-            glds16(reinterpret_cast<const bf16_t*>(vt_ + (size_t)vsrc[j]), st + 8192 + j * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(st + j * 1024), 16, ksrc[j], t * kstep, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (__attribute__((address_space(3))) void*)(st + 8192 + j * 1024), 16, vsrc[j], t * vstep, 0, 0);
         }
     };
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
         if (t < nt) issue(t, t);
 
+    // ---- the first trailing key's K row and V row are requested BEFORE the Q fragments (round 6): behind them they cost every workgroup a second, fully exposed
+    //      memory round trip in front of its first tile (knock-out of the trailing key: 366 -> 344 us, profiles/r06_attn_big_knockouts.txt)
+    const bool skip_rem = a.dbg == 3 || a.dbg == 5;
+    uint4 rk0[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+    uint2 rv0[4] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
+    if (rem > 0 && !skip_rem) {
+        const bf16_t* kp = kbase + (size_t)nkv_main * a.k_rs + g * 8;
+        const bf16_t* vp = vbase + (size_t)nkv_main * a.vr_rs + 4 * g;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) rk0[ks] = *reinterpret_cast<const uint4*>(kp + ks * 32);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) rv0[dt] = *reinterpret_cast<const uint2*>(vp + dt * 16);
+    }
     // ---- Q fragments, scaled once: q' = bf16(q * scale * log2 e)
     bf16x8_t qf[3][2];
 #pragma unroll
@@ -738,7 +761,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const bf16_t* qp = a.Q + (size_t)b * a.q_bs + (size_t)kvh * a.q_hs + (size_t)(q0 + i * 16 + r16) * a.q_rs + g * 8;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const uint4 q4 = *reinterpret_cast<const uint4*>(qp + ks * 32);
+            const uint4 q4 = a.dbg == 5 ? make_uint4(0x3c003c00u + lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u) : *reinterpret_cast<const uint4*>(qp + ks * 32);
             union { bf16x8_t v; uint32_t u[4]; } o;
             o.u[0] = pack2bf(bflo(q4.x) * sc, bfhi(q4.x) * sc);
             o.u[1] = pack2bf(bflo(q4.y) * sc, bfhi(q4.y) * sc);
@@ -759,7 +782,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     bool first = true;
 
     // ---- trailing keys (nkv % 64 of them) on the VALU: they initialise the softmax state
-    for (int jt = 0; jt < rem; ++jt) {
+    // (a.dbg 3 / 4 / 5, timing only — what a persistent form could hide at most: 3 = without these trailing keys, 4 = without the output stores, 5 = both and
+    // the Q fragments not fetched)
+    // The FIRST trailing key opens the softmax state, and for it everything but the three dot products is known: reference m = its own score, p = 2^0 = 1, so
+    // l = 1 and O = its V row (round 6; the general update below spent ~250 VALU instructions per wave on it — one key for the price of a 64-key tile's VALU work,
+    // in a kernel whose VALU pipe, not its matrix pipe, is the busy one: knock-out of the trailing key 336 -> 307 us).  The dots run on v_dot2.
+    int jt0 = 0;
+    if (rem > 0 && !skip_rem) {
+        float vf[4][4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            vf[dt][0] = bflo(rv0[dt].x); vf[dt][1] = bfhi(rv0[dt].x); vf[dt][2] = bflo(rv0[dt].y); vf[dt][3] = bfhi(rv0[dt].y);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float dot = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                union { bf16x8_t v; uint32_t u[4]; } qq;
+                qq.v = qf[i][ks];
+                dot = dot2_el(qq.u[0], rk0[ks].x, dot); dot = dot2_el(qq.u[1], rk0[ks].y, dot);
+                dot = dot2_el(qq.u[2], rk0[ks].z, dot); dot = dot2_el(qq.u[3], rk0[ks].w, dot);
+            }
+            dot += __shfl_xor(dot, 16, 64);                      // the four lanes (q, g = 0..3) hold 16 d each
+            dot += __shfl_xor(dot, 32, 64);
+            m[i] = dot;
+            lacc[i] = f32x4_t{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt][i] = f32x4_t{vf[dt][0], vf[dt][1], vf[dt][2], vf[dt][3]};
+        }
+        first = false;
+        jt0 = 1;
+    }
+    for (int jt = jt0; jt < (skip_rem ? 0 : rem); ++jt) {
         const int kv = nkv_main + jt;
         const bf16_t* kp = kbase + (size_t)kv * a.k_rs + g * 8;
         uint32_t ku[2][4];
@@ -909,16 +964,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         stage_n = stage_n + 1 == NST ? 0 : stage_n + 1;
     }
 
+    if ((a.dbg == 4 || a.dbg == 5) && lacc[0][0] != 12345.678f) return;          // (the condition keeps the accumulators live)
+    // Output rows, 16 bytes per store (round 6; the same bytes as the 8-byte form): lane (q, g) holds d = dt 16 + 4 g .. + 3 of query row q for every d-tile dt.  One
+    // v_permlane16_swap per register of a d-tile pair (dt, dt + 1) hands the dt piece of the odd-g lane to its even-g neighbour and the dt + 1 piece of the even-g lane
+    // to the odd one: even g then holds d = dt 16 + 4 g .. + 7, odd g holds d = (dt + 1) 16 + 4 (g - 1) .. + 7 — 6 stores per lane instead of 12.  The store tail is
+    // issue-bound, not bandwidth-bound (knock-out of the stores: 366 -> 334 us).
+    const bool wide = (a.o_rs % 8 == 0) && (a.o_hs % 8 == 0) && (a.o_bs % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.O) & 15) == 0);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float inv = 1.f / lacc[i][0];
-        bf16_t* op = a.O + (size_t)b * a.o_bs + (size_t)kvh * a.o_hs + (size_t)(q0 + i * 16 + r16) * a.o_rs + 4 * g;
+        bf16_t* orow = a.O + (size_t)b * a.o_bs + (size_t)kvh * a.o_hs + (size_t)(q0 + i * 16 + r16) * a.o_rs;
+        uint2 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            uint2 o;
-            o.x = pack2bf(oacc[dt][i][0] * inv, oacc[dt][i][1] * inv);
-            o.y = pack2bf(oacc[dt][i][2] * inv, oacc[dt][i][3] * inv);
-            *reinterpret_cast<uint2*>(op + dt * 16) = o;
+            o[dt].x = pack2bf(oacc[dt][i][0] * inv, oacc[dt][i][1] * inv);
+            o[dt].y = pack2bf(oacc[dt][i][2] * inv, oacc[dt][i][3] * inv);
+        }
+        if (wide) {
+#pragma unroll
+            for (int dp = 0; dp < 4; dp += 2) {
+                swap16_rows(o[dp].x, o[dp + 1].x);
+                swap16_rows(o[dp].y, o[dp + 1].y);
+                const int d0 = (g & 1) ? (dp + 1) * 16 + 4 * (g - 1) : dp * 16 + 4 * g;
+                *reinterpret_cast<uint4*>(orow + d0) = make_uint4(o[dp].x, o[dp].y, o[dp + 1].x, o[dp + 1].y);
+            }
+        } else {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<uint2*>(orow + 4 * g + dt * 16) = o[dt];
         }
     }
 }

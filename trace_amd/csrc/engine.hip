@@ -1054,7 +1054,8 @@ static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* l
 // decode attention context split: ~256-320 workgroups (8 kv heads x B x nsplit) fill the CUs; more splits only add
 // partial-result traffic and ticket latency (measured, ctx 2100: B=1 16 splits 10.4 us, B=4 8 -> 13 us, B=16 2 -> 26 us,
 // B=32 1 -> 45 us; B=32 with 16 splits: 79 us)
-static int decode_nsplit(int B) { const int n = (40 + B / 2) / B; return n < 1 ? 1 : n > 16 ? 16 : n; }
+int g_attn_decode_nsplit = 0;   // A/B: context splits of the decode attention forced to this number (0 = the rule below; trace_op_set_gemm_variant(850 + n))
+static int decode_nsplit(int B) { if (g_attn_decode_nsplit > 0) return g_attn_decode_nsplit; const int n = (40 + B / 2) / B; return n < 1 ? 1 : n > 16 ? 16 : n; }
 
 static int head_and_select(trace_ctx* c, const bf16_t* xn, int advance, float* logits_out, hipStream_t s);
 int g_decode_wide_min = 32;   // smallest batch that takes the wide (GEMM) decode step — ms per step, GEMV path vs wide step (r03_decode_gemm_ab.txt): 32 rows 5.39 / 5.30, 48 rows
@@ -1476,6 +1477,7 @@ extern "C" int trace_op_set_gemm_variant(int variant) {
     if (variant >= 170 && variant <= 174) { g_decode_fuse_norm_rows = variant - 170; return TRACE_OK; }
     if (variant >= 180 && variant <= 181) { g_decode_fuse_swiglu = variant - 180; return TRACE_OK; }
     if (variant >= 190 && variant <= 192) { g_attn_vit_big = variant - 190; return TRACE_OK; }   // ViT attention: 0 = the 4 x 32-row kernel, 1 = the 192-row kernel (4-stage ring), 2 = (3-stage ring)
+    if (variant >= 850 && variant <= 866) { g_attn_decode_nsplit = variant - 850; return TRACE_OK; }
     if (variant >= 144 && variant <= 145) { g_decode_wide_fuse_qkv = variant - 144; return TRACE_OK; }
     if (variant >= 140 && variant <= 143) { g_decode_wide_min = variant == 140 ? SKINNY_ROWS + 1 : variant == 141 ? 33 : variant == 142 ? 17 : 32; return TRACE_OK; }
     if (variant >= 200 && variant < 210) { g_skinny_debug = variant - 200; return TRACE_OK; }

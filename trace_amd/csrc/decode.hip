@@ -577,27 +577,28 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_decode_kernel(const bf16_t* _
     const int prow = (i >> 2) * 8 + (i & 3);          // + 4 t: position (within the block) of A-row i of S tile t
     const u32x4_t zero4 = {0u, 0u, 0u, 0u};
     u32x4_t kr[2][4], vr[8];
+    // The loads are UNCONDITIONAL (round 6): a block's 32 positions lie below round_up(end, 32) <= ctx_stride, i.e. inside the slot's rows, and what a position >= end
+    // (or the newest row, spliced from LDS below) holds never counts — its score is masked, its p is 0, and the caches hold finite values only (see above).  With
+    // per-lane predicates the loads sat in exec-masked branches, the number in flight was unknown at the joins, and hipcc put s_waitcnt vmcnt(0) in front of the
+    // QK MFMAs: every wave waited for the V^T block it had requested a moment earlier instead of computing S under it (ISA read, round 6; measured against the
+    // predicated form in profiles/r06_decode_attn_waits_ab.txt: equal at batch 128, where 12 waves per CU cover the latency anyway, -1.4 % per step at batch 16).
     auto load_k = [&](int it) {
         const int P0 = beg + it * 32;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int p = P0 + prow + 4 * t;
-            const bool ok = p < end && !(fuse_rope && p == p_new);
             const bf16_t* src = kb + (size_t)p * HD + g * 16;
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-                kr[t][s4] = ok ? ldc(src + (s4 >> 1) * 64 + (s4 & 1) * 8) : zero4;
+            for (int s4 = 0; s4 < 4; ++s4) kr[t][s4] = ldc(src + (s4 >> 1) * 64 + (s4 & 1) * 8);
         }
     };
     auto load_v = [&](int it) {
         const int P0 = beg + it * 32;
-        const bool vok = P0 + g * 8 < end;
         // (dbg == 8, timing only: the same 8 KB read as ONE contiguous block [128 d][32 positions] — what a position-blocked V^T cache would give)
         const bf16_t* vsrc = dbg == 8 ? vb + ((size_t)(P0 >> 5) * HD + i) * 32 + g * 8 : vb + (size_t)i * ctx_stride + P0 + g * 8;
         const size_t vstep = dbg == 8 ? 16 * 32 : (size_t)16 * ctx_stride;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt)
-            vr[dt] = vok ? ldc(vsrc + dt * vstep) : zero4;
+        for (int dt = 0; dt < 8; ++dt) vr[dt] = ldc(vsrc + dt * vstep);
     };
     if (wid < nit) { load_k(wid); load_v(wid); }      // cache blocks start streaming before anything else
 
@@ -661,9 +662,14 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_decode_kernel(const bf16_t* _
 
     // single register set, refilled as soon as the MFMAs that read it have issued: the next block's K streams in
     // during this block's softmax + PV, its V^T during the next block's QK (3 waves/SIMD cover the rest)
-    for (int it = wid; it < nit; it += NW) {
+    // The loop is in two parts (round 6): a steady part whose every iteration requests the next block WITHOUT a condition, and the wave's last block, which
+    // requests nothing.  With `if (it + NW < nit)` around the requests the wait-count pass saw an unknown number of loads in flight at the loop header and waited
+    // for all of them (s_waitcnt vmcnt(0)) in front of the QK MFMAs — the V^T block just requested included; now it waits for the K block only (vmcnt(8)).
+    auto block = [&](const int it, auto prefetch) {
         const int P0 = beg + it * 32;
-        if (fuse_rope && p_new >= P0 && p_new < P0 + 32) {          // wave-uniform: splice the newest k / v (parked in LDS)
+        // (the newest position is the split's last one: it can only lie in a wave's LAST block, so the steady iterations carry no splice — its partial register
+        // writes and LDS reads at a join were the other thing that made the wait-count pass give up and wait for everything)
+        if (!decltype(prefetch)::value && fuse_rope && p_new >= P0 && p_new < P0 + 32) {          // wave-uniform: splice the newest k / v (parked in LDS)
             const int o = p_new - P0;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_decode_kernel(const bf16_t* _
                 S[t] = mfma16(__builtin_bit_cast(bf16x8_t, kr[t][s4]),
                                                                __builtin_bit_cast(bf16x8_t, qf[s4]), S[t]);
         }
-        if (it + NW < nit) load_k(it + NW);
+        if constexpr (decltype(prefetch)::value) load_k(it + NW);
         // lane (head i, group g): S[t][r] is the score of position P0 + g*8 + t*4 + r
         float sv[8];
         float mx = -1e30f;
@@ -724,7 +730,17 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_decode_kernel(const bf16_t* _
             acc[dt] = mfma16(__builtin_bit_cast(bf16x8_t, vr[dt]),
                                                               __builtin_bit_cast(bf16x8_t, pf), acc[dt]);
         }
-        if (it + NW < nit) load_v(it + NW);
+        if constexpr (decltype(prefetch)::value) load_v(it + NW);
+    };
+    // Everything requested so far (the first K / V^T block, the q slices) is waited for HERE, with a wait the compiler's wait-count pass can see (the builtin, not
+    // inline asm).  The q fragments are first used inside the loop; left pending at its entry they are the YOUNGEST loads in flight there, the one static wait at
+    // the loop header has to cover that edge too, and it came out as s_waitcnt vmcnt(0) on EVERY iteration — each QK product waited for the V^T block requested
+    // a moment earlier (ISA read, round 6; the first block is needed in full before its products anyway).  (vmcnt(0); expcnt / lgkmcnt untouched.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    {
+        int it = wid;
+        for (; it + NW < nit; it += NW) block(it, std::true_type{});
+        if (it < nit) block(it, std::false_type{});
     }
     // ---- the k-groups of a wave share m; sum their l; then merge the 4 waves through LDS ----
     l += __shfl_xor(l, 16, 64);

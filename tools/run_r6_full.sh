@@ -1,13 +1,13 @@
-# Round 5 measurement pass on one MI355X (gpurun): the whole GPU suite, smoke, counter passes (traffic of the roofline kernels and of the decode GEMMs; SQ
-# counters of the tower's kernels), bench lines of every configuration (+ the STC connector), rocprofv3 kernel statistics of the tower / decode / bench / STC
-# commands, and a pipelined stress run that adds to the count of clean steps.  Results land under gpurun_out/full5/ (scratch); the summaries quoted in
-# DESIGN.md are copied to profiles/ by hand.
+# Round 6 measurement pass on one MI355X (gpurun): the whole GPU suite, smoke, counter passes (traffic of the roofline kernels and of the decode GEMMs; SQ
+# counters of the tower's kernels and both attention kernels), bench lines of every configuration (+ the STC connector), rocprofv3 kernel statistics of the tower /
+# decode / bench commands, and a pipelined stress run that adds to the count of clean steps.  Results land under gpurun_out/full6/ (scratch); the summaries quoted in
+# DESIGN.md are copied to profiles/ by hand.  (The single-purpose A/B calls of the round quote their command lines in the header of the profiles/ file they produced.)
 set -x
 python -c "from trace_amd import _lib; _lib.load(); _lib.load('f16')" || exit 9
-O=gpurun_out/full5
+O=gpurun_out/full6
 mkdir -p $O
 rm -f gpurun_out/parity_measured.txt
-timeout 1500 python -m pytest tests -m gpu -q --tb=short --timeout=900 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?"
+timeout 1800 python -m pytest tests -m gpu -q --tb=short --timeout=900 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?"
 tail -6 $O/pytest.log
 cp gpurun_out/parity_measured.txt $O/ 2>/dev/null
 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
@@ -26,16 +26,17 @@ python bench.py --steps 3 --warmup 1 --no-pipeline --no-cpu-baseline > $O/bench_
 python bench.py --config c4 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err; echo "bench c4 rc=$?"
 python bench.py --config c5 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c5_fp8.json 2> $O/bench_c5.err; echo "bench c5 rc=$?"
 python bench.py --config stc --steps 10 --warmup 2 > $O/bench_stc.json 2> $O/bench_stc.err; echo "bench stc rc=$?"; cat $O/bench_stc.json
+python bench.py --config c1 > $O/bench_c1.json 2> $O/bench_c1.err; echo "bench c1 rc=$?"; cut -c1-600 $O/bench_c1.json
 timeout 400 python tools/pipeline_stress.py --steps 60 --max-new 200 --plan 0 > $O/pipeline_stress.txt 2>&1; echo "stress rc=$?"; tail -3 $O/pipeline_stress.txt
 timeout 300 python tools/gemm_w4_check.py --time > $O/gemm_w4_check.txt 2>&1; echo "w4 check rc=$?"; grep -c "^ok" $O/gemm_w4_check.txt; grep "mismatching" $O/gemm_w4_check.txt
+timeout 300 python tools/attn_vit_big_probe.py > $O/attn_probe.txt 2>&1; echo "attn probe rc=$?"; grep -v amdgpu $O/attn_probe.txt | tail -6
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_vitstream -- python $R/tools/vit_stream_profile.py > $R/$O/prof_vitstream.log 2>&1; echo "prof vit stream rc=$?"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_dec128 -- python $R/tools/decode_profile.py --batch 128 --steps 32 --eager > $R/$O/prof_dec128.log 2>&1; echo "prof dec128 rc=$?"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_dec1 -- python $R/tools/decode_profile.py --steps 32 --eager > $R/$O/prof_dec1.log 2>&1; echo "prof dec1 rc=$?"
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_stc -- python $R/bench.py --config stc --steps 5 --warmup 1 > $R/$O/prof_stc.log 2>&1; echo "prof stc rc=$?"
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/$O/prof_bench.log 2>&1; echo "prof bench rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipeline > $R/$O/prof_bench.log 2>&1; echo "prof bench rc=$?"
 cd $R
-for d in prof_vitstream prof_dec128 prof_dec1 prof_stc prof_bench; do python tools/kernel_stats_top.py $O/$d 30 > $O/$d.top.txt; done
-head -14 $O/prof_vitstream.top.txt; head -14 $O/prof_stc.top.txt
+for d in prof_vitstream prof_dec128 prof_dec1 prof_bench; do python tools/kernel_stats_top.py $O/$d 30 > $O/$d.top.txt; done
+head -14 $O/prof_vitstream.top.txt; head -12 $O/prof_dec128.top.txt
 find $O -name '*kernel_trace.csv' -delete; find $O -name '*counter_collection.csv' -delete; find $O -name '*agent_info.csv' -delete
 ls $O

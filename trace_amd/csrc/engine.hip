@@ -78,7 +78,11 @@ struct trace_ctx {
     // LLM prefill workspaces
     bf16_t *pX, *pH, *pQKV, *pO, *pACT;
     int32_t *d_kind, *d_row;             // splice index arrays (max_ctx)
-    int32_t *h_kind, *h_row;             // pinned host staging
+    int32_t *h_kind, *h_row;             // pinned host staging: the buffer of the ring below that the current call fills
+    static constexpr int NSTAGE_H = 4;   // ring of staging buffers, each behind an event recorded after its last copy was queued (round 6: the two calls that use
+    int32_t* h_ring = nullptr;           // them waited for the whole stream instead — two drains of the encode stream per video)
+    hipEvent_t h_ev[NSTAGE_H] = {nullptr, nullptr, nullptr, nullptr};
+    int h_next = 0; size_t h_len = 0;
     int spliced_len = 0;
     // decode state
     bf16_t *dX, *dH, *dQKV, *dO, *dACT, *xlast;   // [16, *]
@@ -292,9 +296,11 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     A(c->d_heads_tmp, 3 * SK_ROWS); A(c->d_slots, SK_ROWS); A(c->d_pos, SK_ROWS); A(c->d_heads, SK_ROWS); A(c->d_done, SK_ROWS); A(c->d_out_len, SK_ROWS); A(c->d_step, 4); A(c->d_params, 4);
     A(c->d_out_ids, (size_t)SK_ROWS * cfg->max_new_tokens); A(c->d_forced, (size_t)SK_ROWS * cfg->max_new_tokens);
 #undef A
-    if (rc == TRACE_OK && hipHostMalloc((void**)&c->h_kind, Lm * 8) != hipSuccess) rc = fail(TRACE_ERR_HIP, "hipHostMalloc");
+    if (rc == TRACE_OK && hipHostMalloc((void**)&c->h_ring, Lm * 8 * trace_ctx::NSTAGE_H) != hipSuccess) rc = fail(TRACE_ERR_HIP, "hipHostMalloc");
     if (rc != TRACE_OK) { trace_ctx_destroy(c); return rc; }
-    c->h_row = c->h_kind + Lm;
+    c->h_len = Lm;
+    c->h_kind = c->h_ring; c->h_row = c->h_kind + Lm;
+    for (int i = 0; i < trace_ctx::NSTAGE_H; ++i) hipEventCreateWithFlags(&c->h_ev[i], hipEventDisableTiming);
     hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking);
     hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
     hipEventCreate(&c->gev0); hipEventCreate(&c->gev1);
@@ -321,7 +327,8 @@ extern "C" int trace_ctx_destroy(trace_ctx* c) {
     if (c->gev1) hipEventDestroy(c->gev1);
     for (void* p : c->allocs) hipFree(p);
     if (c->pp_buf) hipFree(c->pp_buf);
-    if (c->h_kind) hipHostFree(c->h_kind);
+    if (c->h_ring) hipHostFree(c->h_ring);
+    for (int i = 0; i < trace_ctx::NSTAGE_H; ++i) if (c->h_ev[i]) hipEventDestroy(c->h_ev[i]);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -722,13 +729,27 @@ extern "C" int trace_stc_connector(trace_ctx* c, const void* feats, int T, void*
     return TRACE_OK;
 }
 
+// The next pinned staging buffer of the ring (h_kind / h_row point into it afterwards): waits only for the copies that last read THAT buffer, four uses ago —
+// normally long done — instead of draining the stream.  stage_release() records the buffer's event behind the copies just queued.
+static int stage_acquire(trace_ctx* c) {
+    c->h_next = (c->h_next + 1) % trace_ctx::NSTAGE_H;
+    HIPCHK(hipEventSynchronize(c->h_ev[c->h_next]));          // (an event never recorded is complete)
+    c->h_kind = c->h_ring + (size_t)c->h_next * 2 * c->h_len;
+    c->h_row = c->h_kind + c->h_len;
+    return TRACE_OK;
+}
+static int stage_release(trace_ctx* c, hipStream_t s) {
+    HIPCHK(hipEventRecord(c->h_ev[c->h_next], s));
+    return TRACE_OK;
+}
+
 // slot pool on `feats` (nullptr = the tower's internal buffer) + the per-frame time-token rows -> c->video
 static int encode_tail(trace_ctx* c, const void* feats, int T, const int32_t* time_ids, void* video_out, void* stream) {
     if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
     hipStream_t s = (hipStream_t)stream;
     TRY(trace_slot_pool(c, feats, T, nullptr, stream));
     const int rows = T * c->TPF;
-    HIPCHK(hipStreamSynchronize(s));        // pinned staging buffer reuse
+    TRY(stage_acquire(c));
     for (int t = 0; t < T; ++t)
         for (int j = 0; j < c->TPF; ++j) {
             const int r = t * c->TPF + j;
@@ -741,6 +762,7 @@ static int encode_tail(trace_ctx* c, const void* feats, int T, const int32_t* ti
         }
     HIPCHK(hipMemcpyAsync(c->d_kind, c->h_kind, rows * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_row, c->h_row, rows * 4, hipMemcpyHostToDevice, s));
+    TRY(stage_release(c, s));
     GatherTabs tabs{};
     tabs.t[0] = c->sl_out; tabs.t[1] = c->time_tab;
     LCHK(launch_gather_rows(tabs, c->d_kind, c->d_row, c->video, rows, c->H, s));
@@ -773,7 +795,7 @@ extern "C" int trace_splice_embeds(trace_ctx* c, const int32_t* ids, int n_ids, 
     if (c->video_rows <= 0) return fail(TRACE_ERR_STATE, "no encoded video");
     const int L = n_ids - 1 + c->video_rows;
     if (L > c->max_ctx) return fail(TRACE_ERR_ARG, "spliced prompt longer than max_ctx");
-    HIPCHK(hipStreamSynchronize(s));
+    TRY(stage_acquire(c));
     int r = 0, ti = 0, si = 0;
     for (int i = 0; i < n_ids; ++i) {
         const int id = ids[i];
@@ -798,6 +820,7 @@ extern "C" int trace_splice_embeds(trace_ctx* c, const int32_t* ids, int n_ids, 
     if (ti != n_time || si != n_score) return fail(TRACE_ERR_ARG, "fewer <time>/<score> placeholders than supplied tokens");
     HIPCHK(hipMemcpyAsync(c->d_kind, c->h_kind, L * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_row, c->h_row, L * 4, hipMemcpyHostToDevice, s));
+    TRY(stage_release(c, s));
     GatherTabs tabs{};
     tabs.t[0] = c->embed; tabs.t[1] = c->video; tabs.t[2] = c->time_tab; tabs.t[3] = c->score_tab; tabs.t[4] = c->sync_row;
     LCHK(launch_gather_rows(tabs, c->d_kind, c->d_row, c->pX, L, c->H, s));
@@ -1170,7 +1193,7 @@ static int decode_step_fused(trace_ctx* c, float* logits_out, hipStream_t s) {
 
 int g_decode_unfused = 0;   // RoPE + cache append as a kernel of its own before the decode attention: 0 = from batch 32 up (bit-identical to the fused
                             // prologue, 1 % faster per 64-sequence step, one launch more — which batch 1 would feel), 1 = always, 2 = never
-                            // (trace_op_set_gemm_variant(120 + x), tools/decode_ab.py)
+                            // (trace_op_set_gemm_variant(120 + x), tools/decode_variant_ab.py --variants 122,121)
 // one decode step for the current batch: consumes dX (embedding of the last token), leaves the next one in dX
 static int decode_step(trace_ctx* c, float* logits_out, hipStream_t s) {
     const int H = c->H, I = c->I, HD = c->HD, QKV = c->QKV, B = c->B;

@@ -184,11 +184,11 @@ class TraceEngine:
 
     def time_ids(self, timestamps: Sequence[Sequence[float]]) -> List[int]:
         """encode_time + [:-1] (trace_arch.py:243,271-288): 6 ids per frame; all frames must agree in length."""
-        toks = [self.time_tower.encode(t) for t in timestamps]
-        assert all(x.shape == toks[0].shape for x in toks), f"{timestamps} {[x.shape for x in toks]}"
-        if toks[0].numel() - 1 != self.cfg.time_tokens_per_frame:
+        toks = [self.time_tower.encode_ids(t) for t in timestamps]
+        assert all(len(x) == len(toks[0]) for x in toks), f"{timestamps} {[len(x) for x in toks]}"
+        if len(toks[0]) - 1 != self.cfg.time_tokens_per_frame:
             raise ValueError("each frame must carry exactly one timestamp (6 time tokens)")
-        return [int(i) for x in toks for i in x[:-1]]
+        return [i for x in toks for i in x[:-1]]
 
     def encode_video(self, frames: torch.Tensor, timestamps, want_output: bool = False):
         frames, dt = self._frames(frames)

@@ -14,6 +14,11 @@ VOCAB = {"<sync>": 0, "<sep>": 1, **{str(i): i + 2 for i in range(10)}, ".": 12}
 IDS_TO_TOKENS = {v: k for k, v in VOCAB.items()}
 
 
+class _Enc:
+    """what a tokenizer call returns: .input_ids"""
+    input_ids: List[int]
+
+
 class NumberTokenizer:
     """Stand-in for TimeTokenizer / ScoreTokenizer (PreTrainedTokenizer subclasses in the reference): the
     drivers only call `.decode(i)` with an int or 0-d tensor (trace/eval/evaluate.py:395,408) and `.get_vocab()`."""
@@ -21,6 +26,7 @@ class NumberTokenizer:
     def __init__(self):
         self.vocab = dict(VOCAB)
         self.ids_to_tokens = dict(IDS_TO_TOKENS)
+        self._keys = sorted(self.vocab, key=len, reverse=True)      # longest first, as the reference's regex alternation matches
 
     def get_vocab(self):
         return self.vocab
@@ -33,7 +39,7 @@ class NumberTokenizer:
 
     def tokenize(self, text: str) -> List[str]:
         out, i = [], 0
-        keys = sorted(self.vocab, key=len, reverse=True)
+        keys = self._keys
         while i < len(text):
             for k in keys:
                 if text.startswith(k, i):
@@ -45,8 +51,6 @@ class NumberTokenizer:
         return out
 
     def __call__(self, text: str):
-        class _Enc:
-            pass
         e = _Enc()
         e.input_ids = [self.vocab[t] for t in self.tokenize(text)]
         return e
@@ -70,16 +74,27 @@ TimeTokenizer = NumberTokenizer
 ScoreTokenizer = NumberTokenizer
 
 
-def _encode(values: Sequence[float], fmt: str) -> torch.Tensor:
-    tok = NumberTokenizer()
-    strs = [format(v, fmt) for v in values]
+_TOK = None          # one tokenizer for every encode() (its tables never change; building it per call was most of a call's time)
+
+
+def _encode_ids(values: Sequence[float], fmt: str) -> List[int]:
+    """The ids of _encode() as a plain list (the engine's per-frame path: 128 calls per video; no tensor per call)."""
+    global _TOK
+    if _TOK is None:
+        _TOK = NumberTokenizer()
+    tok = _TOK
+    sep, sync = tok("<sep>").input_ids, tok("<sync>").input_ids
     ids: List[int] = []
-    for i, s in enumerate(strs):
+    for i, v in enumerate(values):
         if i:
-            ids.extend(tok("<sep>").input_ids)
-        ids.extend(tok(s).input_ids)
-    ids.extend(tok("<sync>").input_ids)
-    return torch.tensor(ids, dtype=torch.long)
+            ids.extend(sep)
+        ids.extend(tok(format(v, fmt)).input_ids)
+    ids.extend(sync)
+    return ids
+
+
+def _encode(values: Sequence[float], fmt: str) -> torch.Tensor:
+    return torch.tensor(_encode_ids(values, fmt), dtype=torch.long)
 
 
 class TimeTower:
@@ -91,6 +106,10 @@ class TimeTower:
 
     def encode(self, values: Sequence[float]) -> torch.Tensor:
         return _encode(values, self.fmt)
+
+    def encode_ids(self, values: Sequence[float]) -> List[int]:
+        """encode() as a list of ints"""
+        return _encode_ids(values, self.fmt)
 
 
 class ScoreTower(TimeTower):

@@ -401,6 +401,31 @@ def medium_goldens(tmp):
     print("medium_vit: feats", tuple(feats.shape), "abs mean %.4f max %.3f" % (feats.abs().mean().item(), feats.abs().max().item()))
 
 
+def medium_multi_goldens(tmp):
+    """The same real CLIP-ViT-L/14-336 geometry for THREE DISTINCT frames in one call of the reference's vision tower + SpatialSlotPool (round 6: the one-frame
+    fixture above pins the arithmetic, this one pins that a frame's result does not depend on its neighbours in the batch or its place in a frame stream).
+    To stay small it stores every frame's 8 slot rows in full (float16) and every 24th feature row of every frame (24 of 576 rows, float16)."""
+    import dataclasses
+    from trace_amd import config as tcfg, synth
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=3), vision_hidden_size=1024, vision_intermediate_size=4096, vision_num_layers=24,
+                              vision_num_heads=16, vision_image_size=336, vision_patch_size=14, mm_hidden_size=1024)
+    model = build_reference_model(cfg, os.path.join(tmp, "medium_multi"))
+    load_synth(model, cfg)
+    frames = synth.synth_frames(cfg, 11, num_frames=3).to(torch.bfloat16).float()
+    assert not torch.equal(frames[0], frames[1]) and not torch.equal(frames[1], frames[2])
+    with torch.no_grad():
+        vt = model.get_model().get_vision_tower()
+        feats = vt(frames)                                           # [3,576,1024]  clip_encoder.py:41-53
+        slots = model.get_model().mm_projector(feats[None])          # [1,3,8,4096]
+        one = vt(frames[1:2])                                        # the reference itself: a frame alone == the frame in a batch (to fp32 rounding)
+        assert (one[0] - feats[1]).abs().max().item() < 1e-3
+    np.savez_compressed(os.path.join(OUT, "medium_vit_multi.npz"), feat_rows=np.arange(0, 576, 24, dtype=np.int32),
+                        vit_feats_rows=feats[:, ::24].numpy().astype(np.float16), slots=slots[0].numpy().astype(np.float16),
+                        feat_abs_mean=np.array(feats.abs().mean().item()), feat_norm=feats.flatten(1).norm(dim=1).numpy().astype(np.float32),
+                        video_idx=np.array(11))
+    print("medium_vit_multi: feats", tuple(feats.shape), "abs mean %.4f max %.3f" % (feats.abs().mean().item(), feats.abs().max().item()))
+
+
 def medium_llm_goldens(tmp, dtype=torch.bfloat16):
     """One decoder layer at the REAL Mistral-7B widths (hidden 4096, intermediate 14336, 32/8 heads x 128) behind the tiny ViT:
     teacher-forced logits of the reference over a stream that visits all three heads.  Pins the K = 14336 down-projection
@@ -848,6 +873,9 @@ if __name__ == "__main__":
     if "--medium-only" in sys.argv:
         medium_goldens(tmp)
         sys.exit(0)
+    if "--medium-multi-only" in sys.argv:
+        medium_multi_goldens(tmp)
+        sys.exit(0)
     if "--medium-llm-only" in sys.argv:
         medium_llm_goldens(tmp)
         sys.exit(0)
@@ -889,6 +917,7 @@ if __name__ == "__main__":
     medium_llm_goldens(tmp, torch.float16)
     deep_llm_goldens(tmp, torch.float16)
     medium_goldens(tmp)
+    medium_multi_goldens(tmp)
     medium_llm_goldens(tmp)
     long_ctx_goldens(tmp)
     real_vocab_goldens(tmp)

@@ -310,6 +310,49 @@ def test_ragged_batch_and_context_limits(setup):
     small.close()
 
 
+def test_vit_large_geometry_three_distinct_frames_vs_reference_fixture(golden_dir):
+    """Real CLIP-ViT-L/14-336 geometry, THREE DISTINCT frames (tests/golden/medium_vit_multi.npz: the reference's own tower + slot pool on them in one call): the HIP
+    tower on the three frames, and on a 24-frame stream that holds each of them eight times in a shuffled order (the 256 x 256 GEMM tiles and the 192-row
+    attention: the path the product runs).  Every copy inside the one-frame test's budget against the reference; the copies of a frame bit-identical wherever
+    they sit in the stream and whatever their neighbours are."""
+    import dataclasses
+    cfg = dataclasses.replace(tcfg.tiny(num_frames=3), vision_hidden_size=1024, vision_intermediate_size=4096, vision_num_layers=24,
+                              vision_num_heads=16, vision_image_size=336, vision_patch_size=14, mm_hidden_size=1024)
+    M = np.load(os.path.join(golden_dir, "medium_vit_multi.npz"))
+    rows = torch.from_numpy(M["feat_rows"]).long()
+    ref = torch.from_numpy(M["vit_feats_rows"].astype(np.float32))           # [3, 24, 1024]
+    ref_norm = torch.from_numpy(M["feat_norm"])
+    rs = torch.from_numpy(M["slots"].astype(np.float32))                     # [3, 8, 4096]
+    amean = float(M["feat_abs_mean"])
+    sd = synth.state_dict(cfg)
+    frames = synth.synth_frames(cfg, int(M["video_idx"]), num_frames=3).to(torch.bfloat16)
+    eng = TraceEngine(cfg, max_batch=1, max_ctx=512, max_frames=24, max_new_tokens=8)
+    eng.load_weights(sd.items())
+
+    def check(f, tag):
+        e = (f[:, rows] - ref).abs()
+        # relative L2 over the sampled rows (the full-tensor norms of the reference are in the fixture: the sampled rows are a 24th of each frame)
+        rl2 = ((f[:, rows] - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)).max().item()
+        print(f"{tag}: max {e.max().item():.4f} mean {e.mean().item():.5f} rel L2 {rl2:.5f}")
+        assert torch.isfinite(f).all()
+        assert e.max().item() < 0.5 and e.mean().item() < 0.02 * amean and rl2 < 0.02, (tag, e.max().item(), e.mean().item(), rl2)
+        assert torch.allclose(f.flatten(1).norm(dim=1), ref_norm, rtol=2e-2)
+
+    f3 = eng.vit_forward(frames).float().cpu()
+    check(f3, "three frames")
+    slots = eng.slot_pool(None, 3).float().cpu().reshape(3, 8, -1)
+    es = (slots - rs).abs()
+    print("slots: max err", es.max().item(), "ref max", rs.abs().max().item())
+    assert es.max().item() < 0.05 * max(1.0, rs.abs().max().item()), (es.max().item(), rs.abs().max().item())
+    order = torch.tensor([0, 1, 2, 2, 0, 1, 1, 2, 0, 0, 0, 1, 2, 2, 1, 1, 0, 2, 2, 1, 0, 1, 0, 2])
+    f24 = eng.vit_forward(frames[order].contiguous()).float().cpu()
+    for k in range(3):
+        idx = (order == k).nonzero().flatten().tolist()
+        assert len(idx) == 8 and all(torch.equal(f24[idx[0]], f24[i]) for i in idx[1:]), k
+    check(torch.stack([f24[(order == k).nonzero()[0, 0]] for k in range(3)]), "24-frame shuffled stream")
+    eng.close()
+
+
 def test_vit_large_geometry_vs_reference_fixture(golden_dir):
     """The real CLIP-ViT-L/14-336 geometry (1024 wide, 23 of 24 layers, 16 heads, 577 tokens) for one frame: HIP ViT + slot
     pool against the fixture captured from the reference's own vision tower + SpatialSlotPool (tests/golden/medium_vit.npz)

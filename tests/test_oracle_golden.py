@@ -174,6 +174,31 @@ def test_medium_vit_matches_reference_fixture(golden_dir):
     assert es.max().item() < 5e-3 * max(1.0, rs.abs().max().item()), es.max().item()
 
 
+def test_medium_vit_three_distinct_frames_match_reference_fixture(golden_dir):
+    """The same geometry for THREE DISTINCT frames in one call (tests/golden/medium_vit_multi.npz, round 6): every 24th feature row and all slot rows of every
+    frame against the reference's own tower + slot pool; a frame alone gives what it gives inside the batch."""
+    import dataclasses
+    cfg = dataclasses.replace(_medium_cfg(), num_frames=3)
+    M = np.load(os.path.join(golden_dir, "medium_vit_multi.npz"))
+    sd = {n: synth.synth_tensor(n, shp, kind, torch.bfloat16).float() for n, shp, kind in synth.weight_specs(cfg)
+          if "vision_tower" in n or "mm_projector" in n}
+    ora = O.Oracle(cfg, sd, emulate_bf16=False)
+    frames = synth.synth_frames(cfg, int(M["video_idx"]), num_frames=3).to(torch.bfloat16).float()
+    rows = torch.from_numpy(M["feat_rows"]).long()
+    with torch.no_grad():
+        feats = ora.vit_forward(frames).reshape(3, 576, 1024)
+        slots = ora.slot_pool(feats).reshape(3, 8, -1)
+        alone = ora.vit_forward(frames[2:3]).reshape(576, 1024)
+    ref = torch.from_numpy(M["vit_feats_rows"].astype(np.float32))
+    err = (feats[:, rows] - ref).abs()
+    assert err.max().item() < 2e-2 and err.mean().item() < 2e-3, (err.max().item(), err.mean().item())
+    assert torch.allclose(feats.flatten(1).norm(dim=1), torch.from_numpy(M["feat_norm"]), rtol=1e-3)
+    rs = torch.from_numpy(M["slots"].astype(np.float32))
+    es = (slots - rs).abs()
+    assert es.max().item() < 5e-3 * max(1.0, rs.abs().max().item()), es.max().item()
+    assert (alone - feats[2]).abs().max().item() < 1e-3
+
+
 def test_medium_llm_matches_reference_fixture(golden_dir):
     """One decoder layer at the real Mistral-7B widths (intermediate 14336): oracle teacher-forced logits vs the reference's."""
     import dataclasses

@@ -44,7 +44,7 @@ alg = 28672 * 4096 * 2
 total = fetch_kb * 1024 * 2 + write_kb * 1024
 import datetime
 json.dump({
-    "measured": "round 5, " + datetime.date.today().isoformat(),
+    "measured": "round 6, " + datetime.date.today().isoformat(),
     "attn_decode_bytes_per_launch": a_total, "attn_decode_batch": AD_B, "attn_decode_ctx": AD_CTX,
     "attn_decode_detail": {
         "kernel": "attn_decode_kernel, %d sequences x ctx %d x 8 kv heads (the wide decode step's dominant kernel), 4 launches" % (AD_B, AD_CTX),

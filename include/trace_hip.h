@@ -213,7 +213,10 @@ int trace_op_swiglu_combine(const float* part, int KS, int N2, void* out, int B,
 int trace_op_add_rmsnorm(const float* part, int KS, const void* R, void* xout, const void* w, void* y, int B, int N,
                          float eps, void* stream);
 /* kcache [B, nkv, max_ctx, 128] row-major; vtcache [B, nkv, 128, max_ctx] = V transposed (the engine's cache layout,
-   max_ctx % 32 == 0); pos[b] = newest position, already in both caches; q [B, nq*128] rotated; ws B*nq*nsplit*130 floats. */
+   max_ctx % 32 == 0); pos[b] = newest position, already in both caches; q [B, nq*128] rotated; ws B*nq*nsplit*130 floats.
+   The kernel fetches whole 32-position blocks: positions pos[b] + 1 .. the next multiple of 32 are READ (their scores are masked
+   and their weights are exactly 0, so what they hold never counts) — both caches must hold finite values there (the engine's
+   caches are zero-filled at creation and only ever hold finite values). */
 int trace_op_attn_decode(const void* q, const void* kcache, const void* vtcache, const int32_t* pos, void* O, float* ws,
                          int B, int nq, int nkv, int max_ctx, int nsplit, float scale, void* stream);
 

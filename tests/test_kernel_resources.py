@@ -126,6 +126,40 @@ def test_vit_attention_tile_loop_touches_no_scratch(res, tmp_path):
     assert seen == 2                                                    # the 3-stage (shipped) and 4-stage ring instantiations
 
 
+def test_decode_attention_block_loop_keeps_its_counted_waits(tmp_path):
+    """attn_decode_kernel: the steady part of the block loop must wait for the K block only in front of the QK products and for the V^T block only in front of
+    the PV products (vmcnt(15 .. 8) / vmcnt(11 .. 8) in the shipped build) — never vmcnt(0), which is what hipcc emitted through round 5 (per-lane load predicates,
+    conditional requests, q-fragment loads pending at the loop's entry edge: DESIGN section 4) and which makes every wave wait for the block it has just requested."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path / "decode.s")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", os.path.join(CSRC, "decode.hip"), "-I", CSRC, "-o", out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    isa = open(out).read()
+    seen = 0
+    for m in re.finditer(r"^(_ZN\S*attn_decode_kernelILi4ELb0E\S*):\s.*?^\.Lfunc_end", isa, re.S | re.M):
+        body = m.group(0).splitlines()
+        # the steady loop = the innermost loop whose blocks hold 16 MFMAs and 16 cache loads (8 K + 8 V^T pieces of the NEXT block)
+        heads = [i for i, l in enumerate(body) if l.startswith(".LBB") and "Loop Header" in l]
+        found = False
+        for h in heads:
+            tag = "Header=" + body[h].split(":")[0].lstrip(".L")
+            mine = [i for i, l in enumerate(body) if l.startswith(".LBB") and "in Loop" in l and tag in l]
+            lo, hi = min([h] + mine), max([h] + mine)
+            end = next(i for i in range(hi + 1, len(body)) if body[i].startswith(".LBB"))
+            loop = body[lo:end]
+            if sum("v_mfma" in l for l in loop) != 16 or sum("global_load_dwordx4" in l for l in loop) != 16:
+                continue
+            waits = [int(x) for l in loop for x in re.findall(r"vmcnt\((\d+)\)", l)]
+            assert waits and min(waits) >= 8, (m.group(1), sorted(set(waits)))
+            found = True
+        assert found, m.group(1)
+        seen += 1
+    assert seen == 1
+
+
 def test_decode_gemv_does_not_spill(res):
     for k, v in _pick(res["decode"], "skinny_lds_kernel").items():
         assert v["ScratchSize"] == 0, (k, v)

@@ -578,7 +578,8 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_decode_kernel(const bf16_t* _
     const u32x4_t zero4 = {0u, 0u, 0u, 0u};
     u32x4_t kr[2][4], vr[8];
     // The loads are UNCONDITIONAL (round 6): a block's 32 positions lie below round_up(end, 32) <= ctx_stride, i.e. inside the slot's rows, and what a position >= end
-    // (or the newest row, spliced from LDS below) holds never counts — its score is masked, its p is 0, and the caches hold finite values only (see above).  With
+    // (or the newest row, spliced from LDS below) holds never counts — its score is masked, its p is 0, whole groups of 8 past `end` are zeroed before the PV
+    // product of a wave's last block, and the caches hold finite values only (see above).  With
     // per-lane predicates the loads sat in exec-masked branches, the number in flight was unknown at the joins, and hipcc put s_waitcnt vmcnt(0) in front of the
     // QK MFMAs: every wave waited for the V^T block it had requested a moment earlier instead of computing S under it (ISA read, round 6; measured against the
     // predicated form in profiles/r06_decode_attn_waits_ab.txt: equal at batch 128, where 12 waves per CU cover the latency anyway, -1.4 % per step at batch 16).
@@ -724,6 +725,13 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_decode_kernel(const bf16_t* _
         }
         l = l * a + ps;
         const u32x4_t pf = {pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])};
+        if constexpr (!decltype(prefetch)::value) {
+            // only a wave's LAST block can reach past `end`: 8-position groups wholly past it count as zeros, as they did when their loads were predicated
+            // (p = 0 there, but 0 x a non-finite leftover of an earlier sequence would not be 0)
+            const bool vok = P0 + g * 8 < end;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) vr[dt] = vok ? vr[dt] : zero4;
+        }
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
             acc[dt] *= a;

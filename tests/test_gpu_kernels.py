@@ -122,7 +122,7 @@ def test_gemm_persistent_equals_loader_wave_kernel(M, N, K):
 def test_gemm_four_wave_kernel_equals_loader_wave_kernel(M, N, K):
     """gemm_w4.hip (variant 8: the persistent 256x256 tile on 4 waves of 128x128, accumulators in AGPRs, the waves issue their own LDS-DMA pieces) against
     gemm_ldr.hip (variant 4), bit for bit, all four epilogues: ragged M, fewer tiles than CUs, several tiles per workgroup (tickets and the static deal),
-    its A/B builds (one barrier per K-tile; L2 touches), the in-place residual, back-to-back launches, and launches alternating with gemm_pers.hip on one
+    its A/B builds (one barrier per K-tile; L2 touches; the check build in which every hand-counted s_waitcnt vmcnt(N) is vmcnt(0): the counted build must give the same bits), the in-place residual, back-to-back launches, and launches alternating with gemm_pers.hip on one
     stream (the two kernels share the stream's ticket counters)."""
     A, W, b, R = rnd(M, K), rnd(N, K, scale=0.05), rnd(N, scale=0.5), rnd(M, N)
     lib = E._lib.load()
@@ -130,7 +130,7 @@ def test_gemm_four_wave_kernel_equals_loader_wave_kernel(M, N, K):
         for epi, kw in ((E.EPI_NONE, dict(bias=b)), (E.EPI_NONE, {}), (E.EPI_QUICKGELU, dict(bias=b)), (E.EPI_RESIDUAL, dict(bias=b, R=R)), (E.EPI_SWIGLU, {})):
             ops.set_gemm_variant(4)
             ref = ops.gemm(A, W, epilogue=epi, **kw)
-            for walk, opt in ((500, 0), (501, 0), (500, 1), (500, 4), (500, 5)):
+            for walk, opt in ((500, 0), (501, 0), (500, 1), (500, 4), (500, 5), (500, 2)):      # (opt 2: the check build whose counted waits are all vmcnt(0))
                 ops.set_gemm_variant(walk)
                 ops.set_gemm_variant(540 + opt)
                 for rep in range(3):

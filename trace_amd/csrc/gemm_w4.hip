@@ -121,6 +121,9 @@ __global__ __launch_bounds__(NTHR) void gemm_w4_kernel(GemmArgs p, int* ctr, int
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, (int)(uint32_t)((long)p.M * p.lda * 2), 0x00020000);      // (the launcher keeps both extents below 4 GB)
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, (int)(uint32_t)((long)p.N * p.ldw * 2), 0x00020000);
     uint32_t voA[8], voW[8];                                 // per-lane byte offsets of the pieces' rows (swizzled 16-byte chunk included)
+    constexpr bool SAFE = (OPT & 2) != 0;                    // check build: every counted s_waitcnt vmcnt(N) below becomes vmcnt(0).  Slower, and correct whatever the
+                                                             // counts are worth: tests/test_gpu_kernels.py compares it bit for bit with the counted build, so a hipcc upgrade that moves a
+                                                             // VMEM operation across one of the counts shows up as a difference instead of as a rare wrong tile
     constexpr bool TOUCH = (OPT & 4) != 0;                   // wave 0 touches the A lines of K-tile kt + 3 into L2 (gemm_pers.hip's L2 touches), one instruction per K-tile
     const bool toucher = TOUCH && wid == 0;
     uint32_t voT = 0;
@@ -188,7 +191,8 @@ __global__ __launch_bounds__(NTHR) void gemm_w4_kernel(GemmArgs p, int* ctr, int
     d_kt = 2;
     bool d_next = false;                                     // the cursor has moved on to the next tile
     bool has_next = false;
-    if (toucher) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    if (SAFE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (toucher) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // K-tile 0 (the bias load is older still)
     bias_publish(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(NTHR) void gemm_w4_kernel(GemmArgs p, int* ctr, int
         lgkm0(af[1], wf[1]);
         if (pend == 0) {
             // every piece issued so far has landed — and the ticket drawn a K-tile ago (tied operand: no use of it can be scheduled before this wait)
-            if (toucher) asm volatile("s_waitcnt vmcnt(1)" : "+v"(ticket) :: "memory");      // (all but the touch behind the pieces; without one: a piece more than needed... never fewer)
+            if (toucher && !SAFE) asm volatile("s_waitcnt vmcnt(1)" : "+v"(ticket) :: "memory");      // (all but the touch behind the pieces; without one: a piece more than needed... never fewer)
             else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
             if (kt == nk - 1 && d_next) bias_publish((n + 1) & 1);      // (the set-up that loaded it was a K-tile ago; this is the full drain behind it)
             if (kt == 1 && leader) {                         // the tile after this one, for everyone to read behind this barrier
@@ -246,7 +250,8 @@ __global__ __launch_bounds__(NTHR) void gemm_w4_kernel(GemmArgs p, int* ctr, int
                 // the launch's last ticket on this XCD re-arms the counter (gemm_pers.hip); asm: hipcc's atomic optimizer would wait for the result it drops
                 if (dynamic && ticket == cnt - 1) asm volatile("global_atomic_swap %0, %1, off" :: "v"(ctr + xcd * CTR_STRIDE), "v"(0) : "memory");
             }
-        } else if (EPI == EPI_SWIGLU) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // (a toucher's touch is OLDER than the stores: these counts hold for it too,
+        } else if (SAFE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (EPI == EPI_SWIGLU) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // (a toucher's touch is OLDER than the stores: these counts hold for it too,
         else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                                //  they just wait for its touch as well)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         pend = 0;
@@ -394,8 +399,9 @@ bool launch_opt(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t 
 }
 template <int EPI>
 bool launch_one(const GemmArgs& p, int nblk, int dynamic, int* ctr, hipStream_t s) {
-    switch (p.opt & 5) {          // A/B builds (trace_op_set_gemm_variant(540 + opt)): bit 0 = without the re-aligning barrier, bit 2 = with the L2 touches of the A panel
+    switch (p.opt & 7) {          // A/B builds (trace_op_set_gemm_variant(540 + opt)): bit 0 = without the re-aligning barrier, bit 2 = with the L2 touches of the A panel; 2 = the check build (vmcnt(0) waits)
         case 1: return launch_opt<EPI, 1>(p, nblk, dynamic, ctr, s);
+        case 2: return launch_opt<EPI, 2>(p, nblk, dynamic, ctr, s);
         case 4: return launch_opt<EPI, 4>(p, nblk, dynamic, ctr, s);
         case 5: return launch_opt<EPI, 5>(p, nblk, dynamic, ctr, s);
         default: return launch_opt<EPI, 0>(p, nblk, dynamic, ctr, s);

@@ -499,7 +499,7 @@ def main():
     # prefill stage is timed into slots of the other bank (pipelined) or over the first slots (the same prompts again)
     slot_base = ((args.steps - 1) % 2) * B if pipelined else 0
     pf_slot = (B if slot_base == 0 else 0) if pipelined else 0
-    npf = min(B, eng.PREFILL_GROUP)
+    npf = min(B, eng.prefill_group(L))           # what encode_prefill() puts through one pass at this prompt length
     embs = []
     for b in range(npf):
         eng.encode_video(videos[b], ts[b])

@@ -114,8 +114,10 @@ int trace_llm_prefill(trace_ctx* ctx, int slot, const void* embeds, int L, void*
  * [L, hidden] bf16 device (the embeds_out of two trace_splice_embeds calls) -> KV slots slot0 and slot0 + 1.  Same results as two
  * trace_llm_prefill calls. */
 int trace_llm_prefill_pair(trace_ctx* ctx, int slot0, const void* embeds0, const void* embeds1, int L, void* stream);
-/* The same for n <= 4 prompts of equal length: embeds = HOST array of n device pointers ([L, hidden] bf16 each) -> KV slots slot0 .. slot0 + n - 1
- * (M = 4 L = 7868 at the C2 shape fills the 256x256 tile grid of every projection in whole rounds). */
+/* The same for n <= 8 prompts of equal length while n * L <= max(4 * max_ctx, min(8192, 8 * max_ctx)) rows (the prefill workspaces; more -> TRACE_ERR_ARG):
+ * embeds = HOST array of n device pointers ([L, hidden] bf16 each) -> KV slots slot0 .. slot0 + n - 1.  M = 4 L = 7868 at the C2 shape fills the 256x256
+ * tile grid of every projection in whole rounds; at the C4 shape (L = 1086) seven prompts do (30 row panels: the o / down grid in 1.9 rounds where four
+ * prompts' 17 panels need 2 rounds for 1.06 of work).  Results per prompt do not depend on n. */
 int trace_llm_prefill_multi(trace_ctx* ctx, int slot0, const void* const* embeds, int n, int L, void* stream);
 
 /* The head stage of forward() for EVERY position (trace_mistral.py:190-252: lm_head | sync_head | time_head | score_head, fp32,

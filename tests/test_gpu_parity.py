@@ -177,6 +177,60 @@ def test_prefill_last_layer_rows_shortcut_is_bit_identical(setup):
         assert torch.equal(a, b), f"last-rows prefill differs from the full last layer: max |d| {(a - b)[torch.isfinite(a)].abs().max().item()}"
 
 
+def test_prefill_run_of_eight_equals_each_prompt_alone(setup):
+    """Round 6: trace_llm_prefill_multi takes up to 8 equal-length prompts while n x L fits the prefill workspaces (max(4 max_ctx, min(8192, 8 max_ctx)) rows).
+    A prompt's result must not depend on how many neighbours share its pass: the first logits and three decode steps of a run of eight, of seven and of five are
+    bit-identical to each prompt prefilled alone.  One prompt too many for the workspace is a TRACE_ERR_ARG, not a crash; the host's choice of the run length
+    (TraceEngine.prefill_group) is 4 at the C2 prompt length and 7 at the C4 one."""
+    from trace_amd import _lib
+    cfg, _, ora, E, frames = setup
+    eng = TraceEngine(cfg, max_batch=8, max_ctx=256, max_frames=4, max_new_tokens=16)
+    eng.load_weights(synth.state_dict(cfg).items())
+    eng.encode_video(frames, E["timestamps"].tolist())
+    L, emb = eng.splice(E["input_ids"].tolist(), want_output=True)
+    assert eng.prefill_rows == 2048 and 8 * L <= eng.prefill_rows
+    embs = [(emb.float() * f).to(emb.dtype) for f in (1.0, 0.5, -0.25, 0.75, -1.0, 0.3, 1.25, -0.6)]
+
+    def run(slots):
+        lg = [eng.decode_begin(slots, [1] * len(slots), 8, eos=-1, want_logits=True).clone()]
+        for _ in range(3):
+            lg.append(eng.decode_steps(1, use_graph=False, want_logits=True).clone())
+        return torch.stack(lg)                     # [4 steps, len(slots), NV]
+
+    alone = []
+    for b in range(8):
+        eng.prefill(0, L, embeds=embs[b])
+        alone.append(run([0])[:, 0])
+    for n in (8, 7, 5):
+        eng.prefill_multi(0, embs[:n])
+        got = run(list(range(n)))
+        for b in range(n):
+            assert torch.equal(got[:, b], alone[b]), (n, b)
+    big = TraceEngine(cfg, max_batch=8, max_ctx=2048, max_frames=4, max_new_tokens=8)       # 4 x 2048 = 8192 rows: four 2000-row prompts fit, five do not
+    try:
+        big.load_weights(synth.state_dict(cfg).items())
+        assert big.prefill_rows == 8192
+        long_embs = [(torch.randn(2000, cfg.hidden_size, device="cuda") * 0.02).to(emb.dtype) for _ in range(5)]
+        big.prefill_multi(0, long_embs[:4])
+        with pytest.raises(AssertionError):
+            big.prefill_multi(0, long_embs)                                                  # the host wrapper refuses ...
+        import ctypes as C
+        ptrs = (C.c_void_p * 5)(*[e.data_ptr() for e in long_embs])
+        with pytest.raises(_lib.TraceHipError, match="prefill workspace"):                   # ... and so does the library (TRACE_ERR_ARG through errcheck)
+            big.lib.trace_llm_prefill_multi(big.h, 0, ptrs, 5, 2000, None)
+    finally:
+        big.close()
+    eng.close()
+    # the host's rule at the benchmark prompt lengths (7B widths; no device work)
+    class _E(TraceEngine):
+        def __init__(self, cfg_, max_ctx):
+            self.cfg, self.max_ctx = cfg_, max_ctx
+        def __del__(self):
+            pass
+    c7 = tcfg.trace_7b(128)
+    assert _E(c7, 2240).prefill_group(1967) == 4 and _E(c7, 1152).prefill_group(1086) == 7 and _E(c7, 3904).prefill_group(3834) == 4
+
+
 def test_graph_replay_equals_eager(setup):
     cfg, eng, ora, E, frames = setup
     forced = E["forced_ids"].tolist()

@@ -36,7 +36,9 @@ struct LlmLayer {
 };
 struct StcBlock { bf16_t *w1, *n1w, *n1b, *wdw, *n2w, *n2b, *fc1w, *fc1b, *fc2w, *fc2b, *w3, *n3w, *n3b, *wd, *ndw, *ndb; int cin, rd; };
 
-constexpr int PF_MAX = 4;        // equal-length prompts one prefill pass can take (trace_llm_prefill_multi)
+constexpr int PF_MAX = 4;        // equal-length prompts of max_ctx rows one prefill pass can take: the workspaces hold pf_rows() rows, and a pass takes up to PF_MAX_N
+constexpr int PF_MAX_N = 8;      // SHORTER prompts while n x L fits them (round 6: four 1086-row Charades prompts are 17 row panels = 1.06 rounds of the o / down tile grid)
+static size_t pf_rows(int max_ctx) { return std::max<size_t>((size_t)PF_MAX * max_ctx, std::min<size_t>(8192, (size_t)PF_MAX_N * max_ctx)); }
 constexpr int MAX_SLOTS = 512;   // KV-cache sequence slots per context (a decode batch is at most SK_ROWS of them)
 static int g_ctx_per_dev[16] = {0};
 
@@ -253,10 +255,11 @@ extern "C" int trace_ctx_create(const trace_config* cfg, int device_id, trace_ct
     // --- prefill workspaces ---
     const size_t Lm = c->max_ctx;
     // prefill workspaces hold PF_MAX sequences (trace_llm_prefill_pair / _multi)
-    A(c->pX, PF_MAX * Lm * H); A(c->pH, PF_MAX * Lm * H); A(c->pQKV, PF_MAX * Lm * c->QKV);
-    A(c->pO, PF_MAX * Lm * H); A(c->pACT, PF_MAX * Lm * I);
+    const size_t PR = pf_rows(c->max_ctx);
+    A(c->pX, PR * H); A(c->pH, PR * H); A(c->pQKV, PR * c->QKV);
+    A(c->pO, PR * H); A(c->pACT, PR * I);
     A(c->d_kind, Lm); A(c->d_row, Lm);
-    if (c->fp8) { A(c->pA8, PF_MAX * Lm * std::max(H, I)); A(c->psa, PF_MAX * Lm); A(c->dA8, (size_t)SK_ROWS * std::max(H, I)); A(c->dsa, SK_ROWS); A(c->dH8, (size_t)SK_ROWS * H); A(c->dsh, SK_ROWS); }
+    if (c->fp8) { A(c->pA8, PR * std::max(H, I)); A(c->psa, PR); A(c->dA8, (size_t)SK_ROWS * std::max(H, I)); A(c->dsa, SK_ROWS); A(c->dH8, (size_t)SK_ROWS * H); A(c->dsh, SK_ROWS); }
     // --- decode ---
     A(c->dX, SK_ROWS * H); A(c->dH, SK_ROWS * H); A(c->dQKV, SK_ROWS * (size_t)c->QKV); A(c->dO, SK_ROWS * H); A(c->dACT, SK_ROWS * I);
     A(c->xlast, (size_t)std::max(c->max_B, 64) * H);
@@ -1023,11 +1026,12 @@ extern "C" int trace_llm_prefill_pair(trace_ctx* c, int slot0, const void* embed
     return prefill_impl(c, slot0, 2, L, nullptr, s);
 }
 
-// n <= 4 prompts of EQUAL spliced length in one pass -> KV slots slot0 .. slot0 + n - 1.  Four 1967-row prompts give the GEMMs M = 7868 = 31 row tiles:
+// n <= 8 prompts of EQUAL spliced length in one pass while n x L <= max(4 max_ctx, min(8192, 8 max_ctx)) rows (the prefill workspaces) -> KV slots slot0 .. slot0 + n - 1.  Four 1967-row prompts give the GEMMs M = 7868 = 31 row tiles:
 // qkv 744 tiles = 2.9 rounds of the 256 CUs (a pair: 384 = 1.5 rounds, a quarter of the second round's CUs idle), o / down 496 = 1.94, gate|up 13.6
 extern "C" int trace_llm_prefill_multi(trace_ctx* c, int slot0, const void* const* embeds, int n, int L, void* stream) {
     if (!c || !c->finalized) return fail(TRACE_ERR_STATE, "context not finalized");
-    if (!embeds || n < 1 || n > PF_MAX || slot0 < 0 || slot0 + n > c->max_B || L < 1 || L > c->max_ctx) return fail(TRACE_ERR_ARG, "bad slot / n / L / embeds");
+    if (!embeds || n < 1 || n > PF_MAX_N || slot0 < 0 || slot0 + n > c->max_B || L < 1 || L > c->max_ctx) return fail(TRACE_ERR_ARG, "bad slot / n / L / embeds");
+    if ((size_t)n * L > pf_rows(c->max_ctx)) return fail(TRACE_ERR_ARG, "n x L exceeds the prefill workspace (max(4 max_ctx, min(8192, 8 max_ctx)) rows)");
     hipStream_t s = (hipStream_t)stream;
     for (int i = 0; i < n; ++i) {
         if (!embeds[i]) return fail(TRACE_ERR_ARG, "null embeds");

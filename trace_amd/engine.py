@@ -281,12 +281,38 @@ class TraceEngine:
         _lib.check(self.lib.trace_llm_prefill_pair(self.h, slot0, _ptr(embeds0.contiguous()), _ptr(embeds1.contiguous()),
                                                    embeds0.shape[0], _stream()))
 
-    PREFILL_GROUP = 4          # equal-length prompts one prefill pass takes (trace_llm_prefill_multi)
+    PREFILL_GROUP = 4          # equal-length prompts of max_ctx rows one prefill pass takes (trace_llm_prefill_multi); shorter prompts: prefill_group(L)
+    PREFILL_GROUP_MAX = 8
+
+    @property
+    def prefill_rows(self) -> int:
+        """rows the prefill workspaces hold (engine.hip pf_rows): n prompts of L rows fit one pass while n * L <= this"""
+        return max(self.PREFILL_GROUP * self.max_ctx, min(8192, self.PREFILL_GROUP_MAX * self.max_ctx))
+
+    def prefill_group(self, L: int) -> int:
+        """How many equal-length prompts of L rows to put through one prefill pass: the n <= 8 that fits the workspaces and minimises the projections' cost per
+        prompt in whole rounds of the 256 CUs — a 256 x 256 tile occupies a CU for one tile time whether its round is full or not, so cost(n) = sum over the four
+        projections of ceil(row panels x column tiles / #CUs) x K.  C2 (L = 1967): 4 (31 row panels; 8 would not fit).  C4 (L = 1086): 7 (30 panels: the o / down
+        grid in 1.9 rounds; four prompts' 17 panels take 2 rounds for 1.06 of work: -22 % of the projections' time per prompt)."""
+        c = self.cfg
+        H, I = c.hidden_size, c.intermediate_size
+        qkv = (c.num_attention_heads + 2 * c.num_key_value_heads) * (H // c.num_attention_heads)
+        shapes = ((qkv, H), (H, H), (2 * I, H), (H, I))          # (N, K) of qkv, o, gate|up, down
+        ncu = 256
+        best, best_cost = 1, None
+        for n in range(1, self.PREFILL_GROUP_MAX + 1):
+            if n * L > self.prefill_rows:
+                break
+            panels = -(-n * L // 256)
+            cost = sum(-(-panels * -(-N // 256) // ncu) * K for N, K in shapes) / n
+            if best_cost is None or cost < best_cost * 0.995:      # (ties go to the smaller group: less latency to the first prefilled slot)
+                best, best_cost = n, cost
+        return best
 
     def prefill_multi(self, slot0: int, embeds: Sequence[torch.Tensor]):
         """up to 4 spliced prompts of equal length -> KV slots slot0 .. slot0 + n - 1 in one pass"""
         n = len(embeds)
-        assert 1 <= n <= self.PREFILL_GROUP and all(e.shape == embeds[0].shape and e.dtype == self.dtype and e.is_cuda for e in embeds)
+        assert 1 <= n <= self.PREFILL_GROUP_MAX and n * embeds[0].shape[0] <= self.prefill_rows and all(e.shape == embeds[0].shape and e.dtype == self.dtype and e.is_cuda for e in embeds)
         keep = [e.contiguous() for e in embeds]
         ptrs = (C.c_void_p * n)(*[e.data_ptr() for e in keep])
         _lib.check(self.lib.trace_llm_prefill_multi(self.h, slot0, ptrs, n, keep[0].shape[0], _stream()))
@@ -423,7 +449,7 @@ class TraceEngine:
                 self._bracket("prefill", lambda: self.prefill(slot0, L1), rec)
                 continue
             L, emb = self.splice(input_ids[b], want_output=True)
-            if held and (held[0].shape[0] != L or len(held) == self.PREFILL_GROUP):
+            if held and (held[0].shape[0] != L or len(held) == self.prefill_group(held[0].shape[0])):
                 flush()
             if not held:
                 held_slot0 = slot0 + b
